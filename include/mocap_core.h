@@ -1,0 +1,158 @@
+/* mocap_core.h -- C ABI of the MI355X-native multi-view marker-tracking core.
+ *
+ * Drop-in boundary for the hot path of jyjblrd/Low-Cost-Mocap
+ * (computer_code/api/helpers.py:203-421).  The reference has no FFI/plugin layer:
+ * the seam is four module-level Python functions imported by name at
+ * computer_code/api/index.py:1.  A Python module with the same four names
+ * (low-cost-mocap_amd/mocap_core/helpers.py) binds these entry points with ctypes;
+ * INTEGRATION.md shows the stub a maintainer adds to the reference.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; all matrices row-major; doubles unless stated.
+ *   - "host" entry points take caller-owned host buffers, copy in/out and return
+ *     after the work finished.  "_dev" entry points take DEVICE pointers, enqueue on
+ *     the context's stream and return immediately (mocap_synchronize to wait).
+ *   - the library never retains a caller pointer past return.
+ *   - return value: 0 = ok, negative = error (MOCAP_E_*); text in mocap_last_error.
+ *     Per-frame conditions (candidate/root cap overflow) are reported in `status`,
+ *     never by aborting.
+ *   - a context is internally locked: calls on one context from several threads
+ *     serialise (Flask-SocketIO handlers and the MJPEG generator run on different
+ *     threads with no locking, reference helpers.py:84-94 vs :165-186).
+ *   - unseen observations are NaN (the reference uses None / [None, None]).
+ */
+#ifndef MOCAP_CORE_H
+#define MOCAP_CORE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mocap_ctx mocap_ctx;
+
+enum {
+  MOCAP_OK = 0,
+  MOCAP_E_ARG = -1,      /* bad argument (null pointer, size out of range)          */
+  MOCAP_E_HIP = -2,      /* a HIP runtime call failed                                */
+  MOCAP_E_NOCAMS = -3,   /* mocap_set_cameras has not been called                    */
+  MOCAP_E_LIMIT = -4,    /* configuration exceeds a compiled limit (see mocap_limits) */
+  MOCAP_E_NOCONV = -5    /* solver hit its iteration cap (result still written)      */
+};
+
+/* per-frame status bits written by mocap_match_triangulate* */
+enum {
+  MOCAP_ST_ROOT_OVERFLOW = 1, /* more roots than K_max: frame output invalid          */
+  MOCAP_ST_CAND_OVERFLOW = 2, /* a root has more than G_cap candidate groups: invalid */
+  MOCAP_ST_HIT_OVERFLOW = 4   /* reserved                                             */
+};
+
+/* flags for mocap_set_options */
+enum {
+  MOCAP_OPT_F32_ROUNDING = 1 /* default ON: reproduce OpenCV's float32 roundings of the
+                                epipolar line (helpers.py:363) and of the projected point /
+                                pixel (helpers.py:231-237).  OFF = all-double arithmetic. */
+};
+
+/* ---------------------------------------------------------------- lifetime */
+int mocap_create(int device_id, mocap_ctx** out);
+void mocap_destroy(mocap_ctx* ctx);
+const char* mocap_last_error(const mocap_ctx* ctx);
+const char* mocap_version(void);
+/* enqueue on an existing hipStream_t (e.g. the host framework's current stream);
+ * NULL restores the context's own stream. */
+int mocap_set_stream(mocap_ctx* ctx, void* hip_stream);
+int mocap_synchronize(mocap_ctx* ctx);
+int mocap_set_options(mocap_ctx* ctx, uint32_t flags);
+/* compiled limits: max cameras, max blobs per camera */
+void mocap_limits(int* max_cameras, int* max_blobs);
+
+/* ---------------------------------------------------------------- cameras
+ * Replaces the per-call rebuild of P = K [R|t] (helpers.py:305-308, :351-355) and the
+ * per-(root, camera) cv.sfm.fundamentalFromProjections (helpers.py:362): builds the
+ * projection table (with the reference's "intrinsics by compacted index" quirk,
+ * helpers.py:296-298,305-307) and the C x C fundamental table once.
+ * K [C][9], R [C][9], t [C][3]: host pointers, copied.  Natural call site:
+ * Cameras.start_trangulating_points (helpers.py:171-175). */
+int mocap_set_cameras(mocap_ctx* ctx, int C, const double* K, const double* R, const double* t);
+/* read back the host-side fundamental table F [C][C][9] (tests / debugging) */
+int mocap_get_fundamental(mocap_ctx* ctx, double* F);
+
+/* ---------------------------------------------------------------- triangulation
+ * Replaces triangulate_points (helpers.py:330-336) + calculate_reprojection_errors
+ * (helpers.py:203-211) for explicit correspondences.
+ *   obs [N][C][2]  pixel observations, NaN = unseen
+ *   xyz [N][3]     DLT point (NaN row when < 2 views; the reference yields [None]*3)
+ *   err [N]        mean squared reprojection error in px^2 (NaN when < 2 views; the
+ *                  reference skips the entry).  err may be NULL. */
+int mocap_triangulate(mocap_ctx* ctx, int64_t N, const double* obs, double* xyz, double* err);
+int mocap_triangulate_dev(mocap_ctx* ctx, int64_t N, const double* d_obs, double* d_xyz, double* d_err);
+
+/* ---------------------------------------------------------------- frame path
+ * Replaces find_point_correspondance_and_object_points (helpers.py:339-421) for a
+ * batch of independent frames.
+ *   blobs  [F][C][M_max][2] float32 pixel centroids (slots >= counts are ignored)
+ *   counts [F][C]           int32 blobs per camera (0 = the reference's [[None, None]])
+ *   gate_px                 epipolar gate, the reference hard-codes 5 (helpers.py:375,383)
+ *   K_max                   capacity for roots / output points per frame
+ *   G_cap                   cap on candidate groups per root (the reference enumerates the
+ *                           full Cartesian product, helpers.py:394-400)
+ * outputs, root order as the reference (camera-0 blobs first, then leftovers of camera 1, ...):
+ *   xyz    [F][K_max][3]    winning DLT point per kept root
+ *   err    [F][K_max]       its mean squared reprojection error (px^2)
+ *   corr   [F][K_max][C]    int16 blob index per camera of the winning group, -1 = none
+ *   n_out  [F]              number of points written for the frame (slots beyond are untouched)
+ *   status [F]              MOCAP_ST_* bits; non-zero = that frame's outputs are invalid,
+ *                           re-submit it with larger caps
+ *   n_cand [F]              (may be NULL) candidate groups evaluated for the frame */
+int mocap_match_triangulate(mocap_ctx* ctx, int64_t n_frames, int M_max, const float* blobs,
+                            const int32_t* counts, double gate_px, int K_max, int64_t G_cap,
+                            double* xyz, double* err, int16_t* corr, int32_t* n_out,
+                            int32_t* status, int32_t* n_cand);
+int mocap_match_triangulate_dev(mocap_ctx* ctx, int64_t n_frames, int M_max, const float* d_blobs,
+                                const int32_t* d_counts, double gate_px, int K_max, int64_t G_cap,
+                                double* d_xyz, double* d_err, int16_t* d_corr, int32_t* d_n_out,
+                                int32_t* d_status, int32_t* d_n_cand);
+
+/* ---------------------------------------------------------------- bundle adjustment
+ * Parameter vector as the reference (helpers.py:278-285):
+ *   x = [f0, (f_i, rotvec_i[3], t_i[3]) for i = 1..C-1],  n = 1 + 7 (C-1); camera 0 = (I, 0).
+ * The focal entries are carried but have no effect, exactly as in the reference
+ * (helpers.py:267-270 writes them into a temporary copy).  Intrinsics come from
+ * mocap_set_cameras (R, t given there are ignored by the BA entry points).
+ *
+ * mocap_ba_residuals: replaces residual_function (helpers.py:264-276) for a batch of P
+ * parameter vectors: r[p][i] = mean squared reprojection error of point i re-triangulated
+ * with the poses of params[p] (float64; the reference then casts to float32);
+ * NaN where the point has < 2 views (the reference drops the entry).
+ *   params [P][n], obs [N][C][2] (NaN unseen), r [P][N] */
+int mocap_ba_residuals(mocap_ctx* ctx, int P, const double* params, int64_t N, const double* obs,
+                       double* r);
+
+/* mocap_ba_normal_eq: one linearisation at x: forward-difference Jacobian (step rule of
+ * scipy.optimize._numdiff for the given residual precision: rel_step = sqrt(eps),
+ * h = rel_step * sign(x) * max(1, |x|)), Cauchy loss scaling (scipy _lsq/least_squares.py
+ * `cauchy`, `scale_for_robust_loss_function`), then the dense contractions on the matrix
+ * cores:  JtJ [n][n] = J^T J,  Jtr [n] = J^T f,  cost = 0.5 * sum(rho(f^2)).
+ *   f32_residuals != 0 reproduces the reference's float32 cast of the residuals
+ *   (helpers.py:273) and the resulting float32 step size.
+ *   J_out (may be NULL): [m][n] the scaled Jacobian, m = number of valid points (returned in *m_out) */
+int mocap_ba_normal_eq(mocap_ctx* ctx, const double* x, int64_t N, const double* obs,
+                       int f32_residuals, int use_cauchy, double* JtJ, double* Jtr, double* cost,
+                       double* J_out, int64_t* m_out);
+
+/* mocap_ba_solve: resident Levenberg-Marquardt / trust-region loop (the algorithm of
+ * scipy.optimize.least_squares(method="trf", loss="cauchy"), helpers.py:287-289, restated
+ * on the normal equations).  x [n] in/out.
+ *   ftol, xtol, gtol    termination tolerances (reference: ftol=1e-2, others 1e-8)
+ *   max_iter            cap on LM iterations (0 = 100*n like scipy's max_nfev)
+ *   f32_residuals       see above
+ *   info [8]            (may be NULL) {iterations, nfev, status, cost0, cost, optimality, m, elapsed_ms} */
+int mocap_ba_solve(mocap_ctx* ctx, double* x, int64_t N, const double* obs, double ftol, double xtol,
+                   double gtol, int max_iter, int f32_residuals, int use_cauchy, double* info);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOCAP_CORE_H */

@@ -1,0 +1,186 @@
+"""Seeded synthetic rigs and blob streams (SURVEY.md section 8d / BASELINE.md section 3).
+
+The reference ships no data, so every workload is generated: C cameras on a ring
+looking at the origin, re-expressed relative to camera 0 (the reference fixes
+camera 0 at (I, 0): computer_code/api/index.py:235-238, helpers.py:250-253),
+markers uniform in a cube, pinhole projection + Gaussian pixel noise, `int()`
+truncation exactly like the reference blob finder (helpers.py:154-155), a random
+per-camera permutation and per-(camera, marker) dropout.
+
+Layouts produced here are the ones the C-ABI consumes (include/mocap_core.h):
+  blobs  f32 [F][C][M_max][2]   (unused slots = NaN)
+  counts i32 [F][C]
+"""
+import numpy as np
+
+DEFAULT_K = [[320.0, 0.0, 160.0], [0.0, 320.0, 160.0], [0.0, 0.0, 1.0]]  # camera-params.json:3-5
+VGA_K = [[640.0, 0.0, 320.0], [0.0, 640.0, 240.0], [0.0, 0.0, 1.0]]
+
+
+def _look_at(cam_pos, target=np.zeros(3)):
+    """World->camera rotation with +z along the optical axis, +y roughly world -z (image down)."""
+    z = target - cam_pos
+    z = z / np.linalg.norm(z)
+    up = np.array([0.0, 0.0, 1.0])
+    x = np.cross(z, up)
+    x = x / np.linalg.norm(x)
+    y = np.cross(z, x)
+    return np.stack([x, y, z])
+
+
+def ring_rig(num_cameras, radius=3.0, height=1.5, K=None, image_size=None):
+    """Returns dict(K (C,3,3), R (C,3,3), t (C,3), image_size (w,h)) relative to camera 0.
+
+    64-camera stress rig: two rings of C/2 at heights 1.0 / 2.5 m."""
+    C = int(num_cameras)
+    K = np.array(DEFAULT_K if K is None else K, dtype=np.float64)
+    if image_size is None:
+        image_size = (int(round(2 * K[0, 2])), int(round(2 * K[1, 2])))
+    Rw, tw = [], []
+    for i in range(C):
+        if C >= 32:
+            half = C // 2
+            ring, k, n = (0, i, half) if i < half else (1, i - half, C - half)
+            h = 1.0 if ring == 0 else 2.5
+            ang = 2 * np.pi * (k + 0.5 * ring) / n
+        else:
+            h = height
+            ang = 2 * np.pi * i / C
+        pos = np.array([radius * np.cos(ang), radius * np.sin(ang), h])
+        R = _look_at(pos)
+        Rw.append(R)
+        tw.append(-R @ pos)
+    Rw, tw = np.array(Rw), np.array(tw)
+    R0, t0 = Rw[0], tw[0]
+    R = np.array([Rw[i] @ R0.T for i in range(C)])
+    t = np.array([tw[i] - R[i] @ t0 for i in range(C)])
+    R[0] = np.eye(3)
+    t[0] = 0.0
+    # markers live around the world origin == this point in camera-0 coordinates
+    centre = R0 @ np.zeros(3) + t0
+    return {"K": np.repeat(K[None], C, axis=0), "R": R, "t": t,
+            "image_size": image_size, "centre": centre, "R0": R0}
+
+
+def rig_to_pose_dicts(rig):
+    """Poses in the JSON shape the reference's socket API carries ({"R": 3x3, "t": 3})."""
+    return [{"R": rig["R"][i].tolist(), "t": rig["t"][i].tolist()} for i in range(len(rig["R"]))]
+
+
+def perturb_rig(rig, rng, rot_sigma=0.02, trans_sigma=0.05):
+    """Initial poses for BA: truth (+) N(0, rot_sigma rad) / N(0, trans_sigma m); camera 0 untouched."""
+    from scipy.spatial.transform import Rotation
+    out = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in rig.items()}
+    for i in range(1, len(rig["R"])):
+        dR = Rotation.from_rotvec(rng.normal(0, rot_sigma, 3)).as_matrix()
+        out["R"][i] = dR @ rig["R"][i]
+        out["t"][i] = rig["t"][i] + rng.normal(0, trans_sigma, 3)
+    return out
+
+
+def _sample_markers(rng, n_frames, n_markers, half_extent, min_sep):
+    pts = rng.uniform(-half_extent, half_extent, size=(n_frames, n_markers, 3))
+    if min_sep > 0 and n_markers > 1:
+        for _ in range(20):
+            d = np.linalg.norm(pts[:, :, None, :] - pts[:, None, :, :], axis=-1)
+            d[:, np.arange(n_markers), np.arange(n_markers)] = np.inf
+            # resample the higher-indexed member of every too-close pair
+            close = np.triu(np.ones((n_markers, n_markers), bool), 1)[None] & (d < min_sep)
+            bad = close.any(axis=1)
+            if not bad.any():
+                break
+            pts[bad] = rng.uniform(-half_extent, half_extent, size=(int(bad.sum()), 3))
+    return pts
+
+
+def make_blob_stream(rig, n_frames, n_markers, seed=0, noise_px=0.3, dropout=0.05,
+                     half_extent=0.7, min_sep=0.05, truncate=True, m_max=None, shuffle=True):
+    """Returns (blobs f32 [F][C][M_max][2] NaN-padded, counts i32 [F][C], truth dict)."""
+    rng = np.random.default_rng(seed)
+    C = len(rig["R"])
+    F, M = int(n_frames), int(n_markers)
+    m_max = M if m_max is None else int(m_max)
+    world = _sample_markers(rng, F, M, half_extent, min_sep)
+    # world -> camera-0 coordinates
+    X0 = world @ rig["R0"].T + rig["centre"]
+    blobs = np.full((F, C, m_max, 2), np.nan, dtype=np.float32)
+    counts = np.zeros((F, C), dtype=np.int32)
+    ident = np.full((F, C, m_max), -1, dtype=np.int32)
+    w, h = rig["image_size"]
+    for c in range(C):
+        Xc = X0 @ rig["R"][c].T + rig["t"][c]
+        K = rig["K"][c]
+        u = K[0, 0] * Xc[..., 0] / Xc[..., 2] + K[0, 2] + rng.normal(0, noise_px, (F, M))
+        v = K[1, 1] * Xc[..., 1] / Xc[..., 2] + K[1, 2] + rng.normal(0, noise_px, (F, M))
+        if truncate:
+            u, v = np.trunc(u), np.trunc(v)
+        seen = (rng.random((F, M)) >= dropout) & (Xc[..., 2] > 0)
+        seen &= (u >= 0) & (u < w) & (v >= 0) & (v < h)
+        # random per-frame order, seen blobs first
+        key = rng.random((F, M)) if shuffle else np.tile(np.arange(M, dtype=np.float64) / M, (F, 1))
+        key = np.where(seen, key, 2.0)
+        order = np.argsort(key, axis=1, kind="stable")
+        n = seen.sum(axis=1).astype(np.int32)
+        uu = np.take_along_axis(u, order, 1)
+        vv = np.take_along_axis(v, order, 1)
+        valid = np.arange(M)[None, :] < n[:, None]
+        mm = min(M, m_max)
+        blobs[:, c, :mm, 0] = np.where(valid, uu, np.nan)[:, :mm]
+        blobs[:, c, :mm, 1] = np.where(valid, vv, np.nan)[:, :mm]
+        ident[:, c, :mm] = np.where(valid, order, -1)[:, :mm]
+        counts[:, c] = np.minimum(n, m_max)
+    return blobs, counts, {"points_cam0": X0, "ident": ident}
+
+
+def frame_to_reference_lists(blobs_f, counts_f, as_int=True):
+    """One frame -> the nested lists `_find_dot` would produce (helpers.py:150-163):
+    per camera a list of [x, y] Python ints, or [[None, None]] when the camera saw nothing."""
+    out = []
+    for c in range(blobs_f.shape[0]):
+        n = int(counts_f[c])
+        if n == 0:
+            out.append([[None, None]])
+            continue
+        if as_int:
+            out.append([[int(blobs_f[c, k, 0]), int(blobs_f[c, k, 1])] for k in range(n)])
+        else:
+            out.append([[float(blobs_f[c, k, 0]), float(blobs_f[c, k, 1])] for k in range(n)])
+    return out
+
+
+def make_ba_observations(rig, n_points, seed=0, noise_px=0.3, dropout=0.05, half_extent=0.7,
+                         truncate=False):
+    """Calibration capture set: obs f64 [N][C][2] with NaN for unseen (one marker waved around;
+    computer_code/api/index.py:232 receives it as (N, C, 2) with None = unseen)."""
+    rng = np.random.default_rng(seed)
+    C = len(rig["R"])
+    world = rng.uniform(-half_extent, half_extent, size=(n_points, 3))
+    X0 = world @ rig["R0"].T + rig["centre"]
+    obs = np.full((n_points, C, 2), np.nan)
+    w, h = rig["image_size"]
+    for c in range(C):
+        Xc = X0 @ rig["R"][c].T + rig["t"][c]
+        K = rig["K"][c]
+        u = K[0, 0] * Xc[:, 0] / Xc[:, 2] + K[0, 2] + rng.normal(0, noise_px, n_points)
+        v = K[1, 1] * Xc[:, 1] / Xc[:, 2] + K[1, 2] + rng.normal(0, noise_px, n_points)
+        if truncate:
+            u, v = np.trunc(u), np.trunc(v)
+        seen = (rng.random(n_points) >= dropout) & (Xc[:, 2] > 0) & (u >= 0) & (u < w) & (v >= 0) & (v < h)
+        obs[seen, c, 0] = u[seen]
+        obs[seen, c, 1] = v[seen]
+    return obs, X0
+
+
+def obs_to_reference_array(obs, as_int=False):
+    """(N, C, 2) NaN-coded -> object ndarray with None, as np.array(cameraPoints) yields (index.py:232)."""
+    N, C, _ = obs.shape
+    out = np.empty((N, C, 2), dtype=object)
+    for n in range(N):
+        for c in range(C):
+            if np.isnan(obs[n, c, 0]):
+                out[n, c, 0] = None
+                out[n, c, 1] = None
+            else:
+                out[n, c, 0] = int(obs[n, c, 0]) if as_int else float(obs[n, c, 0])
+                out[n, c, 1] = int(obs[n, c, 1]) if as_int else float(obs[n, c, 1])
+    return out

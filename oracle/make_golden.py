@@ -1,0 +1,235 @@
+"""TEST INFRASTRUCTURE ONLY (oracle/).  Generates tests/golden/*.npz by running the
+REFERENCE'S OWN functions (/root/reference/computer_code/api/helpers.py) through the
+stub harness (oracle/ref_harness.py).  Runs only in the build container, where
+/root/reference exists; the vectors are committed so the GPU box never needs it.
+
+    python -m oracle.make_golden            # from the repo root
+
+The reference ships no tests or vectors, so these are the
+pinning set: reference outputs on seeded synthetic inputs.  The three OpenCV calls
+inside are the NumPy restatements of oracle/cv_restate.py (PARITY UNPINNED there).
+"""
+import os
+import sys
+
+import numpy as np
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, _ROOT)
+sys.path.insert(0, os.path.join(_ROOT, "low-cost-mocap_amd"))
+
+from mocap_core import synth  # noqa: E402
+from oracle import ref_harness  # noqa: E402
+
+OUT = os.path.join(_ROOT, "tests", "golden")
+
+# Default camera poses of the reference UI (computer_code/src/App.tsx:44): a really calibrated
+# 4-camera rig.  Numeric fixture only.
+APP_TSX_POSES = [
+    {"R": [[1, 0, 0], [0, 1, 0], [0, 0, 1]], "t": [0, 0, 0]},
+    {"R": [[-0.0008290000610233772, -0.7947131755287576, 0.6069845808584402],
+           [0.7624444396180684, 0.3922492478955913, 0.5146056781855716],
+           [-0.6470531579819294, 0.46321862674804054, 0.6055994671226776]],
+     "t": [-2.6049886186449047, -2.173986915510569, 0.7303458563542193]},
+    {"R": [[-0.9985541623963866, -0.028079891357569067, -0.045837806036037466],
+           [-0.043210651917521686, -0.08793122558361385, 0.9951888962042462],
+           [-0.03197537054848707, 0.995730696156702, 0.0865907408997996]],
+     "t": [0.8953888630067902, -3.4302652822708373, 3.70967106300893]},
+    {"R": [[-0.4499864100408215, 0.6855400696798954, -0.5723172578577878],
+           [-0.7145273934510732, 0.10804105689305427, 0.6912146801345055],
+           [0.5356891214002657, 0.7199735709654319, 0.4412201517663212]],
+     "t": [2.50141072072536, -2.313616767292231, 1.8529907514099284]},
+]
+# computer_code/api/camera-params copy.json:3-21 (three really calibrated intrinsics)
+CALIBRATED_K = [
+    [[268.66976067, 0, 123.58679484], [0, 268.57495496, 167.56126939], [0, 0, 1]],
+    [[269.95158059, 0, 139.37072352], [0, 270.09608831, 160.36482761], [0, 0, 1]],
+    [[269.95158059, 0, 139.37072352], [0, 270.09608831, 160.36482761], [0, 0, 1]],
+]
+
+
+def rig_from_poses(poses, Ks, image_size=(320, 320)):
+    """Wrap explicit poses as a synth rig; markers are placed around the point closest to all optical axes."""
+    R = np.array([np.array(p["R"], dtype=np.float64) for p in poses])
+    t = np.array([np.array(p["t"], dtype=np.float64).reshape(3) for p in poses])
+    A = np.zeros((3, 3))
+    b = np.zeros(3)
+    for i in range(len(R)):
+        c = -R[i].T @ t[i]
+        d = R[i].T @ np.array([0, 0, 1.0])
+        Pm = np.eye(3) - np.outer(d, d)
+        A += Pm
+        b += Pm @ c
+    centre = np.linalg.solve(A, b)
+    return {"K": np.array(Ks, dtype=np.float64), "R": R, "t": t, "image_size": image_size,
+            "centre": centre, "R0": np.eye(3)}
+
+
+def run_reference_frames(H, rig, blobs, counts, as_int=True):
+    """find_point_correspondance_and_object_points (helpers.py:339) per frame, also capturing the
+    winning group's coordinates per kept root (what the reference carries instead of indices)."""
+    F, C, M, _ = blobs.shape
+    poses = synth.rig_to_pose_dicts(rig)
+    kmax = C * M
+    ref_xyz = np.full((F, kmax, 3), np.nan)
+    ref_err = np.full((F, kmax), np.nan)
+    ref_xy = np.full((F, kmax, C, 2), np.nan)
+    ref_n = np.zeros(F, dtype=np.int32)
+    captured = []
+    orig = H.calculate_reprojection_errors
+
+    def spy(image_points, object_points, camera_poses):
+        e = orig(image_points, object_points, camera_poses)
+        captured.append(image_points[int(np.argmin(e))])
+        return e
+
+    H.calculate_reprojection_errors = spy
+    try:
+        for f in range(F):
+            captured.clear()
+            ip = synth.frame_to_reference_lists(blobs[f], counts[f], as_int=as_int)
+            err, pts, _ = H.find_point_correspondance_and_object_points(ip, poses, [None] * C)
+            k = len(err)
+            assert k == len(captured)
+            ref_n[f] = k
+            if k:
+                ref_xyz[f, :k] = np.asarray(pts, dtype=np.float64)
+                ref_err[f, :k] = err
+                for r, grp in enumerate(captured):
+                    for c, xy in enumerate(grp):
+                        if xy[0] is not None:
+                            ref_xy[f, r, c] = xy
+    finally:
+        H.calculate_reprojection_errors = orig
+    return ref_xyz, ref_err, ref_xy, ref_n
+
+
+def golden_frames(name, rig, n_frames, n_markers, seed, Ks_list=None, **kw):
+    C = len(rig["R"])
+    if Ks_list is None:
+        Ks_list = rig["K"].tolist()
+    H = ref_harness.load_reference(C, intrinsics=Ks_list)
+    blobs, counts, _ = synth.make_blob_stream(rig, n_frames, n_markers, seed=seed, **kw)
+    ref_xyz, ref_err, ref_xy, ref_n = run_reference_frames(H, rig, blobs, counts)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), K=rig["K"], R=rig["R"], t=rig["t"],
+                        blobs=blobs, counts=counts, ref_xyz=ref_xyz, ref_err=ref_err,
+                        ref_corr_xy=ref_xy, ref_n=ref_n)
+    print(name, "frames", n_frames, "points", int(ref_n.sum()))
+
+
+def golden_dlt(name, rig, n_points, seed, Ks_list=None, dropout=0.3):
+    C = len(rig["R"])
+    if Ks_list is None:
+        Ks_list = rig["K"].tolist()
+    H = ref_harness.load_reference(C, intrinsics=Ks_list)
+    obs, _ = synth.make_ba_observations(rig, n_points, seed=seed, dropout=dropout)
+    obs[0, :, :] = np.nan            # no view at all
+    obs[1, 1:, :] = np.nan           # a single view
+    poses = synth.rig_to_pose_dicts(rig)
+    ref_obs = synth.obs_to_reference_array(obs)
+    xyz = H.triangulate_points(ref_obs, poses)
+    ref_xyz = np.full((n_points, 3), np.nan)
+    ref_err = np.full(n_points, np.nan)
+    for n in range(n_points):
+        if xyz[n][0] is not None:
+            ref_xyz[n] = np.asarray(xyz[n], dtype=np.float64)
+            ref_err[n] = H.calculate_reprojection_error(ref_obs[n], xyz[n], poses)
+    # calculate_reprojection_errors skips None rows (helpers.py:207-208): keep the packed form too
+    packed = H.calculate_reprojection_errors(ref_obs, xyz, poses)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), K=rig["K"], R=rig["R"], t=rig["t"], obs=obs,
+                        ref_xyz=ref_xyz, ref_err=ref_err, ref_err_packed=packed)
+    print(name, "points", n_points, "valid", int(np.isfinite(ref_err).sum()))
+
+
+def golden_ba(name, C, n_points, seed, run_solver):
+    """residual_function values (helpers.py:264-276) at several parameter vectors, and (small case)
+    the poses bundle_adjustment returns (helpers.py:287-290)."""
+    from scipy.spatial.transform import Rotation
+    H = ref_harness.load_reference(C)
+    rig = synth.ring_rig(C)
+    rng = np.random.default_rng(seed)
+    obs, _ = synth.make_ba_observations(rig, n_points, seed=seed, dropout=0.1)
+    init = synth.perturb_rig(rig, rng)
+    ref_obs = synth.obs_to_reference_array(obs)
+    poses0 = [{"R": init["R"][i].copy(), "t": init["t"][i].copy()} for i in range(C)]
+
+    # helpers.py:278-285 (parameter vector layout)
+    x0 = [320.0]
+    for i in range(1, C):
+        x0 += [320.0] + Rotation.from_matrix(init["R"][i]).as_rotvec().tolist() + init["t"][i].tolist()
+    x0 = np.array(x0)
+    xs = [x0] + [x0 + rng.normal(0, 1e-3, x0.size) for _ in range(3)]
+
+    # evaluate the reference's residual_function closure by capturing it from least_squares
+    captured = {}
+    real_ls = H.optimize.least_squares
+
+    def fake_ls(fun, x_init, **kw):
+        captured["fun"] = fun
+        captured["x_init"] = np.array(x_init)
+        captured["kw"] = kw
+
+        class Res:
+            x = np.array(x_init)
+        return Res()
+
+    H.optimize.least_squares = fake_ls
+    try:
+        H.bundle_adjustment(ref_obs, poses0, ref_harness.NullSocket())
+    finally:
+        H.optimize.least_squares = real_ls
+    assert np.allclose(captured["x_init"], x0, atol=1e-12), (captured["x_init"], x0)
+    res32 = np.array([captured["fun"](x) for x in xs])          # float32, None rows dropped
+    # float64 (pre-cast) residuals through the reference's public functions
+    res64 = []
+    for x in xs:
+        poses = [{"R": np.eye(3), "t": np.zeros(3)}]
+        for i in range(C - 1):
+            poses.append({"R": Rotation.from_rotvec(x[i * 7 + 2:i * 7 + 5]).as_matrix(),
+                          "t": x[i * 7 + 5:i * 7 + 8]})
+        op = H.triangulate_points(ref_obs, poses)
+        res64.append(H.calculate_reprojection_errors(ref_obs, op, poses))
+    res64 = np.array(res64)
+    out = dict(K=rig["K"], R_true=rig["R"], t_true=rig["t"], R_init=init["R"], t_init=init["t"],
+               obs=obs, xs=np.array(xs), res32=res32, res64=res64,
+               ls_kwargs=np.array(sorted((k, str(v)) for k, v in captured["kw"].items())))
+    if run_solver:
+        import contextlib
+        import io
+        with contextlib.redirect_stdout(io.StringIO()):
+            sol = H.bundle_adjustment(ref_obs, [{"R": init["R"][i].copy(), "t": init["t"][i].copy()}
+                                                for i in range(C)], ref_harness.NullSocket())
+        out["R_ba"] = np.array([np.asarray(p["R"], dtype=np.float64) for p in sol])
+        out["t_ba"] = np.array([np.asarray(p["t"], dtype=np.float64).reshape(3) for p in sol])
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(name, "points", n_points, "m", res32.shape[1])
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    # BASELINE.json configs[0..2] shapes
+    golden_frames("frames_c2_m1", synth.ring_rig(2), 8, 1, seed=0)
+    golden_frames("frames_c4_m4", synth.ring_rig(4), 40, 4, seed=0)
+    golden_frames("frames_c8_m16", synth.ring_rig(8), 6, 16, seed=0)
+    # VGA intrinsics (configs[1] "640x480")
+    golden_frames("frames_c4_m4_vga", synth.ring_rig(4, K=synth.VGA_K, image_size=(640, 480)), 20, 4, seed=1)
+    # really calibrated rig of the reference UI + default intrinsics
+    golden_frames("frames_apptsx_rig", rig_from_poses(APP_TSX_POSES, [synth.DEFAULT_K] * 4), 20, 5,
+                  seed=2, half_extent=0.5)
+    # non-identical intrinsics: exercises the compacted-index quirk (helpers.py:305-307)
+    rig3 = synth.ring_rig(3)
+    rig3["K"] = np.array(CALIBRATED_K, dtype=np.float64)
+    golden_frames("frames_c3_calibK", rig3, 20, 4, seed=3, Ks_list=CALIBRATED_K, half_extent=0.5, dropout=0.2)
+    # heavy dropout / empty cameras
+    golden_frames("frames_c4_dropout", synth.ring_rig(4), 30, 3, seed=4, dropout=0.5)
+    # explicit-correspondence DLT + reprojection error
+    golden_dlt("dlt_c4", synth.ring_rig(4), 64, seed=5)
+    golden_dlt("dlt_c8", synth.ring_rig(8), 96, seed=6)
+    golden_dlt("dlt_c3_calibK", rig3, 48, seed=7, Ks_list=CALIBRATED_K)
+    # bundle adjustment
+    golden_ba("ba_c4_n40", 4, 40, seed=8, run_solver=False)
+    golden_ba("ba_c3_n24", 3, 24, seed=9, run_solver=True)
+
+
+if __name__ == "__main__":
+    main()

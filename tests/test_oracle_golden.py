@@ -1,0 +1,94 @@
+"""CPU: the oracle (Python + C restatements) against the golden vectors produced by the
+reference's own functions (oracle/make_golden.py).  Pins the checker before it is trusted."""
+import numpy as np
+import pytest
+
+from conftest import golden_names, load_golden
+from oracle import c_oracle, mocap_oracle as mo
+
+FRAME_SETS = golden_names("frames_")
+DLT_SETS = golden_names("dlt_")
+
+
+def _corr_xy(blobs_f, corr):
+    K, C = corr.shape
+    out = np.full((K, C, 2), np.nan)
+    for r in range(K):
+        for c in range(C):
+            if corr[r, c] >= 0:
+                out[r, c] = blobs_f[c, corr[r, c]]
+    return out
+
+
+@pytest.mark.parametrize("name", FRAME_SETS)
+def test_python_oracle_frames_bit_exact(name):
+    g = load_golden(name)
+    Ks = [k for k in g["K"]]
+    F = g["blobs"].shape[0]
+    Ftab = mo.fundamental_table(Ks, g["R"], g["t"])
+    for f in range(min(F, 12)):
+        o = mo.find_point_correspondance_and_object_points(g["blobs"][f], g["counts"][f], Ks, g["R"], g["t"], Ftab=Ftab)
+        k = int(g["ref_n"][f])
+        assert len(o["errors"]) == k
+        # same arithmetic as the reference -> bit-exact
+        assert np.array_equal(o["object_points"], g["ref_xyz"][f, :k])
+        assert np.array_equal(o["errors"], g["ref_err"][f, :k])
+        assert np.array_equal(_corr_xy(g["blobs"][f], o["corr"]), g["ref_corr_xy"][f, :k], equal_nan=True)
+
+
+@pytest.mark.parametrize("name", FRAME_SETS)
+def test_c_oracle_frames(name):
+    g = load_golden(name)
+    co = c_oracle.COracle(g["K"], g["R"], g["t"])
+    res = co.match_triangulate(g["blobs"], g["counts"])
+    assert np.array_equal(res["n_out"], g["ref_n"])
+    assert not res["status"].any()
+    for f in range(g["blobs"].shape[0]):
+        k = int(g["ref_n"][f])
+        # correspondence: bit-exact
+        assert np.array_equal(_corr_xy(g["blobs"][f], res["corr"][f, :k]), g["ref_corr_xy"][f, :k], equal_nan=True)
+        if k:
+            # 3-D points: 1e-5 relative is the contract; the restatement is ~1e-12
+            np.testing.assert_allclose(res["xyz"][f, :k], g["ref_xyz"][f, :k], rtol=1e-9, atol=1e-12)
+            np.testing.assert_allclose(res["err"][f, :k], g["ref_err"][f, :k], rtol=1e-6, atol=1e-12)
+
+
+@pytest.mark.parametrize("name", DLT_SETS)
+def test_oracles_dlt(name):
+    g = load_golden(name)
+    Ks = [k for k in g["K"]]
+    xyz_py = mo.triangulate_points(g["obs"], Ks, g["R"], g["t"])
+    err_py = mo.reprojection_errors(g["obs"], xyz_py, Ks, g["R"], g["t"])
+    assert np.array_equal(xyz_py, g["ref_xyz"], equal_nan=True)
+    assert np.array_equal(err_py, g["ref_err"], equal_nan=True)
+    assert np.array_equal(err_py[np.isfinite(err_py)], g["ref_err_packed"])
+    co = c_oracle.COracle(g["K"], g["R"], g["t"])
+    xyz_c, err_c = co.triangulate(g["obs"])
+    assert np.array_equal(np.isnan(xyz_c), np.isnan(g["ref_xyz"]))
+    np.testing.assert_allclose(xyz_c, g["ref_xyz"], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(err_c, g["ref_err"], rtol=1e-6, atol=1e-12)
+
+
+@pytest.mark.parametrize("name", golden_names("ba_"))
+def test_oracles_ba_residuals(name):
+    g = load_golden(name)
+    Ks = [k for k in g["K"]]
+    co = c_oracle.COracle(g["K"], g["R_init"], g["t_init"])
+    r_c = co.ba_residuals(g["xs"], g["obs"])
+    for p, x in enumerate(g["xs"]):
+        r_py = mo.ba_residuals(x, g["obs"], Ks)
+        valid = np.isfinite(r_py)
+        np.testing.assert_allclose(r_py[valid], g["res64"][p], rtol=1e-12)
+        # the float32 cast of helpers.py:273
+        assert np.array_equal(r_py[valid].astype(np.float32), g["res32"][p])
+        np.testing.assert_allclose(r_c[p][valid], g["res64"][p], rtol=1e-7)
+        assert np.array_equal(np.isfinite(r_c[p]), valid)
+
+
+def test_f32_rounding_switch_changes_little():
+    g = load_golden("frames_c4_m4")
+    a = c_oracle.COracle(g["K"], g["R"], g["t"], f32_rounding=True).match_triangulate(g["blobs"], g["counts"])
+    b = c_oracle.COracle(g["K"], g["R"], g["t"], f32_rounding=False).match_triangulate(g["blobs"], g["counts"])
+    assert np.array_equal(a["n_out"], b["n_out"])
+    m = np.isfinite(a["err"]) & np.isfinite(b["err"])
+    np.testing.assert_allclose(a["err"][m], b["err"][m], rtol=1e-2, atol=1e-5)
