@@ -1,0 +1,245 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X-native marker-tracking core.
+
+Metric (BASELINE.json): triangulated 3-D markers/sec at 8 cams x 16 markers (synthetic blob
+streams), plus BA iterations/sec (8 cams, 1k points) as a secondary figure in the same line.
+
+A "step" = one pass of the hot path (mocap_match_triangulate_dev: epipolar matching + candidate
+triangulation + per-root selection) over one batch of FRAMES_PER_GPU synthetic frames that is
+ALREADY RESIDENT in HBM when the timed region starts.  With N > 1 (one process per GPU, launched
+by torch.distributed.run) every rank owns its own contiguous block of frames (weak scaling) and a
+step ends with the single exchange of the path: the gather of the packed track records on rank 0
+(RCCL over xGMI).  value = markers produced by all ranks / max-over-ranks time.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "low-cost-mocap_amd"))
+
+from mocap_core import capi, dist as mdist, synth  # noqa: E402
+
+CAMS, MARKERS = 8, 16
+FRAMES_PER_GPU = 100_000      # BASELINE.json configs[2] / SURVEY.md 8d cfg3
+K_MAX = 48
+G_CAP = 1 << 20
+HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: 8 TB/s spec
+FP64_VALU_PEAK_TF = 78.6      # MI355X FP64 vector peak
+
+
+def algorithmic_bytes(counts, n_out, C, M):
+    """per frame 8*C*M + 4*C in, K*(24 + 8 + 2*C) out (K = points produced)."""
+    F = counts.shape[0]
+    return F * (8 * C * M + 4 * C) + int(n_out.sum()) * (24 + 8 + 2 * C)
+
+
+def cpu_baseline(rig, blobs, counts, budget_s=15.0):
+    """The oracle's C restatement of the reference path ("port"), single thread, on a bounded
+    prefix of the SAME frames.  Reported baseline only -- never the thing measured or shipped."""
+    from oracle import c_oracle
+    co = c_oracle.COracle(rig["K"], rig["R"], rig["t"])
+    co.match_triangulate(blobs[:20], counts[:20])          # warm
+    n, done, pts, t0 = 500, 0, 0, time.perf_counter()
+    while done < blobs.shape[0]:
+        hi = min(done + n, blobs.shape[0])
+        r = co.match_triangulate(blobs[done:hi], counts[done:hi])
+        pts += int(r["n_out"].sum())
+        done = hi
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    out = {"value": pts / dt, "unit": "markers/s", "cores": 1, "kind": "port",
+           "sample": f"first {done} frames of the bench batch, C restatement (oracle/c), 1 thread, {dt:.1f}s"}
+    # the NumPy/Python restatement keeps the reference's own structure (Python loops + LAPACK SVD per
+    # candidate) and is bit-exact against it: its rate is the closest stand-in for the reference itself
+    try:
+        from oracle import mocap_oracle as mo
+        Ks = [k for k in rig["K"]]
+        Ftab = mo.fundamental_table(Ks, rig["R"], rig["t"])
+        t1, p2, f2 = time.perf_counter(), 0, 0
+        while time.perf_counter() - t1 < 6.0 and f2 < 40:
+            o = mo.find_point_correspondance_and_object_points(blobs[f2], counts[f2], Ks, rig["R"], rig["t"], Ftab=Ftab)
+            p2 += len(o["errors"])
+            f2 += 1
+        out["python_port_markers_per_s"] = p2 / (time.perf_counter() - t1)
+        out["python_port_sample"] = f"{f2} frames, oracle/mocap_oracle.py (bit-exact vs the reference), 1 thread"
+    except Exception as e:  # pragma: no cover
+        out["python_port_error"] = repr(e)
+    return out
+
+
+def ba_bench(core, iters=12):
+    """Secondary metric: LM iterations/sec, 8 cams x 1000 points, reference settings
+    (cauchy loss, float32 residual cast, 2-point Jacobian incl. the dead focal columns)."""
+    from mocap_core import helpers
+    rig = synth.ring_rig(CAMS)
+    rng = np.random.default_rng(7)
+    obs, _ = synth.make_ba_observations(rig, 1000, seed=7)
+    init = synth.perturb_rig(rig, rng)
+    core.set_cameras(rig["K"], init["R"], init["t"])
+    helpers.set_camera_params([{"intrinsic_matrix": k.tolist()} for k in rig["K"]])
+    x0 = helpers._ba_x0([{"R": init["R"][i], "t": init["t"][i]} for i in range(CAMS)])
+    core.ba_solve(x0, obs, ftol=0.0, xtol=0.0, gtol=0.0, max_iter=3)            # warm-up
+    # tolerances 0 so that exactly `iters` trust-region iterations run (each = n+1 residual
+    # evaluations for the Jacobian, the MFMA J^T J, the step and its evaluation)
+    t0 = time.perf_counter()
+    _, info = core.ba_solve(x0, obs, ftol=0.0, xtol=0.0, gtol=0.0, max_iter=iters + 1)
+    dt = time.perf_counter() - t0
+    _, info_ref = core.ba_solve(x0, obs, ftol=1e-2)                             # reference stopping rule
+    return {"metric": "BA iters/sec (8 cams, 1k pts)", "value": info["iterations"] / dt,
+            "iterations": info["iterations"], "nfev": info["nfev"], "ms_per_iter": 1e3 * dt / max(info["iterations"], 1),
+            "params": int(x0.size), "points": int(info["m"]),
+            "reference_rule_run": {"iterations": info_ref["iterations"], "status": info_ref["status"],
+                                   "cost0": info_ref["cost0"], "cost": info_ref["cost"],
+                                   "elapsed_ms": info_ref["elapsed_ms"]}}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--frames", type=int, default=FRAMES_PER_GPU, help="frames per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ba", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    rank, local_rank, world = mdist.init_process_group()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    # ---- synthetic workload: each rank owns its own block of frames (seed differs per rank)
+    C, M, F = CAMS, MARKERS, args.frames
+    rig = synth.ring_rig(C)
+    blobs, counts, _ = synth.make_blob_stream(rig, F, M, seed=1 + rank)
+    core = capi.MocapCore(local_rank)
+    core.set_cameras(rig["K"], rig["R"], rig["t"])
+    stream = torch.cuda.current_stream(dev)
+    core.set_stream(stream.cuda_stream)
+
+    d_blobs = torch.from_numpy(blobs).to(dev)
+    d_counts = torch.from_numpy(counts).to(dev)
+    d_xyz = torch.empty((F, K_MAX, 3), dtype=torch.float64, device=dev)
+    d_err = torch.empty((F, K_MAX), dtype=torch.float64, device=dev)
+    d_corr = torch.empty((F, K_MAX, C), dtype=torch.int16, device=dev)
+    d_nout = torch.zeros(F, dtype=torch.int32, device=dev)
+    d_status = torch.zeros(F, dtype=torch.int32, device=dev)
+    d_ncand = torch.zeros(F, dtype=torch.int32, device=dev)
+
+    def hot_path():
+        core.match_triangulate_dev(F, M, d_blobs.data_ptr(), d_counts.data_ptr(), 5.0, K_MAX, G_CAP,
+                                   d_xyz.data_ptr(), d_err.data_ptr(), d_corr.data_ptr(), d_nout.data_ptr(),
+                                   d_status.data_ptr(), d_ncand.data_ptr())
+
+    def step():
+        hot_path()
+        if world > 1:   # the one exchange of the path: final tracks -> rank 0
+            mdist.gather_records(mdist.pack_records(d_nout, d_xyz, d_err, d_corr), dst=0)
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    # kernel time with HIP events on the stream the kernel is launched on (torch's current stream)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ev[i][0].record(stream)
+        hot_path()
+        ev[i][1].record(stream)
+        if world > 1:
+            mdist.gather_records(mdist.pack_records(d_nout, d_xyz, d_err, d_corr), dst=0)
+    fence()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+
+    n_out = d_nout.cpu().numpy()
+    status = d_status.cpu().numpy()
+    n_cand = d_ncand.cpu().numpy()
+    local = torch.tensor([float(n_out.sum()), elapsed, float(status.astype(bool).sum())], dtype=torch.float64, device=dev)
+    if world > 1:
+        allv = [torch.zeros_like(local) for _ in range(world)]
+        dist.all_gather(allv, local)
+        allv = torch.stack(allv).cpu().numpy()
+    else:
+        allv = local.cpu().numpy()[None]
+    total_markers = float(allv[:, 0].sum())
+    t_max = float(allv[:, 1].max())
+
+    if rank == 0:
+        value = total_markers * args.steps / t_max
+        abytes = algorithmic_bytes(counts, n_out, C, M)
+        ach = abytes / (kernel_ms * 1e-3) / 1e9
+        # FP64 work model: per candidate 92*v + 1500 flop; v = views of the kept groups
+        corr = d_corr.cpu().numpy()
+        valid = np.arange(K_MAX)[None, :] < n_out[:, None]
+        v_mean = float((corr[valid] >= 0).sum(axis=1).mean()) if valid.any() else float(C)
+        flops = float(n_cand.sum()) * (92.0 * v_mean + 1500.0)
+        line = {
+            "metric": "triangulated 3D markers/sec at 8 cams x 16 markers",
+            "value": value, "unit": "markers/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * t_max / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "8 cams x 16 markers, synthetic ring rig f=320 c=160 (camera-params.json), "
+                                   "int-truncated blobs, sigma=0.3px, 5% dropout (BASELINE.json configs[2])",
+                       "frames_per_gpu": F, "cams": C, "markers": M, "K_max": K_MAX, "gate_px": 5.0,
+                       "parallelism": f"frame-shard x{world}", "frames_per_s": F * world * args.steps / t_max,
+                       "markers_per_frame": total_markers / (F * world),
+                       "candidates_per_frame": float(n_cand.mean()), "overflow_frames": int(allv[:, 2].sum())},
+            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "mocap::frame_kernel", "kernel_ms": kernel_ms,
+                         "algorithmic_bytes_per_launch": abytes,
+                         "note": "path is FP64-VALU bound (~1e3 flop/byte), see roofline_fp64"},
+            "roofline_fp64": {"bound": "fp64_valu", "achieved": flops / (kernel_ms * 1e-3) / 1e12,
+                              "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s",
+                              "frac": flops / (kernel_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TF,
+                              "model": "candidates x (92 v + 1500) flop, v = mean views", "v_mean": v_mean,
+                              "candidates_per_launch": float(n_cand.sum())},
+        }
+        if world == 1:
+            # parity gate next to the number: a prefix of the very batch that was timed, vs the oracle
+            from oracle import c_oracle
+            nchk = 300
+            ref = c_oracle.COracle(rig["K"], rig["R"], rig["t"]).match_triangulate(blobs[:nchk], counts[:nchk], K_max=K_MAX)
+            vv = valid[:nchk]
+            xyz = d_xyz[:nchk].cpu().numpy()
+            line["parity"] = {
+                "frames_checked": nchk,
+                "n_out_equal": bool(np.array_equal(ref["n_out"], n_out[:nchk])),
+                "corr_bit_exact": bool(np.array_equal(ref["corr"][vv], corr[:nchk][vv])),
+                "xyz_max_rel": float(np.abs(xyz[vv] - ref["xyz"][vv]).max() / np.abs(ref["xyz"][vv]).max()),
+            }
+            if not args.no_cpu_baseline:
+                line["cpu_baseline"] = cpu_baseline(rig, blobs, counts)
+                line["config"]["host_cores"] = os.cpu_count()
+            if not args.no_ba:
+                core.set_stream(0)
+                line["ba"] = ba_bench(core)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

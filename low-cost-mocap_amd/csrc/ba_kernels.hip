@@ -1,0 +1,255 @@
+// ba_kernels.hip -- bundle-adjustment building blocks around the batched residual kernel
+// (csrc/tri_kernel.hip).  Replaces the inner work of
+//   bundle_adjustment / residual_function          (reference computer_code/api/helpers.py:244-290)
+//   scipy.optimize.least_squares(method="trf", loss="cauchy") linearisation: 2-point finite
+//   differences (scipy/optimize/_numdiff.py), Cauchy scaling (scipy/optimize/_lsq/least_squares.py,
+//   _lsq/common.py scale_for_robust_loss_function) and the dense J^T J / J^T f contraction.
+//
+// The contraction runs on the FP64 matrix cores (v_mfma_f64_16x16x4_f64): the Jacobian is
+// stored augmented, Jaug = [ J | f | 0-pad ] with a row length NP that is a multiple of 16, so
+// one Gram product G = Jaug^T Jaug yields J^T J, J^T f and f^T f together.  Reduction over the
+// row (K) dimension is split across waves and finished in a fixed order -> bit-reproducible.
+#include "kernels.hpp"
+
+namespace mocap {
+
+// ---------------------------------------------------------------- parameter perturbation
+// scipy _numdiff._compute_absolute_step / _dense_difference (2-point):
+//   h_j = rel_step * sign(x_j) * max(1, |x_j|),   dx_j = (x_j + h_j) - x_j
+__global__ void ba_perturb_kernel(const double* __restrict__ x, int n, double rel_step,
+                                  double* __restrict__ params, double* __restrict__ hvec) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;  // 0..n : row of params
+  if (j > n) return;
+  for (int k = 0; k < n; k++) {
+    double v = x[k];
+    if (j >= 1 && k == j - 1) {
+      const double sgn = v >= 0.0 ? 1.0 : -1.0;
+      const double h = rel_step * sgn * fmax(1.0, fabs(v));
+      const double x1 = v + h;
+      hvec[k] = x1 - v;
+      v = x1;
+    }
+    params[(size_t)j * n + k] = v;
+  }
+}
+
+hipError_t launch_ba_perturb(const double* x, int n, double rel_step, double* params, double* hvec,
+                             hipStream_t stream) {
+  hipLaunchKernelGGL(ba_perturb_kernel, dim3((n + 1 + 63) / 64), dim3(64), 0, stream, x, n, rel_step,
+                     params, hvec);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- parameters -> camera tables
+// params_to_camera_poses (helpers.py:247-262): camera 0 = (I, 0); camera i = (from_rotvec, t).
+// Rotation.from_rotvec(...).as_matrix() restated: rotvec -> quaternion (series below 1e-3 rad)
+// -> matrix.
+__device__ inline void rotvec_to_matrix(const double* rv, double* R) {
+  const double angle = sqrt(rv[0] * rv[0] + rv[1] * rv[1] + rv[2] * rv[2]);
+  double scale;
+  if (angle <= 1e-3) {
+    const double a2 = angle * angle;
+    scale = 0.5 - a2 / 48 + a2 * a2 / 3840;
+  } else {
+    scale = sin(angle / 2) / angle;
+  }
+  const double x = scale * rv[0], y = scale * rv[1], z = scale * rv[2], w = cos(angle / 2);
+  const double x2 = x * x, y2 = y * y, z2 = z * z, w2 = w * w;
+  const double xy = x * y, zw = z * w, xz = x * z, yw = y * w, yz = y * z, xw = x * w;
+  R[0] = x2 - y2 - z2 + w2;
+  R[1] = 2 * (xy - zw);
+  R[2] = 2 * (xz + yw);
+  R[3] = 2 * (xy + zw);
+  R[4] = -x2 + y2 - z2 + w2;
+  R[5] = 2 * (yz - xw);
+  R[6] = 2 * (xz - yw);
+  R[7] = 2 * (yz + xw);
+  R[8] = -x2 - y2 + z2 + w2;
+}
+
+__global__ void ba_build_cameras_kernel(BaCamArgs a) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= a.P * a.C) return;
+  const int p = idx / a.C, cam = idx - p * a.C;
+  const double* x = a.params + (size_t)p * a.n;
+  double rt[12];
+  if (cam == 0) {
+    for (int k = 0; k < 12; k++) rt[k] = 0.0;
+    rt[0] = rt[4] = rt[8] = 1.0;
+  } else {
+    rotvec_to_matrix(x + (cam - 1) * 7 + 2, rt);
+    rt[9] = x[(cam - 1) * 7 + 5];
+    rt[10] = x[(cam - 1) * 7 + 6];
+    rt[11] = x[(cam - 1) * 7 + 7];
+  }
+  double* RT = a.RT + (size_t)p * a.stride_RT + 12 * cam;
+  for (int k = 0; k < 12; k++) RT[k] = rt[k];
+  // P = K[j] @ [R | t] (helpers.py:306-307); j = compacted view index <= cam
+  const int jn = a.uniformK ? 1 : cam + 1;
+  for (int j = 0; j < jn; j++) {
+    const double* K = a.K + 9 * j;
+    double* P = a.Pq + (size_t)p * a.stride_Pq + 12 * (a.uniformK ? (size_t)cam : (size_t)j * a.C + cam);
+    for (int r = 0; r < 3; r++)
+      for (int c = 0; c < 4; c++) {
+        const double r0 = c < 3 ? rt[c] : rt[9], r1 = c < 3 ? rt[3 + c] : rt[10],
+                     r2 = c < 3 ? rt[6 + c] : rt[11];
+        P[r * 4 + c] = K[r * 3 + 0] * r0 + K[r * 3 + 1] * r1 + K[r * 3 + 2] * r2;
+      }
+  }
+}
+
+hipError_t launch_ba_build_cameras(const BaCamArgs& a, hipStream_t stream) {
+  const int total = a.P * a.C;
+  hipLaunchKernelGGL(ba_build_cameras_kernel, dim3((total + 63) / 64), dim3(64), 0, stream, a);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- Jacobian + robust scaling
+// J[i][j] = (r_j[i] - r_0[i]) / dx_j ; with f32_residuals the residuals are first rounded to
+// float32 and differenced in float32, as the reference does (helpers.py:273 + _numdiff).
+// Cauchy loss (f_scale = 1): z = f^2, rho0 = log1p(z), rho1 = 1/(1+z), rho2 = -1/(1+z)^2;
+// J_scale = sqrt(max(rho1 + 2 rho2 f^2, EPS)); f <- f rho1 / J_scale ; J <- J_scale J.
+__global__ __launch_bounds__(256) void ba_jacobian_kernel(BaJacArgs a) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // valid-row index (fastest)
+  const int j = blockIdx.y;                                          // column of Jaug
+  const int64_t m_pad = (a.m + 3) / 4 * 4;
+  if (i >= m_pad) return;
+  double out = 0.0;
+  if (i < a.m && j <= a.n) {
+    const int64_t idx = a.valid[i];
+    double f0 = a.r[idx];
+    if (a.f32_residuals) f0 = (double)(float)f0;
+    double jscale = 1.0, fs = f0, rho0 = f0 * f0;
+    if (a.use_cauchy) {
+      const double z = f0 * f0;
+      const double t = 1.0 + z;
+      const double rho1 = 1.0 / t, rho2 = -1.0 / (t * t);
+      rho0 = log1p(z);
+      jscale = rho1 + 2.0 * rho2 * (f0 * f0);
+      if (jscale < 2.220446049250313e-16) jscale = 2.220446049250313e-16;
+      jscale = sqrt(jscale);
+      fs = f0 * (rho1 / jscale);
+    }
+    if (j == a.n) {
+      out = fs;
+      if (a.rho0) a.rho0[i] = rho0;
+    } else {
+      double fj = a.r[(size_t)(1 + j) * a.N + idx];
+      double df;
+      if (a.f32_residuals)
+        df = (double)((float)fj - (float)f0);
+      else
+        df = fj - f0;
+      out = (df / a.hvec[j]) * jscale;
+    }
+  }
+  if (j < a.NP) a.Jaug[(size_t)i * a.NP + j] = out;
+}
+
+hipError_t launch_ba_jacobian(const BaJacArgs& a, hipStream_t stream) {
+  const int64_t m_pad = (a.m + 3) / 4 * 4;
+  if (m_pad == 0) return hipSuccess;
+  dim3 grid((unsigned)((m_pad + 255) / 256), (unsigned)a.NP);
+  hipLaunchKernelGGL(ba_jacobian_kernel, grid, dim3(256), 0, stream, a);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- Gram matrix on the matrix cores
+// One wave per (16x16 output tile, K split).  v_mfma_f64_16x16x4_f64 operands (one f64 per lane):
+//   A[i][k]: i = lane & 15, k = lane >> 4      -> Jaug[k0 + (lane>>4)][ti*16 + (lane&15)]
+//   B[k][j]: k = lane >> 4, j = lane & 15      -> Jaug[k0 + (lane>>4)][tj*16 + (lane&15)]
+//   D: 4 f64 per lane, col = lane & 15, row = (lane >> 4) + 4 * reg
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(64) void ba_gram_kernel(const double* __restrict__ Jaug, int64_t m_pad,
+                                                     int NP, int ksplit, double* __restrict__ partial) {
+  const int nt = NP / 16;
+  const int tile = blockIdx.x;
+  const int ti = tile / nt, tj = tile - ti * nt;
+  const int ks = blockIdx.y;
+  const int lane = threadIdx.x;
+  const int64_t steps = m_pad / 4;
+  const int64_t s0 = steps * ks / ksplit, s1 = steps * (ks + 1) / ksplit;
+  const double* pa = Jaug + (size_t)(lane >> 4) * NP + ti * 16 + (lane & 15);
+  const double* pb = Jaug + (size_t)(lane >> 4) * NP + tj * 16 + (lane & 15);
+  double4_t acc = {0.0, 0.0, 0.0, 0.0};
+  for (int64_t s = s0; s < s1; s++) {
+    const double av = pa[(size_t)s * 4 * NP];
+    const double bv = pb[(size_t)s * 4 * NP];
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+  }
+  double* out = partial + (size_t)ks * NP * NP;
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int row = ti * 16 + (lane >> 4) + 4 * r;
+    const int col = tj * 16 + (lane & 15);
+    out[(size_t)row * NP + col] = acc[r];
+  }
+}
+
+__global__ void ba_gram_reduce_kernel(const double* __restrict__ partial, int NP, int ksplit,
+                                      double* __restrict__ G) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= NP * NP) return;
+  double s = 0.0;
+  for (int k = 0; k < ksplit; k++) s += partial[(size_t)k * NP * NP + idx];  // fixed order
+  G[idx] = s;
+}
+
+int ba_gram_ksplit(int64_t m_pad, int NP) {
+  (void)NP;
+  int64_t ks = m_pad / 256;
+  if (ks < 1) ks = 1;
+  if (ks > 64) ks = 64;
+  return (int)ks;
+}
+
+hipError_t launch_ba_gram(const double* Jaug, int64_t m_pad, int NP, double* partial, int ksplit,
+                          double* G, hipStream_t stream) {
+  const int nt = NP / 16;
+  hipLaunchKernelGGL(ba_gram_kernel, dim3(nt * nt, ksplit), dim3(64), 0, stream, Jaug, m_pad, NP, ksplit,
+                     partial);
+  hipLaunchKernelGGL(ba_gram_reduce_kernel, dim3((NP * NP + 255) / 256), dim3(256), 0, stream, partial, NP,
+                     ksplit, G);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- cost of one residual vector
+// cost = 0.5 * sum rho(f^2) over the valid points (scipy loss_function(..., cost_only=True));
+// out[1] = 1 when every residual is finite.  Single workgroup, fixed-order tree -> reproducible.
+__global__ __launch_bounds__(256) void ba_cost_kernel(const double* __restrict__ r,
+                                                      const int32_t* __restrict__ valid, int64_t m,
+                                                      int f32_residuals, int use_cauchy,
+                                                      double* __restrict__ out) {
+  __shared__ double sh[256];
+  __shared__ int bad;
+  if (threadIdx.x == 0) bad = 0;
+  __syncthreads();
+  double s = 0.0;
+  for (int64_t i = threadIdx.x; i < m; i += 256) {
+    double f = r[valid[i]];
+    if (f32_residuals) f = (double)(float)f;
+    if (!isfinite(f)) bad = 1;
+    const double z = f * f;
+    s += use_cauchy ? log1p(z) : z;
+  }
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    out[0] = 0.5 * sh[0];
+    out[1] = bad ? 0.0 : 1.0;
+  }
+}
+
+hipError_t launch_ba_cost(const double* r, const int32_t* valid, int64_t m, int f32_residuals,
+                          int use_cauchy, double* out, hipStream_t stream) {
+  hipLaunchKernelGGL(ba_cost_kernel, dim3(1), dim3(256), 0, stream, r, valid, m, f32_residuals, use_cauchy,
+                     out);
+  return hipGetLastError();
+}
+
+}  // namespace mocap

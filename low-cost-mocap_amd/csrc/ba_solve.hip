@@ -1,0 +1,465 @@
+// ba_solve.hip -- bundle-adjustment entry points of include/mocap_core.h.
+//
+// Replaces bundle_adjustment (reference computer_code/api/helpers.py:244-290), i.e.
+// scipy.optimize.least_squares(residual_function, x0, loss="cauchy", ftol=1e-2) with its default
+// method="trf" (no bounds), 2-point finite-difference Jacobian and exact trust-region solver
+// (scipy/optimize/_lsq/trf.py `trf_no_bounds`, _lsq/common.py `solve_lsq_trust_region`,
+// `update_tr_radius`, `check_termination`, `evaluate_quadratic`).
+//
+// Division of labour: every residual evaluation, the (n+1)-way finite-difference batch, the
+// robust scaling and the dense J^T J / J^T f contraction (FP64 MFMA) run on the GPU
+// (tri_kernel.hip, ba_kernels.hip); the host keeps only the n x n trust-region algebra.
+// SciPy factors J with an SVD (J = U S V^T); here the same quantities come from the symmetric
+// eigen-decomposition of the Gram matrix: J^T J = V S^2 V^T and S U^T f = V^T (J^T f), which is
+// all `solve_lsq_trust_region` uses.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "../../include/mocap_core.h"
+#include "ctx.hpp"
+
+using namespace mocap;
+
+#define HIP_TRY(ctx, expr)                                  \
+  do {                                                      \
+    hipError_t e__ = (expr);                                \
+    if (e__ != hipSuccess) return (ctx)->hip_fail(e__, #expr); \
+  } while (0)
+
+namespace {
+
+constexpr double kEps = 2.220446049250313e-16;
+
+// Cyclic Jacobi eigen-decomposition of a symmetric n x n matrix (row-major, destroyed).
+// Exactly-zero rows/columns (the dead focal parameters, helpers.py:267-270) stay decoupled.
+void sym_eig(int n, std::vector<double>& A, std::vector<double>& V, std::vector<double>& d) {
+  V.assign((size_t)n * n, 0.0);
+  for (int i = 0; i < n; i++) V[(size_t)i * n + i] = 1.0;
+  for (int sweep = 0; sweep < 60; sweep++) {
+    double off = 0.0, dg = 0.0;
+    for (int p = 0; p < n; p++) {
+      dg += A[(size_t)p * n + p] * A[(size_t)p * n + p];
+      for (int q = p + 1; q < n; q++) off += A[(size_t)p * n + q] * A[(size_t)p * n + q];
+    }
+    if (!(off > 1e-34 * dg)) break;
+    for (int p = 0; p < n - 1; p++)
+      for (int q = p + 1; q < n; q++) {
+        const double apq = A[(size_t)p * n + q];
+        if (apq == 0.0) continue;
+        const double app = A[(size_t)p * n + p], aqq = A[(size_t)q * n + q];
+        const double h = aqq - app;
+        const double t = (h < 0 ? -2.0 : 2.0) * apq / (std::fabs(h) + std::sqrt(h * h + 4.0 * apq * apq));
+        const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
+        A[(size_t)p * n + p] = app - t * apq;
+        A[(size_t)q * n + q] = aqq + t * apq;
+        A[(size_t)p * n + q] = A[(size_t)q * n + p] = 0.0;
+        for (int k = 0; k < n; k++) {
+          if (k != p && k != q) {
+            const double akp = A[(size_t)k * n + p], akq = A[(size_t)k * n + q];
+            const double nkp = c * akp - s * akq, nkq = s * akp + c * akq;
+            A[(size_t)k * n + p] = A[(size_t)p * n + k] = nkp;
+            A[(size_t)k * n + q] = A[(size_t)q * n + k] = nkq;
+          }
+          const double vkp = V[(size_t)k * n + p], vkq = V[(size_t)k * n + q];
+          V[(size_t)k * n + p] = c * vkp - s * vkq;
+          V[(size_t)k * n + q] = s * vkp + c * vkq;
+        }
+      }
+  }
+  d.resize(n);
+  for (int i = 0; i < n; i++) d[i] = A[(size_t)i * n + i];
+}
+
+double norm2(const std::vector<double>& v) {
+  double s = 0;
+  for (double x : v) s += x * x;
+  return std::sqrt(s);
+}
+
+// scipy/optimize/_lsq/common.py solve_lsq_trust_region, on (s, suf = s * U^T f, V).
+// s sorted descending.  Returns step p, updates alpha.
+void solve_tr(int n, int64_t m, const std::vector<double>& suf, const std::vector<double>& s,
+              const std::vector<double>& V /* columns = right singular vectors, row-major n x n */, double Delta,
+              double& alpha, std::vector<double>& p) {
+  auto apply = [&](const std::vector<double>& coef) {  // p = -V coef
+    p.assign(n, 0.0);
+    for (int i = 0; i < n; i++) {
+      double acc = 0;
+      for (int k = 0; k < n; k++) acc += V[(size_t)i * n + k] * coef[k];
+      p[i] = -acc;
+    }
+  };
+  auto phi_and_derivative = [&](double a, double& phi, double& phi_prime) {
+    double pn2 = 0, sum3 = 0;
+    for (int k = 0; k < n; k++) {
+      const double denom = s[k] * s[k] + a;
+      const double q = suf[k] / denom;
+      pn2 += q * q;
+      sum3 += suf[k] * suf[k] / (denom * denom * denom);
+    }
+    const double p_norm = std::sqrt(pn2);
+    phi = p_norm - Delta;
+    phi_prime = -sum3 / p_norm;
+  };
+  bool full_rank = false;
+  if (m >= n) {
+    const double threshold = kEps * (double)m * s[0];
+    full_rank = s[n - 1] > threshold;
+  }
+  std::vector<double> coef(n);
+  if (full_rank) {
+    for (int k = 0; k < n; k++) coef[k] = suf[k] / (s[k] * s[k]);  // uf / s
+    apply(coef);
+    if (norm2(p) <= Delta) {
+      alpha = 0.0;
+      return;
+    }
+  }
+  double alpha_upper = norm2(suf) / Delta;
+  double alpha_lower = 0.0;
+  if (full_rank) {
+    double phi, phi_prime;
+    phi_and_derivative(0.0, phi, phi_prime);
+    alpha_lower = -phi / phi_prime;
+  }
+  if (!full_rank && alpha == 0.0) alpha = std::max(0.001 * alpha_upper, std::sqrt(alpha_lower * alpha_upper));
+  for (int it = 0; it < 10; it++) {
+    if (alpha < alpha_lower || alpha > alpha_upper)
+      alpha = std::max(0.001 * alpha_upper, std::sqrt(alpha_lower * alpha_upper));
+    double phi, phi_prime;
+    phi_and_derivative(alpha, phi, phi_prime);
+    if (phi < 0) alpha_upper = alpha;
+    const double ratio = phi / phi_prime;
+    alpha_lower = std::max(alpha_lower, alpha - ratio);
+    alpha -= (phi + Delta) * ratio / Delta;
+    if (std::fabs(phi) < 0.01 * Delta) break;
+  }
+  for (int k = 0; k < n; k++) coef[k] = suf[k] / (s[k] * s[k] + alpha);
+  apply(coef);
+  const double pn = norm2(p);
+  if (pn > 0)
+    for (double& x : p) x *= Delta / pn;
+}
+
+// Workspace carved out of ctx->scratch[1..3].
+struct BaWork {
+  int C = 0, n = 0, NP = 0, ksplit = 1, uniformK = 1;
+  int64_t N = 0, m = 0, m_pad = 0;
+  size_t stride_Pq = 0, stride_RT = 0;
+  double *d_x = nullptr, *d_params = nullptr, *d_hvec = nullptr, *d_Pq = nullptr, *d_RT = nullptr,
+         *d_obs = nullptr, *d_r = nullptr, *d_Jaug = nullptr, *d_partial = nullptr, *d_G = nullptr,
+         *d_cost = nullptr;
+  int32_t* d_valid = nullptr;
+  std::vector<int32_t> valid;
+};
+
+int ba_setup(mocap_ctx* ctx, BaWork& w, int64_t N, const double* obs, int Pmax) {
+  if (!ctx->C) return ctx->fail(MOCAP_E_NOCAMS, "mocap_set_cameras has not been called");
+  if (N < 1 || !obs) return ctx->fail(MOCAP_E_ARG, "bundle adjustment: bad argument");
+  const int C = ctx->C;
+  w.C = C;
+  w.n = 1 + 7 * (C - 1);
+  w.NP = (w.n + 1 + 15) / 16 * 16;
+  w.N = N;
+  w.uniformK = ctx->cv.uniformK;
+  w.stride_Pq = w.uniformK ? (size_t)12 * C : (size_t)12 * C * C;
+  w.stride_RT = (size_t)12 * C;
+  // a point enters the residual vector when >= 2 cameras see it (helpers.py:222-223, :207-208)
+  w.valid.clear();
+  for (int64_t i = 0; i < N; i++) {
+    int v = 0;
+    for (int c = 0; c < C; c++) {
+      const double x = obs[(i * C + c) * 2], y = obs[(i * C + c) * 2 + 1];
+      v += (std::isnan(x) || std::isnan(y)) ? 0 : 1;
+    }
+    if (v >= 2) w.valid.push_back((int32_t)i);
+  }
+  w.m = (int64_t)w.valid.size();
+  w.m_pad = (w.m + 3) / 4 * 4;
+  w.ksplit = ba_gram_ksplit(w.m_pad, w.NP);
+  auto al = [](size_t x) { return (x + 31) / 32 * 32; };
+  const size_t nd_x = al(w.n), nd_params = al((size_t)Pmax * w.n), nd_h = al(w.n),
+               nd_Pq = al((size_t)Pmax * w.stride_Pq), nd_RT = al((size_t)Pmax * w.stride_RT),
+               nd_obs = al((size_t)N * C * 2), nd_r = al((size_t)Pmax * N),
+               nd_J = al((size_t)std::max<int64_t>(w.m_pad, 4) * w.NP),
+               nd_part = al((size_t)w.ksplit * w.NP * w.NP), nd_G = al((size_t)w.NP * w.NP), nd_cost = 32;
+  const size_t total = nd_x + nd_params + nd_h + nd_Pq + nd_RT + nd_obs + nd_r + nd_J + nd_part + nd_G + nd_cost;
+  if (ctx->scratch[1].reserve(total * sizeof(double))) return ctx->fail(MOCAP_E_HIP, "hipMalloc(BA workspace) failed");
+  if (ctx->scratch[2].reserve(sizeof(int32_t) * (size_t)std::max<int64_t>(w.m, 1)))
+    return ctx->fail(MOCAP_E_HIP, "hipMalloc(BA valid list) failed");
+  double* p = (double*)ctx->scratch[1].ptr;
+  w.d_x = p;        p += nd_x;
+  w.d_params = p;   p += nd_params;
+  w.d_hvec = p;     p += nd_h;
+  w.d_Pq = p;       p += nd_Pq;
+  w.d_RT = p;       p += nd_RT;
+  w.d_obs = p;      p += nd_obs;
+  w.d_r = p;        p += nd_r;
+  w.d_Jaug = p;     p += nd_J;
+  w.d_partial = p;  p += nd_part;
+  w.d_G = p;        p += nd_G;
+  w.d_cost = p;
+  w.d_valid = (int32_t*)ctx->scratch[2].ptr;
+  HIP_TRY(ctx, hipMemcpyAsync(w.d_obs, obs, sizeof(double) * (size_t)N * C * 2, hipMemcpyHostToDevice, ctx->stream));
+  if (w.m)
+    HIP_TRY(ctx, hipMemcpyAsync(w.d_valid, w.valid.data(), sizeof(int32_t) * (size_t)w.m, hipMemcpyHostToDevice, ctx->stream));
+  return MOCAP_OK;
+}
+
+// residuals for P parameter vectors already in w.d_params -> w.d_r [P][N]
+int ba_eval_device(mocap_ctx* ctx, BaWork& w, int P) {
+  BaCamArgs ca;
+  ca.C = w.C;
+  ca.n = w.n;
+  ca.P = P;
+  ca.uniformK = w.uniformK;
+  ca.params = w.d_params;
+  ca.K = ctx->d_K9;
+  ca.Pq = w.d_Pq;
+  ca.RT = w.d_RT;
+  ca.stride_Pq = w.stride_Pq;
+  ca.stride_RT = w.stride_RT;
+  HIP_TRY(ctx, launch_ba_build_cameras(ca, ctx->stream));
+  TriArgs ta;
+  ta.cv = ctx->cv;
+  ta.cv.Pq = w.d_Pq;
+  ta.cv.RT = w.d_RT;
+  ta.N = w.N;
+  ta.P = P;
+  ta.stride_Pq = w.stride_Pq;
+  ta.stride_RT = w.stride_RT;
+  ta.obs = w.d_obs;
+  ta.xyz = nullptr;
+  ta.err = w.d_r;
+  HIP_TRY(ctx, launch_triangulate(ta, ctx->stream));
+  return MOCAP_OK;
+}
+
+// cost at x (host) -> cost, finite
+int ba_cost_at(mocap_ctx* ctx, BaWork& w, const double* x, int f32, int cauchy, double& cost, bool& finite) {
+  HIP_TRY(ctx, hipMemcpyAsync(w.d_params, x, sizeof(double) * w.n, hipMemcpyHostToDevice, ctx->stream));
+  int rc = ba_eval_device(ctx, w, 1);
+  if (rc) return rc;
+  HIP_TRY(ctx, launch_ba_cost(w.d_r, w.d_valid, w.m, f32, cauchy, w.d_cost, ctx->stream));
+  double out[2];
+  HIP_TRY(ctx, hipMemcpyAsync(out, w.d_cost, sizeof out, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  cost = out[0];
+  finite = out[1] != 0.0;
+  return MOCAP_OK;
+}
+
+// linearise at x: G = [J|f]^T [J|f] (host copy, NP x NP), cost
+int ba_linearize(mocap_ctx* ctx, BaWork& w, const double* x, int f32, int cauchy, std::vector<double>& G,
+                 double& cost) {
+  HIP_TRY(ctx, hipMemcpyAsync(w.d_x, x, sizeof(double) * w.n, hipMemcpyHostToDevice, ctx->stream));
+  // scipy _numdiff: rel_step = sqrt(eps of the residual dtype) for the 2-point scheme
+  const double rel_step = f32 ? std::sqrt((double)1.1920928955078125e-07) : std::sqrt(kEps);
+  HIP_TRY(ctx, launch_ba_perturb(w.d_x, w.n, rel_step, w.d_params, w.d_hvec, ctx->stream));
+  int rc = ba_eval_device(ctx, w, w.n + 1);
+  if (rc) return rc;
+  BaJacArgs ja;
+  ja.n = w.n;
+  ja.NP = w.NP;
+  ja.N = w.N;
+  ja.m = w.m;
+  ja.valid = w.d_valid;
+  ja.r = w.d_r;
+  ja.hvec = w.d_hvec;
+  ja.f32_residuals = f32;
+  ja.use_cauchy = cauchy;
+  ja.Jaug = w.d_Jaug;
+  ja.rho0 = nullptr;
+  HIP_TRY(ctx, launch_ba_jacobian(ja, ctx->stream));
+  HIP_TRY(ctx, launch_ba_gram(w.d_Jaug, w.m_pad, w.NP, w.d_partial, w.ksplit, w.d_G, ctx->stream));
+  HIP_TRY(ctx, launch_ba_cost(w.d_r, w.d_valid, w.m, f32, cauchy, w.d_cost, ctx->stream));
+  G.resize((size_t)w.NP * w.NP);
+  double out[2];
+  HIP_TRY(ctx, hipMemcpyAsync(G.data(), w.d_G, sizeof(double) * G.size(), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(out, w.d_cost, sizeof out, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  cost = out[0];
+  return MOCAP_OK;
+}
+
+}  // namespace
+
+extern "C" int mocap_ba_residuals(mocap_ctx* ctx, int P, const double* params, int64_t N, const double* obs,
+                                  double* r) {
+  if (!ctx) return MOCAP_E_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (P < 1 || !params || !r) return ctx->fail(MOCAP_E_ARG, "mocap_ba_residuals: bad argument");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  BaWork w;
+  int rc = ba_setup(ctx, w, N, obs, P);
+  if (rc) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(w.d_params, params, sizeof(double) * (size_t)P * w.n, hipMemcpyHostToDevice, ctx->stream));
+  rc = ba_eval_device(ctx, w, P);
+  if (rc) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(r, w.d_r, sizeof(double) * (size_t)P * N, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return MOCAP_OK;
+}
+
+extern "C" int mocap_ba_normal_eq(mocap_ctx* ctx, const double* x, int64_t N, const double* obs,
+                                  int f32_residuals, int use_cauchy, double* JtJ, double* Jtr, double* cost,
+                                  double* J_out, int64_t* m_out) {
+  if (!ctx) return MOCAP_E_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (!x || !JtJ || !Jtr) return ctx->fail(MOCAP_E_ARG, "mocap_ba_normal_eq: bad argument");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  BaWork w;
+  int rc = ba_setup(ctx, w, N, obs, 1 + 7 * (ctx->C - 1) + 1);
+  if (rc) return rc;
+  std::vector<double> G;
+  double c = 0;
+  rc = ba_linearize(ctx, w, x, f32_residuals, use_cauchy, G, c);
+  if (rc) return rc;
+  const int n = w.n, NP = w.NP;
+  for (int i = 0; i < n; i++) {
+    for (int j = 0; j < n; j++) JtJ[(size_t)i * n + j] = G[(size_t)i * NP + j];
+    Jtr[i] = G[(size_t)i * NP + n];
+  }
+  if (cost) *cost = c;
+  if (m_out) *m_out = w.m;
+  if (J_out && w.m) {
+    std::vector<double> Jaug((size_t)w.m_pad * NP);
+    HIP_TRY(ctx, hipMemcpy(Jaug.data(), w.d_Jaug, sizeof(double) * Jaug.size(), hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < w.m; i++)
+      for (int j = 0; j < n; j++) J_out[(size_t)i * n + j] = Jaug[(size_t)i * NP + j];
+  }
+  return MOCAP_OK;
+}
+
+extern "C" int mocap_ba_solve(mocap_ctx* ctx, double* x, int64_t N, const double* obs, double ftol, double xtol,
+                              double gtol, int max_iter, int f32_residuals, int use_cauchy, double* info) {
+  if (!ctx) return MOCAP_E_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (!x) return ctx->fail(MOCAP_E_ARG, "mocap_ba_solve: bad argument");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const auto t_begin = std::chrono::steady_clock::now();
+  BaWork w;
+  int rc = ba_setup(ctx, w, N, obs, 1 + 7 * (ctx->C - 1) + 1);
+  if (rc) return rc;
+  const int n = w.n, NP = w.NP;
+  if (w.m < 1) return ctx->fail(MOCAP_E_ARG, "mocap_ba_solve: no point is seen by two cameras");
+  const int max_nfev = max_iter > 0 ? max_iter : 100 * n;  // scipy: max_nfev = 100 * n
+
+  std::vector<double> xv(x, x + n), G, JtJ((size_t)n * n), g(n), A, V, lam, s(n), suf(n), Vs((size_t)n * n),
+      step, x_new(n), tmp(n);
+  double cost = 0;
+  rc = ba_linearize(ctx, w, xv.data(), f32_residuals, use_cauchy, G, cost);
+  if (rc) return rc;
+  const double cost0 = cost;
+  int nfev = 1, njev = 1, iteration = 0, termination = 0;
+  double Delta = norm2(xv);  // x_scale = 1 (scipy default)
+  if (Delta == 0) Delta = 1.0;
+  double alpha = 0.0, g_norm = 0.0;
+  bool need_factor = true;
+  std::vector<int> order(n);
+
+  while (true) {
+    if (need_factor) {
+      for (int i = 0; i < n; i++) {
+        for (int j = 0; j < n; j++) JtJ[(size_t)i * n + j] = G[(size_t)i * NP + j];
+        g[i] = G[(size_t)i * NP + n];  // compute_grad: J^T f
+      }
+    }
+    g_norm = 0;
+    for (double v : g) g_norm = std::max(g_norm, std::fabs(v));
+    if (g_norm < gtol) termination = 1;
+    if (termination || nfev >= max_nfev) break;
+    if (need_factor) {
+      A = JtJ;
+      sym_eig(n, A, V, lam);
+      for (int i = 0; i < n; i++) order[i] = i;
+      std::sort(order.begin(), order.end(), [&](int a, int b) { return lam[a] > lam[b]; });
+      for (int k = 0; k < n; k++) {
+        const int src = order[k];
+        s[k] = std::sqrt(std::max(lam[src], 0.0));
+        double acc = 0;
+        for (int i = 0; i < n; i++) {
+          Vs[(size_t)i * n + k] = V[(size_t)i * n + src];
+          acc += V[(size_t)i * n + src] * g[i];
+        }
+        suf[k] = acc;  // s * U^T f = V^T J^T f
+      }
+      need_factor = false;
+    }
+    double actual_reduction = -1, step_norm = 0, cost_new = cost;
+    while (actual_reduction <= 0 && nfev < max_nfev) {
+      solve_tr(n, w.m, suf, s, Vs, Delta, alpha, step);
+      // predicted_reduction = -evaluate_quadratic(J, g, step) = -(0.5 |J step|^2 + step.g)
+      double q = 0, l = 0;
+      for (int i = 0; i < n; i++) {
+        double acc = 0;
+        for (int j = 0; j < n; j++) acc += JtJ[(size_t)i * n + j] * step[j];
+        q += step[i] * acc;
+        l += step[i] * g[i];
+      }
+      const double predicted_reduction = -(0.5 * q + l);
+      for (int i = 0; i < n; i++) x_new[i] = xv[i] + step[i];
+      bool finite = true;
+      rc = ba_cost_at(ctx, w, x_new.data(), f32_residuals, use_cauchy, cost_new, finite);
+      if (rc) return rc;
+      nfev++;
+      const double step_h_norm = norm2(step);
+      if (!finite || !std::isfinite(cost_new)) {
+        Delta = 0.25 * step_h_norm;
+        continue;
+      }
+      actual_reduction = cost - cost_new;
+      // update_tr_radius
+      double ratio;
+      if (predicted_reduction > 0)
+        ratio = actual_reduction / predicted_reduction;
+      else if (predicted_reduction == 0 && actual_reduction == 0)
+        ratio = 1;
+      else
+        ratio = 0;
+      double Delta_new = Delta;
+      if (ratio < 0.25)
+        Delta_new = 0.25 * step_h_norm;
+      else if (ratio > 0.75 && step_h_norm > 0.95 * Delta)
+        Delta_new = Delta * 2.0;
+      step_norm = step_h_norm;
+      // check_termination
+      const bool ftol_ok = actual_reduction < ftol * cost && ratio > 0.25;
+      const bool xtol_ok = step_norm < xtol * (xtol + norm2(xv));
+      termination = (ftol_ok && xtol_ok) ? 4 : ftol_ok ? 2 : xtol_ok ? 3 : 0;
+      if (termination) break;
+      alpha *= Delta / Delta_new;
+      Delta = Delta_new;
+    }
+    if (actual_reduction > 0) {
+      xv = x_new;
+      cost = cost_new;
+      if (!termination) {  // (scipy re-linearises even when it is about to stop; the result is unused)
+        rc = ba_linearize(ctx, w, xv.data(), f32_residuals, use_cauchy, G, cost_new);
+        if (rc) return rc;
+        njev++;
+        need_factor = true;
+      }
+    }
+    iteration++;
+    if (termination) break;
+  }
+  memcpy(x, xv.data(), sizeof(double) * n);
+  if (info) {
+    const auto t_end = std::chrono::steady_clock::now();
+    info[0] = iteration;
+    info[1] = nfev;
+    info[2] = termination;
+    info[3] = cost0;
+    info[4] = cost;
+    info[5] = g_norm;
+    info[6] = (double)w.m;
+    info[7] = std::chrono::duration<double, std::milli>(t_end - t_begin).count();
+  }
+  return termination ? MOCAP_OK : MOCAP_E_NOCONV;
+}

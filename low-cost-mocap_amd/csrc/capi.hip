@@ -1,0 +1,401 @@
+// capi.hip -- the C ABI of include/mocap_core.h: context, camera tables, host/device entry
+// points.  Host runtime only; all arithmetic of the hot path happens in the HIP kernels
+// (frame_kernel.hip, tri_kernel.hip, ba_kernels.hip).  The only host-side numerics are the
+// frame-invariant camera tables (P = K[R|t], the C x C fundamental table) and the n x n
+// trust-region algebra of the LM loop (ba_solve.hip).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/mocap_core.h"
+#include "ctx.hpp"
+
+using namespace mocap;
+
+// ------------------------------------------------------------------ helpers
+int mocap_ctx::fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  err = buf;
+  return code;
+}
+
+int mocap_ctx::hip_fail(hipError_t e, const char* what) {
+  return fail(MOCAP_E_HIP, "%s: %s", what, hipGetErrorString(e));
+}
+
+#define HIP_TRY(ctx, expr)                                  \
+  do {                                                      \
+    hipError_t e__ = (expr);                                \
+    if (e__ != hipSuccess) return (ctx)->hip_fail(e__, #expr); \
+  } while (0)
+
+int DevBuf::reserve(size_t bytes) {
+  if (bytes <= cap) return 0;
+  if (ptr) (void)hipFree(ptr);
+  ptr = nullptr;
+  cap = 0;
+  size_t want = bytes + bytes / 4 + 256;
+  hipError_t e = hipMalloc(&ptr, want);
+  if (e != hipSuccess) {
+    ptr = nullptr;
+    return -1;
+  }
+  cap = want;
+  return 0;
+}
+void DevBuf::release() {
+  if (ptr) (void)hipFree(ptr);
+  ptr = nullptr;
+  cap = 0;
+}
+
+// ------------------------------------------------------------------ lifetime
+extern "C" int mocap_create(int device_id, mocap_ctx** out) {
+  if (!out) return MOCAP_E_ARG;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device_id < 0 || device_id >= ndev) return MOCAP_E_HIP;
+  mocap_ctx* c = new mocap_ctx();
+  c->device = device_id;
+  if (hipSetDevice(device_id) != hipSuccess || hipStreamCreate(&c->own_stream) != hipSuccess) {
+    delete c;
+    return MOCAP_E_HIP;
+  }
+  c->stream = c->own_stream;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) c->num_cus = prop.multiProcessorCount;
+  const char* t = getenv("MOCAP_FRAME_THREADS");
+  if (t) {
+    int v = atoi(t);
+    if (v == 64 || v == 128 || v == 256) c->frame_threads = v;
+  }
+  *out = c;
+  return MOCAP_OK;
+}
+
+extern "C" void mocap_destroy(mocap_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  ctx->tables.release();
+  for (auto& b : ctx->scratch) b.release();
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+  delete ctx;
+}
+
+extern "C" const char* mocap_last_error(const mocap_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+extern "C" const char* mocap_version(void) { return "mocap_core 0.1 (gfx950)"; }
+
+extern "C" int mocap_set_stream(mocap_ctx* ctx, void* hip_stream) {
+  if (!ctx) return MOCAP_E_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+  return MOCAP_OK;
+}
+
+extern "C" int mocap_synchronize(mocap_ctx* ctx) {
+  if (!ctx) return MOCAP_E_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return MOCAP_OK;
+}
+
+extern "C" int mocap_set_options(mocap_ctx* ctx, uint32_t flags) {
+  if (!ctx) return MOCAP_E_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  ctx->flags = flags;
+  ctx->cv.f32_rounding = (flags & MOCAP_OPT_F32_ROUNDING) ? 1 : 0;
+  return MOCAP_OK;
+}
+
+extern "C" void mocap_limits(int* max_cameras, int* max_blobs) {
+  if (max_cameras) *max_cameras = kMaxCameras;
+  if (max_blobs) *max_blobs = kMaxBlobs;
+}
+
+// ------------------------------------------------------------------ cameras
+namespace {
+
+// cv::determinant for a 4x4 CV_64F (OpenCV core/src/lapack.cpp -> hal::LU64f, partial pivoting,
+// eps = 100*DBL_EPSILON, p * prod(diag)); used by cv.sfm.fundamentalFromProjections (helpers.py:362).
+// This TU is compiled with -ffp-contract=off so the loop rounds like the scalar x86-64 build.
+double det4_lu(const double* M) {
+  double A[16];
+  memcpy(A, M, sizeof A);
+  double p = 1.0;
+  const double eps = 2.220446049250313e-16 * 100;
+  for (int i = 0; i < 4; i++) {
+    int k = i;
+    for (int j = i + 1; j < 4; j++)
+      if (std::fabs(A[j * 4 + i]) > std::fabs(A[k * 4 + i])) k = j;
+    if (std::fabs(A[k * 4 + i]) < eps) return 0.0;
+    if (k != i) {
+      for (int j = i; j < 4; j++) std::swap(A[i * 4 + j], A[k * 4 + j]);
+      p = -p;
+    }
+    const double d = -1.0 / A[i * 4 + i];
+    for (int j = i + 1; j < 4; j++) {
+      const double alpha = A[j * 4 + i] * d;
+      for (int kk = i + 1; kk < 4; kk++) A[j * 4 + kk] = A[j * 4 + kk] + alpha * A[i * 4 + kk];
+    }
+  }
+  double r = p;
+  for (int i = 0; i < 4; i++) r = r * A[i * 4 + i];
+  return r;
+}
+
+void projection(const double* K, const double* R, const double* t, double* P) {
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 4; c++) {
+      const double r0 = c < 3 ? R[c] : t[0], r1 = c < 3 ? R[3 + c] : t[1], r2 = c < 3 ? R[6 + c] : t[2];
+      P[r * 4 + c] = K[r * 3 + 0] * r0 + K[r * 3 + 1] * r1 + K[r * 3 + 2] * r2;
+    }
+}
+
+void fundamental(const double* P1, const double* P2, double* F) {
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      double XY[16];
+      memcpy(XY + 0, P1 + 4 * ((j + 1) % 3), 32);
+      memcpy(XY + 4, P1 + 4 * ((j + 2) % 3), 32);
+      memcpy(XY + 8, P2 + 4 * ((i + 1) % 3), 32);
+      memcpy(XY + 12, P2 + 4 * ((i + 2) % 3), 32);
+      F[i * 3 + j] = det4_lu(XY);
+    }
+}
+
+}  // namespace
+
+extern "C" int mocap_set_cameras(mocap_ctx* ctx, int C, const double* K, const double* R, const double* t) {
+  if (!ctx) return MOCAP_E_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (!K || !R || !t || C < 1) return ctx->fail(MOCAP_E_ARG, "mocap_set_cameras: bad argument");
+  if (C > kMaxCameras) return ctx->fail(MOCAP_E_LIMIT, "mocap_set_cameras: C=%d exceeds %d", C, kMaxCameras);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  ctx->hK.assign(K, K + 9 * C);
+  ctx->hR.assign(R, R + 9 * C);
+  ctx->ht.assign(t, t + 3 * C);
+  bool uniform = true;
+  for (int i = 1; i < C && uniform; i++) uniform = memcmp(K, K + 9 * i, 72) == 0;
+  // layout of the device table block (doubles): Pq | RT | K4 | F | K9
+  const size_t nPq = uniform ? (size_t)12 * C : (size_t)12 * C * C;
+  const size_t nRT = (size_t)12 * C, nK4 = (size_t)4 * C, nF = (size_t)9 * C * C, nK9 = (size_t)9 * C;
+  std::vector<double> h(nPq + nRT + nK4 + nF + nK9, 0.0);
+  double* Pq = h.data();
+  double* RT = Pq + nPq;
+  double* K4 = RT + nRT;
+  double* F = K4 + nK4;
+  double* K9 = F + nF;
+  std::vector<double> Ptrue((size_t)12 * C);
+  for (int c = 0; c < C; c++) {
+    projection(K + 9 * c, R + 9 * c, t + 3 * c, Ptrue.data() + 12 * c);
+    memcpy(RT + 12 * c, R + 9 * c, 72);
+    memcpy(RT + 12 * c + 9, t + 3 * c, 24);
+    K4[4 * c + 0] = K[9 * c + 0];
+    K4[4 * c + 1] = K[9 * c + 4];
+    K4[4 * c + 2] = K[9 * c + 2];
+    K4[4 * c + 3] = K[9 * c + 5];
+  }
+  if (uniform) {
+    memcpy(Pq, Ptrue.data(), sizeof(double) * 12 * C);
+  } else {
+    // intrinsics by compacted view index j, pose by camera (helpers.py:296-298,305-307)
+    for (int j = 0; j < C; j++)
+      for (int c = j; c < C; c++) projection(K + 9 * j, R + 9 * c, t + 3 * c, Pq + 12 * ((size_t)j * C + c));
+  }
+  for (int a = 0; a < C; a++)
+    for (int b = 0; b < C; b++)
+      if (a != b) fundamental(Ptrue.data() + 12 * a, Ptrue.data() + 12 * b, F + 9 * ((size_t)a * C + b));
+  memcpy(K9, K, sizeof(double) * 9 * C);
+  ctx->hF.assign(F, F + nF);
+
+  // a frame call may be in flight on another stream of the same context: the mutex serialises
+  // host calls; wait for queued device work before replacing the tables it reads.
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->tables.reserve(h.size() * sizeof(double))) return ctx->fail(MOCAP_E_HIP, "hipMalloc(camera tables) failed");
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->tables.ptr, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  const double* d = (const double*)ctx->tables.ptr;
+  ctx->C = C;
+  ctx->cv.C = C;
+  ctx->cv.uniformK = uniform ? 1 : 0;
+  ctx->cv.f32_rounding = (ctx->flags & MOCAP_OPT_F32_ROUNDING) ? 1 : 0;
+  ctx->cv.Pq = d;
+  ctx->cv.RT = d + nPq;
+  ctx->cv.K4 = ctx->cv.RT + nRT;
+  ctx->cv.F = ctx->cv.K4 + nK4;
+  ctx->d_K9 = ctx->cv.F + nF;
+  return MOCAP_OK;
+}
+
+extern "C" int mocap_get_fundamental(mocap_ctx* ctx, double* F) {
+  if (!ctx || !F) return MOCAP_E_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (!ctx->C) return ctx->fail(MOCAP_E_NOCAMS, "mocap_set_cameras has not been called");
+  memcpy(F, ctx->hF.data(), ctx->hF.size() * sizeof(double));
+  return MOCAP_OK;
+}
+
+// ------------------------------------------------------------------ triangulation
+static int triangulate_dev_locked(mocap_ctx* ctx, int64_t N, const double* d_obs, double* d_xyz, double* d_err) {
+  if (!ctx->C) return ctx->fail(MOCAP_E_NOCAMS, "mocap_set_cameras has not been called");
+  if (N < 0 || (N > 0 && !d_obs)) return ctx->fail(MOCAP_E_ARG, "mocap_triangulate: bad argument");
+  TriArgs a;
+  a.cv = ctx->cv;
+  a.N = N;
+  a.P = 1;
+  a.stride_Pq = a.stride_RT = 0;
+  a.obs = d_obs;
+  a.xyz = d_xyz;
+  a.err = d_err;
+  HIP_TRY(ctx, launch_triangulate(a, ctx->stream));
+  return MOCAP_OK;
+}
+
+extern "C" int mocap_triangulate_dev(mocap_ctx* ctx, int64_t N, const double* d_obs, double* d_xyz, double* d_err) {
+  if (!ctx) return MOCAP_E_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  return triangulate_dev_locked(ctx, N, d_obs, d_xyz, d_err);
+}
+
+extern "C" int mocap_triangulate(mocap_ctx* ctx, int64_t N, const double* obs, double* xyz, double* err) {
+  if (!ctx) return MOCAP_E_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (!ctx->C) return ctx->fail(MOCAP_E_NOCAMS, "mocap_set_cameras has not been called");
+  if (N < 0 || (N > 0 && (!obs || !xyz))) return ctx->fail(MOCAP_E_ARG, "mocap_triangulate: bad argument");
+  if (N == 0) return MOCAP_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const int C = ctx->C;
+  const size_t b_obs = sizeof(double) * (size_t)N * C * 2, b_xyz = sizeof(double) * (size_t)N * 3,
+               b_err = sizeof(double) * (size_t)N;
+  DevBuf& s = ctx->scratch[0];
+  if (s.reserve(b_obs + b_xyz + b_err)) return ctx->fail(MOCAP_E_HIP, "hipMalloc(%zu) failed", b_obs + b_xyz + b_err);
+  double* d_obs = (double*)s.ptr;
+  double* d_xyz = d_obs + (size_t)N * C * 2;
+  double* d_err = d_xyz + (size_t)N * 3;
+  HIP_TRY(ctx, hipMemcpyAsync(d_obs, obs, b_obs, hipMemcpyHostToDevice, ctx->stream));
+  int rc = triangulate_dev_locked(ctx, N, d_obs, d_xyz, d_err);
+  if (rc) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(xyz, d_xyz, b_xyz, hipMemcpyDeviceToHost, ctx->stream));
+  if (err) HIP_TRY(ctx, hipMemcpyAsync(err, d_err, b_err, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return MOCAP_OK;
+}
+
+// ------------------------------------------------------------------ frame path
+static int match_dev_locked(mocap_ctx* ctx, int64_t n_frames, int M_max, const float* d_blobs,
+                            const int32_t* d_counts, double gate_px, int K_max, int64_t G_cap, double* d_xyz,
+                            double* d_err, int16_t* d_corr, int32_t* d_n_out, int32_t* d_status,
+                            int32_t* d_n_cand) {
+  if (!ctx->C) return ctx->fail(MOCAP_E_NOCAMS, "mocap_set_cameras has not been called");
+  if (n_frames < 0 || M_max < 1 || K_max < 1 || G_cap < 1)
+    return ctx->fail(MOCAP_E_ARG, "mocap_match_triangulate: bad size argument");
+  if (n_frames == 0) return MOCAP_OK;
+  if (!d_blobs || !d_counts || !d_xyz || !d_err || !d_corr || !d_n_out || !d_status)
+    return ctx->fail(MOCAP_E_ARG, "mocap_match_triangulate: null buffer");
+  if (M_max > kMaxBlobs) return ctx->fail(MOCAP_E_LIMIT, "M_max=%d exceeds %d", M_max, kMaxBlobs);
+  if (G_cap > (1ll << 24)) G_cap = 1ll << 24;  // 32-bit candidate offsets per frame
+  FrameArgs a;
+  a.cv = ctx->cv;
+  a.n_frames = n_frames;
+  a.M = M_max;
+  a.K_max = K_max;
+  a.gate_px = gate_px;
+  a.G_cap = G_cap;
+  a.blobs = d_blobs;
+  a.counts = d_counts;
+  a.xyz = d_xyz;
+  a.err = d_err;
+  a.corr = d_corr;
+  a.n_out = d_n_out;
+  a.status = d_status;
+  a.n_cand = d_n_cand;
+  int T = ctx->frame_threads;
+  size_t lds = frame_lds_bytes(ctx->C, M_max, K_max, T);
+  while (lds > 160 * 1024 && T > 64) {
+    T /= 2;
+    lds = frame_lds_bytes(ctx->C, M_max, K_max, T);
+  }
+  if (lds > 160 * 1024)
+    return ctx->fail(MOCAP_E_LIMIT, "frame state needs %zu B of LDS (C=%d, M_max=%d, K_max=%d): lower K_max",
+                     lds, ctx->C, M_max, K_max);
+  // persistent-style grid: enough workgroups to fill every CU at the LDS-limited occupancy
+  int per_cu = (int)((160 * 1024) / lds);
+  const int wave_cap = 32 / (T / 64);
+  if (per_cu > wave_cap) per_cu = wave_cap;
+  if (per_cu > 8) per_cu = 8;
+  if (per_cu < 1) per_cu = 1;
+  int64_t grid = (int64_t)ctx->num_cus * per_cu;
+  if (grid > n_frames) grid = n_frames;
+  HIP_TRY(ctx, launch_frame_kernel(a, T, (int)grid, ctx->stream));
+  return MOCAP_OK;
+}
+
+extern "C" int mocap_match_triangulate_dev(mocap_ctx* ctx, int64_t n_frames, int M_max, const float* d_blobs,
+                                           const int32_t* d_counts, double gate_px, int K_max, int64_t G_cap,
+                                           double* d_xyz, double* d_err, int16_t* d_corr, int32_t* d_n_out,
+                                           int32_t* d_status, int32_t* d_n_cand) {
+  if (!ctx) return MOCAP_E_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  return match_dev_locked(ctx, n_frames, M_max, d_blobs, d_counts, gate_px, K_max, G_cap, d_xyz, d_err, d_corr,
+                          d_n_out, d_status, d_n_cand);
+}
+
+extern "C" int mocap_match_triangulate(mocap_ctx* ctx, int64_t n_frames, int M_max, const float* blobs,
+                                       const int32_t* counts, double gate_px, int K_max, int64_t G_cap,
+                                       double* xyz, double* err, int16_t* corr, int32_t* n_out,
+                                       int32_t* status, int32_t* n_cand) {
+  if (!ctx) return MOCAP_E_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (!ctx->C) return ctx->fail(MOCAP_E_NOCAMS, "mocap_set_cameras has not been called");
+  if (n_frames < 0 || M_max < 1 || K_max < 1) return ctx->fail(MOCAP_E_ARG, "mocap_match_triangulate: bad size argument");
+  if (n_frames == 0) return MOCAP_OK;
+  if (!blobs || !counts || !xyz || !err || !corr || !n_out || !status)
+    return ctx->fail(MOCAP_E_ARG, "mocap_match_triangulate: null buffer");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const int C = ctx->C;
+  const size_t F = (size_t)n_frames;
+  const size_t b_blobs = sizeof(float) * F * C * M_max * 2, b_counts = sizeof(int32_t) * F * C,
+               b_xyz = sizeof(double) * F * K_max * 3, b_err = sizeof(double) * F * K_max,
+               b_corr = sizeof(int16_t) * F * K_max * C, b_i = sizeof(int32_t) * F;
+  auto al = [](size_t x) { return (x + 255) / 256 * 256; };
+  const size_t total = al(b_xyz) + al(b_err) + al(b_blobs) + al(b_counts) + al(b_corr) + 3 * al(b_i);
+  DevBuf& s = ctx->scratch[0];
+  if (s.reserve(total)) return ctx->fail(MOCAP_E_HIP, "hipMalloc(%zu) failed", total);
+  char* p = (char*)s.ptr;
+  double* d_xyz = (double*)p;       p += al(b_xyz);
+  double* d_err = (double*)p;       p += al(b_err);
+  float* d_blobs = (float*)p;       p += al(b_blobs);
+  int32_t* d_counts = (int32_t*)p;  p += al(b_counts);
+  int16_t* d_corr = (int16_t*)p;    p += al(b_corr);
+  int32_t* d_n_out = (int32_t*)p;   p += al(b_i);
+  int32_t* d_status = (int32_t*)p;  p += al(b_i);
+  int32_t* d_n_cand = (int32_t*)p;
+  HIP_TRY(ctx, hipMemcpyAsync(d_blobs, blobs, b_blobs, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(d_counts, counts, b_counts, hipMemcpyHostToDevice, ctx->stream));
+  int rc = match_dev_locked(ctx, n_frames, M_max, d_blobs, d_counts, gate_px, K_max, G_cap, d_xyz, d_err, d_corr,
+                            d_n_out, d_status, d_n_cand);
+  if (rc) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(xyz, d_xyz, b_xyz, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(err, d_err, b_err, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(corr, d_corr, b_corr, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(n_out, d_n_out, b_i, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(status, d_status, b_i, hipMemcpyDeviceToHost, ctx->stream));
+  if (n_cand) HIP_TRY(ctx, hipMemcpyAsync(n_cand, d_n_cand, b_i, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return MOCAP_OK;
+}

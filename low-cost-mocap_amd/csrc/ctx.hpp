@@ -1,0 +1,35 @@
+// ctx.hpp -- the opaque context behind `mocap_ctx*` (include/mocap_core.h).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "kernels.hpp"
+
+struct DevBuf {
+  void* ptr = nullptr;
+  size_t cap = 0;
+  int reserve(size_t bytes);  // grow-only; 0 on success
+  void release();
+};
+
+struct mocap_ctx {
+  int device = 0;
+  int num_cus = 256;
+  int frame_threads = 256;  // workgroup size of the frame kernel (MOCAP_FRAME_THREADS=64|128|256)
+  hipStream_t own_stream = nullptr, stream = nullptr;
+  std::mutex mu;            // one context = one serialised caller (include/mocap_core.h)
+  std::string err;
+  uint32_t flags = 1u;      // MOCAP_OPT_F32_ROUNDING on by default
+  int C = 0;
+  std::vector<double> hK, hR, ht, hF;  // host copies (intrinsics are reused by bundle adjustment)
+  DevBuf tables;            // Pq | RT | K4 | F | K9
+  const double* d_K9 = nullptr;
+  mocap::CamView cv{};
+  DevBuf scratch[4];        // [0] host-API staging, [1..3] bundle adjustment workspace
+
+  int fail(int code, const char* fmt, ...);
+  int hip_fail(hipError_t e, const char* what);
+};

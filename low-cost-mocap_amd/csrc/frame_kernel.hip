@@ -1,0 +1,414 @@
+// frame_kernel.hip -- per-frame epipolar correspondence search + candidate triangulation +
+// per-root selection, fused in one launch.  Replaces
+//   find_point_correspondance_and_object_points   (reference computer_code/api/helpers.py:339-421)
+// for a batch of independent frames: one workgroup per frame, every intermediate (blobs, roots,
+// sorted hit lists, candidate bookkeeping) lives in LDS; HBM sees only the blob arrays in and
+// the kept points out (~2 KB per 8x16 frame).
+//
+// Phases per frame (T threads):
+//   A  coalesced load of the frame's blobs/counts into LDS
+//   B  for camera i = 1..C-1 (sequential dependency, helpers.py:359-406):
+//        B1 one lane per root: epipolar line (helpers.py:362-364) -> LDS
+//        B2 one lane per (root, blob): point-line distance (helpers.py:373)
+//        B3 rank-by-counting sort of the gated hits (helpers.py:375-385), stable (distance, index)
+//        B4 mark blobs equal (by value) to a root's closest hit (helpers.py:391)
+//        B5 ballot-compaction of the unclaimed blobs into new roots (helpers.py:402-406)
+//   C  per-root candidate counts (Cartesian product sizes, helpers.py:394-400), offsets
+//   D  flat candidate space [0, G) split into T contiguous runs; each lane triangulates and scores
+//      its run (csrc/mocap_device.hpp) keeping a (error, index) first-minimum per (lane, root)
+//      segment -- at most T + R segments per frame, stored in LDS, no atomics
+//   E  one lane per kept root scans its segments (np.argmin first-minimum, helpers.py:418), decodes
+//      the winning group's blob indices and writes xyz / err / corr
+#include "mocap_device.hpp"
+#include "kernels.hpp"
+
+namespace mocap {
+
+struct FrameLds {
+  // byte offsets into dynamic LDS, computed identically on host (size) and device (carve)
+  size_t line, dist, seg_e, seg_x, seg_g, goff, gcnt, outslot, bx, by, hits, sel, nh, root_blob,
+      root_cam, claimed, cnt, misc, total;
+  __host__ __device__ static size_t align(size_t x, size_t a) { return (x + a - 1) / a * a; }
+  __host__ __device__ FrameLds(int C, int M, int R, int T) {
+    size_t o = 0;
+    line = o;      o += sizeof(double) * 4 * R;
+    dist = o;      o += sizeof(double) * (size_t)R * M;
+    seg_e = o;     o += sizeof(double) * (T + R);
+    seg_x = o;     o += sizeof(double) * 3 * (T + R);
+    seg_g = o;     o += sizeof(uint32_t) * (T + R);
+    goff = o;      o += sizeof(uint32_t) * (R + 1);
+    gcnt = o;      o += sizeof(uint32_t) * R;
+    outslot = o;   o += sizeof(int32_t) * R;
+    bx = o;        o += sizeof(float) * (size_t)C * M;
+    by = o;        o += sizeof(float) * (size_t)C * M;
+    cnt = o;       o += sizeof(int32_t) * C;
+    misc = o;      o += sizeof(int32_t) * 8;
+    hits = o;      o += sizeof(uint16_t) * (size_t)R * C * M;
+    sel = o;       o += sizeof(uint16_t) * (size_t)T * C;
+    nh = o;        o += sizeof(uint16_t) * (size_t)R * C;
+    root_blob = o; o += sizeof(uint16_t) * R;
+    root_cam = o;  o += R;
+    claimed = o;   o += M;
+    total = align(o, 16);
+  }
+};
+
+size_t frame_lds_bytes(int C, int M, int R, int T) { return FrameLds(C, M, R, T).total; }
+
+constexpr uint16_t kNone = 0xFFFF;
+
+template <int T, bool UNIFORM_K>
+__global__ __launch_bounds__(T) void frame_kernel(FrameArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const CamView cv = p.cv;
+  const int C = cv.C, M = p.M, R = p.K_max;
+  const int tid = threadIdx.x;
+  const FrameLds L(C, M, R, T);
+  double* line = (double*)(smem + L.line);
+  double* dist = (double*)(smem + L.dist);
+  double* seg_e = (double*)(smem + L.seg_e);
+  double* seg_x = (double*)(smem + L.seg_x);
+  uint32_t* seg_g = (uint32_t*)(smem + L.seg_g);
+  uint32_t* goff = (uint32_t*)(smem + L.goff);
+  uint32_t* gcnt = (uint32_t*)(smem + L.gcnt);
+  int32_t* outslot = (int32_t*)(smem + L.outslot);
+  float* bx = (float*)(smem + L.bx);
+  float* by = (float*)(smem + L.by);
+  int32_t* cnt = (int32_t*)(smem + L.cnt);
+  int32_t* misc = (int32_t*)(smem + L.misc);  // [0] nroots, [1] status, [2] n_out, [3] G
+  uint16_t* hits = (uint16_t*)(smem + L.hits);
+  uint16_t* sel = (uint16_t*)(smem + L.sel) + (size_t)tid * C;
+  uint16_t* nh = (uint16_t*)(smem + L.nh);
+  uint16_t* root_blob = (uint16_t*)(smem + L.root_blob);
+  uint8_t* root_cam = (uint8_t*)(smem + L.root_cam);
+  uint8_t* claimed = (uint8_t*)(smem + L.claimed);
+  const bool f32r = cv.f32_rounding != 0;
+
+  for (int64_t frame = blockIdx.x; frame < p.n_frames; frame += gridDim.x) {
+    // ---------------------------------------------------------------- A: load
+    {
+      const float2* src = (const float2*)(p.blobs + (size_t)frame * C * M * 2);
+      for (int i = tid; i < C * M; i += T) {
+        const float2 b = src[i];
+        bx[i] = b.x;
+        by[i] = b.y;
+      }
+      if (tid < C) {
+        int n = p.counts[(size_t)frame * C + tid];
+        cnt[tid] = n < 0 ? 0 : (n > M ? M : n);
+      }
+      if (tid == 0) misc[1] = 0;
+    }
+    __syncthreads();
+    // roots from camera 0 (helpers.py:349,357)
+    {
+      const int n0 = cnt[0];
+      for (int r = tid; r < n0 && r < R; r += T) {
+        root_cam[r] = 0;
+        root_blob[r] = (uint16_t)r;
+      }
+      if (tid == 0) {
+        misc[0] = n0 < R ? n0 : R;
+        if (n0 > R) misc[1] |= MOCAP_ST_ROOT_OVERFLOW_;
+      }
+    }
+    __syncthreads();
+
+    // ---------------------------------------------------------------- B: camera sweep
+    for (int i = 1; i < C; i++) {
+      const int nroots = misc[0];
+      const int Mi = cnt[i];
+      const float* pxs = bx + (size_t)i * M;
+      const float* pys = by + (size_t)i * M;
+      // B1: epipolar line of every root in camera i.  cv.computeCorrespondEpilines on a float32
+      // point: double math, scale by 1/sqrt(a^2+b^2), float32 result (helpers.py:363-364).
+      for (int r = tid; r < nroots; r += T) {
+        const int rc = root_cam[r], rb = root_blob[r];
+        const double* Fm = cv.F + 9 * ((size_t)rc * C + i);
+        const double x = (double)bx[(size_t)rc * M + rb], y = (double)by[(size_t)rc * M + rb];
+        double a = Fm[0] * x + Fm[1] * y + Fm[2];
+        double b = Fm[3] * x + Fm[4] * y + Fm[5];
+        double c = Fm[6] * x + Fm[7] * y + Fm[8];
+        double nu = a * a + b * b;
+        nu = nu != 0.0 ? 1.0 / sqrt(nu) : 1.0;
+        a *= nu;
+        b *= nu;
+        c *= nu;
+        if (f32r) {
+          a = (double)(float)a;
+          b = (double)(float)b;
+          c = (double)(float)c;
+        }
+        line[4 * r + 0] = a;
+        line[4 * r + 1] = b;
+        line[4 * r + 2] = c;
+        line[4 * r + 3] = sqrt(a * a + b * b);  // helpers.py:373 divides by it again
+        nh[(size_t)r * C + i] = 0;
+      }
+      for (int k = tid; k < M; k += T) claimed[k] = 0;
+      __syncthreads();
+      // B2: |a x + b y + c| / sqrt(a^2 + b^2) for every (root, blob) pair (helpers.py:373)
+      const int npairs = nroots * Mi;
+      for (int idx = tid; idx < npairs; idx += T) {
+        const int r = idx / Mi, k = idx - r * Mi;
+        const double a = line[4 * r + 0], b = line[4 * r + 1], c = line[4 * r + 2], den = line[4 * r + 3];
+        const double px = (double)pxs[k], py = (double)pys[k];
+        dist[(size_t)r * M + k] = fabs(a * px + b * py + c) / den;
+      }
+      __syncthreads();
+      // B3: gate (strict <, helpers.py:375,383) and order by (distance, index) via rank counting
+      for (int idx = tid; idx < npairs; idx += T) {
+        const int r = idx / Mi, k = idx - r * Mi;
+        const double* dr = dist + (size_t)r * M;
+        const double d = dr[k];
+        if (d < p.gate_px) {
+          int rank = 0;
+          for (int k2 = 0; k2 < Mi; k2++) {
+            const double d2 = dr[k2];
+            rank += (d2 < d || (d2 == d && k2 < k)) ? 1 : 0;
+          }
+          hits[((size_t)r * C + i) * M + rank] = (uint16_t)k;
+        }
+        if (k == 0) {
+          int n = 0;
+          for (int k2 = 0; k2 < Mi; k2++) n += dr[k2] < p.gate_px ? 1 : 0;
+          nh[(size_t)r * C + i] = (uint16_t)n;
+        }
+      }
+      __syncthreads();
+      // B4: the closest hit of every matched root is removed *by value* from the unmatched set
+      // (helpers.py:391): flag every blob with the same coordinates.
+      for (int idx = tid; idx < npairs; idx += T) {
+        const int r = idx / Mi, k = idx - r * Mi;
+        if (nh[(size_t)r * C + i] > 0) {
+          const int k0 = hits[((size_t)r * C + i) * M];
+          if (pxs[k] == pxs[k0] && pys[k] == pys[k0]) claimed[k] = 1;
+        }
+      }
+      __syncthreads();
+      // B5: unclaimed blobs become new roots, in blob order (helpers.py:402-406); wave 0 compacts
+      if (tid < 64) {
+        int base_root = nroots;
+        for (int k0 = 0; k0 < Mi; k0 += 64) {
+          const int k = k0 + tid;
+          const bool flag = k < Mi && !claimed[k];
+          const unsigned long long mask = __ballot(flag);
+          const int pos = __popcll(mask & ((1ull << tid) - 1ull));
+          if (flag) {
+            const int rr = base_root + pos;
+            if (rr < R) {
+              root_cam[rr] = (uint8_t)i;
+              root_blob[rr] = (uint16_t)k;
+            }
+          }
+          base_root += __popcll(mask);
+        }
+        if (tid == 0) {
+          if (base_root > R) {
+            misc[1] |= MOCAP_ST_ROOT_OVERFLOW_;
+            base_root = R;
+          }
+          misc[0] = base_root;
+        }
+      }
+      __syncthreads();
+    }
+
+    // ---------------------------------------------------------------- C: candidate counts
+    const int nroots = misc[0];
+    for (int r = tid; r < nroots; r += T) {
+      const int rc = root_cam[r];
+      unsigned long long total = 1;
+      int views = 1;
+      bool over = false;
+      for (int c = rc + 1; c < C; c++) {
+        const unsigned n = nh[(size_t)r * C + c];
+        if (n) {
+          views++;
+          total *= n;
+          if (total > (unsigned long long)p.G_cap) {
+            over = true;
+            total = 1;
+          }
+        }
+      }
+      if (over) atomicOr(&misc[1], MOCAP_ST_CAND_OVERFLOW_);
+      gcnt[r] = (views > 1 && !over) ? (uint32_t)total : 0u;  // helpers.py:413-414 drops 1-view roots
+    }
+    __syncthreads();
+    if (tid == 0) {
+      uint32_t acc = 0;
+      int slot = 0;
+      for (int r = 0; r < nroots; r++) {
+        goff[r] = acc;
+        outslot[r] = gcnt[r] ? slot : -1;
+        slot += gcnt[r] ? 1 : 0;
+        const uint32_t nxt = acc + gcnt[r];
+        if (nxt < acc) misc[1] |= MOCAP_ST_CAND_OVERFLOW_;
+        acc = nxt;
+      }
+      goff[nroots] = acc;
+      misc[2] = slot;
+      misc[3] = (int32_t)acc;
+    }
+    __syncthreads();
+    const int status = misc[1];
+    const uint32_t G = status ? 0u : (uint32_t)misc[3];
+
+    // ---------------------------------------------------------------- D: evaluate candidates
+    if (G) {
+      const uint32_t q = (G + T - 1) / T;
+      uint32_t g = (uint32_t)tid * q;
+      const uint32_t g_end = (g + q < G) ? g + q : G;
+      if (g < g_end) {
+        // first root whose range contains g
+        int lo = 0, hi = nroots - 1;
+        while (lo < hi) {
+          const int mid = (lo + hi + 1) >> 1;
+          if (goff[mid] <= g) lo = mid; else hi = mid - 1;
+        }
+        int r = lo;
+        while (goff[r + 1] <= g) r++;  // skip empty roots sharing the offset
+        double best_e = 0.0, best_X[3] = {0, 0, 0};
+        uint32_t best_g = 0;
+        bool have = false;
+        for (; g < g_end; g++) {
+          if (g >= goff[r + 1]) {
+            // leaving root r: flush the segment (lane, root)
+            const int s = tid + outslot[r];
+            seg_e[s] = best_e;
+            seg_g[s] = best_g;
+            seg_x[3 * s + 0] = best_X[0];
+            seg_x[3 * s + 1] = best_X[1];
+            seg_x[3 * s + 2] = best_X[2];
+            have = false;
+            do { r++; } while (goff[r + 1] <= g);
+          }
+          const uint32_t gl = g - goff[r];
+          const int rc = root_cam[r];
+          const uint16_t rb = root_blob[r];
+          const uint16_t* nhr = nh + (size_t)r * C;
+          const uint16_t* hr = hits + (size_t)r * C * M;
+          uint32_t rem = gl;
+          // pass 1 decodes the mixed-radix group index (camera rc+1 = fastest digit,
+          // helpers.py:394-400) and parks the blob index per camera for pass 2
+          auto obs1 = [&](int c, double& x, double& y) -> bool {
+            uint16_t s = kNone;
+            if (c == rc) {
+              s = rb;
+            } else if (c > rc) {
+              const uint32_t n = nhr[c];
+              if (n) {
+                const uint32_t qd = rem / n;
+                const uint32_t dgt = rem - qd * n;
+                rem = qd;
+                s = hr[(size_t)c * M + dgt];
+              }
+            }
+            sel[c] = s;
+            if (s == kNone) return false;
+            x = (double)bx[(size_t)c * M + s];
+            y = (double)by[(size_t)c * M + s];
+            return true;
+          };
+          auto obs2 = [&](int c, double& x, double& y) -> bool {
+            const uint16_t s = sel[c];
+            if (s == kNone) return false;
+            x = (double)bx[(size_t)c * M + s];
+            y = (double)by[(size_t)c * M + s];
+            return true;
+          };
+          double X[3], e;
+          triangulate_and_score<UNIFORM_K, true>(cv, obs1, obs2, X, e);
+          if (!have || e < best_e) {  // strict <: first minimum within the lane's ascending run
+            have = true;
+            best_e = e;
+            best_g = gl;
+            best_X[0] = X[0];
+            best_X[1] = X[1];
+            best_X[2] = X[2];
+          }
+        }
+        const int s = tid + outslot[r];
+        seg_e[s] = best_e;
+        seg_g[s] = best_g;
+        seg_x[3 * s + 0] = best_X[0];
+        seg_x[3 * s + 1] = best_X[1];
+        seg_x[3 * s + 2] = best_X[2];
+      }
+    }
+    __syncthreads();
+
+    // ---------------------------------------------------------------- E: select + write out
+    if (tid == 0) {
+      p.n_out[frame] = status ? 0 : misc[2];
+      p.status[frame] = status;
+      if (p.n_cand) p.n_cand[frame] = (int32_t)G;
+    }
+    if (G) {
+      const uint32_t q = (G + T - 1) / T;
+      for (int r = tid; r < nroots; r += T) {
+        const int k = outslot[r];
+        if (k < 0) continue;
+        const uint32_t t0 = goff[r] / q, t1 = (goff[r + 1] - 1) / q;
+        int sbest = (int)t0 + k;
+        double eb = seg_e[sbest];
+        for (uint32_t t = t0 + 1; t <= t1; t++) {
+          const int s = (int)t + k;
+          const double e = seg_e[s];
+          if (e < eb) {  // NaN never wins; earlier segment wins ties (np.argmin, helpers.py:418)
+            eb = e;
+            sbest = s;
+          }
+        }
+        const size_t o = (size_t)frame * R + k;
+        p.xyz[o * 3 + 0] = seg_x[3 * sbest + 0];
+        p.xyz[o * 3 + 1] = seg_x[3 * sbest + 1];
+        p.xyz[o * 3 + 2] = seg_x[3 * sbest + 2];
+        p.err[o] = eb;
+        // decode the winning group
+        uint32_t rem = seg_g[sbest];
+        const int rc = root_cam[r];
+        int16_t* co = p.corr + o * C;
+        for (int c = 0; c < C; c++) {
+          int16_t s = -1;
+          if (c == rc) {
+            s = (int16_t)root_blob[r];
+          } else if (c > rc) {
+            const uint32_t n = nh[(size_t)r * C + c];
+            if (n) {
+              const uint32_t qd = rem / n;
+              s = (int16_t)hits[((size_t)r * C + c) * M + (rem - qd * n)];
+              rem = qd;
+            }
+          }
+          co[c] = s;
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <int T>
+static hipError_t launch_T(const FrameArgs& a, int grid, size_t lds, hipStream_t stream) {
+  auto k = a.cv.uniformK ? frame_kernel<T, true> : frame_kernel<T, false>;
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(k, dim3(grid), dim3(T), lds, stream, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_frame_kernel(const FrameArgs& a, int threads, int grid, hipStream_t stream) {
+  const size_t lds = frame_lds_bytes(a.cv.C, a.M, a.K_max, threads);
+  switch (threads) {
+    case 64: return launch_T<64>(a, grid, lds, stream);
+    case 128: return launch_T<128>(a, grid, lds, stream);
+    case 256: return launch_T<256>(a, grid, lds, stream);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+}  // namespace mocap

@@ -1,0 +1,82 @@
+// kernels.hpp -- host-visible launch interface of the HIP kernels (internal to the .so).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mocap_device.hpp"
+
+namespace mocap {
+
+// status bits, mirrored from include/mocap_core.h (MOCAP_ST_*)
+constexpr int MOCAP_ST_ROOT_OVERFLOW_ = 1;
+constexpr int MOCAP_ST_CAND_OVERFLOW_ = 2;
+
+struct FrameArgs {
+  CamView cv;
+  int64_t n_frames;
+  int M;      // blob slots per camera
+  int K_max;  // root / output capacity per frame
+  double gate_px;
+  int64_t G_cap;
+  const float* blobs;     // [F][C][M][2]
+  const int32_t* counts;  // [F][C]
+  double* xyz;            // [F][K_max][3]
+  double* err;            // [F][K_max]
+  int16_t* corr;          // [F][K_max][C]
+  int32_t* n_out;         // [F]
+  int32_t* status;        // [F]
+  int32_t* n_cand;        // [F] or null
+};
+
+size_t frame_lds_bytes(int C, int M, int R, int T);
+hipError_t launch_frame_kernel(const FrameArgs& a, int threads, int grid, hipStream_t stream);
+
+// explicit-correspondence triangulation, optionally batched over P camera sets (bundle adjustment)
+struct TriArgs {
+  CamView cv;             // tables of camera set 0; set p is offset by the strides below
+  int64_t N;              // points
+  int P;                  // camera sets (1 for plain triangulation)
+  size_t stride_Pq, stride_RT;  // doubles between consecutive camera sets
+  const double* obs;      // [N][C][2], NaN = unseen
+  double* xyz;            // [P][N][3] or null
+  double* err;            // [P][N] or null
+};
+hipError_t launch_triangulate(const TriArgs& a, hipStream_t stream);
+
+// ---- bundle adjustment building blocks (csrc/ba_kernels.hip)
+struct BaCamArgs {
+  int C, n, P, uniformK;
+  const double* params;  // [P][n]
+  const double* K;       // [C][9]
+  double* Pq;            // [P][...]
+  double* RT;            // [P][C][12]
+  size_t stride_Pq, stride_RT;
+};
+hipError_t launch_ba_build_cameras(const BaCamArgs& a, hipStream_t stream);
+
+// x (n) -> params [n+1][n]: row 0 = x, row 1+j = x + h_j e_j ; h written to hvec [n]
+hipError_t launch_ba_perturb(const double* x, int n, double rel_step, double* params, double* hvec,
+                             hipStream_t stream);
+
+struct BaJacArgs {
+  int n, NP;             // parameters, padded row length of Jaug (multiple of 16, >= n + 1)
+  int64_t N, m;          // points, valid points
+  const int32_t* valid;  // [m] indices of valid points
+  const double* r;       // [n+1][N] residuals (row 0 at x)
+  const double* hvec;    // [n]
+  int f32_residuals, use_cauchy;
+  double* Jaug;          // [m_pad][NP]: scaled J | scaled f | 0 padding; m_pad = ceil(m/4)*4
+  double* rho0;          // [m] loss values (cost = 0.5 * sum)
+};
+hipError_t launch_ba_jacobian(const BaJacArgs& a, hipStream_t stream);
+
+// G = Jaug^T Jaug on the matrix cores (v_mfma_f64_16x16x4_f64); G [NP][NP]
+hipError_t launch_ba_gram(const double* Jaug, int64_t m_pad, int NP, double* partial, int ksplit,
+                          double* G, hipStream_t stream);
+int ba_gram_ksplit(int64_t m_pad, int NP);
+
+// cost-only evaluation: sum of rho over valid points of residual row r [N]
+hipError_t launch_ba_cost(const double* r, const int32_t* valid, int64_t m, int f32_residuals,
+                          int use_cauchy, double* out /*[2]: cost, finite flag*/, hipStream_t stream);
+
+}  // namespace mocap

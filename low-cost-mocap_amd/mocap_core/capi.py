@@ -1,0 +1,228 @@
+"""ctypes binding of the C ABI in include/mocap_core.h (lib/libmocap_core.so).
+
+This is the host side of the drop-in boundary.  There is NO CPU fallback: if the shared
+library is missing or no MI355X is visible, construction raises.  Marshalling only --
+every number comes from the HIP kernels.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_PKG_ROOT, "lib", "libmocap_core.so")
+
+MOCAP_OK = 0
+MOCAP_E_NOCONV = -5
+ST_ROOT_OVERFLOW = 1
+ST_CAND_OVERFLOW = 2
+OPT_F32_ROUNDING = 1
+
+_vp, _i32, _i64, _dbl, _u32 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_double, ctypes.c_uint32
+
+# name -> (restype, argtypes); must list every symbol include/mocap_core.h declares
+SIGNATURES = {
+    "mocap_create": (_i32, [_i32, ctypes.POINTER(_vp)]),
+    "mocap_destroy": (None, [_vp]),
+    "mocap_last_error": (ctypes.c_char_p, [_vp]),
+    "mocap_version": (ctypes.c_char_p, []),
+    "mocap_set_stream": (_i32, [_vp, _vp]),
+    "mocap_synchronize": (_i32, [_vp]),
+    "mocap_set_options": (_i32, [_vp, _u32]),
+    "mocap_limits": (None, [ctypes.POINTER(_i32), ctypes.POINTER(_i32)]),
+    "mocap_set_cameras": (_i32, [_vp, _i32, _vp, _vp, _vp]),
+    "mocap_get_fundamental": (_i32, [_vp, _vp]),
+    "mocap_triangulate": (_i32, [_vp, _i64, _vp, _vp, _vp]),
+    "mocap_triangulate_dev": (_i32, [_vp, _i64, _vp, _vp, _vp]),
+    "mocap_match_triangulate": (_i32, [_vp, _i64, _i32, _vp, _vp, _dbl, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mocap_match_triangulate_dev": (_i32, [_vp, _i64, _i32, _vp, _vp, _dbl, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mocap_ba_residuals": (_i32, [_vp, _i32, _vp, _i64, _vp, _vp]),
+    "mocap_ba_normal_eq": (_i32, [_vp, _vp, _i64, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "mocap_ba_solve": (_i32, [_vp, _vp, _i64, _vp, _dbl, _dbl, _dbl, _i32, _i32, _i32, _vp]),
+}
+
+_lib = None
+
+
+class MocapError(RuntimeError):
+    pass
+
+
+def load_library(path=None):
+    """dlopen the core.  Raises (never falls back) when the library is absent."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise MocapError(f"{p} not found: build it with `make -C {_PKG_ROOT}` (hipcc, gfx950); "
+                         "there is no CPU fallback")
+    lib = ctypes.CDLL(p)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)      # AttributeError = the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+class MocapCore:
+    """One context = one GPU (include/mocap_core.h).  Methods mirror the C entry points."""
+
+    def __init__(self, device_id=0):
+        self.lib = load_library()
+        h = ctypes.c_void_p()
+        rc = self.lib.mocap_create(int(device_id), ctypes.byref(h))
+        if rc != MOCAP_OK:
+            raise MocapError(f"mocap_create(device {device_id}) failed with {rc}: no MI355X visible? "
+                             "(there is no CPU fallback)")
+        self._h = h
+        self.device_id = int(device_id)
+        self.C = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.mocap_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, allow=()):
+        if rc != MOCAP_OK and rc not in allow:
+            raise MocapError(f"mocap_core error {rc}: {self.lib.mocap_last_error(self._h).decode()}")
+        return rc
+
+    # ------------------------------------------------------------------ configuration
+    def set_cameras(self, K, R, t):
+        K = np.ascontiguousarray(K, dtype=np.float64).reshape(-1, 9)
+        C = K.shape[0]
+        R = np.ascontiguousarray(R, dtype=np.float64).reshape(C, 9)
+        t = np.ascontiguousarray(t, dtype=np.float64).reshape(C, 3)
+        self._check(self.lib.mocap_set_cameras(self._h, C, _p(K), _p(R), _p(t)))
+        self.C = C
+
+    def set_options(self, f32_rounding=True):
+        self._check(self.lib.mocap_set_options(self._h, OPT_F32_ROUNDING if f32_rounding else 0))
+
+    def set_stream(self, hip_stream_handle):
+        self._check(self.lib.mocap_set_stream(self._h, ctypes.c_void_p(hip_stream_handle or 0)))
+
+    def synchronize(self):
+        self._check(self.lib.mocap_synchronize(self._h))
+
+    def fundamental(self):
+        F = np.zeros((self.C, self.C, 3, 3))
+        self._check(self.lib.mocap_get_fundamental(self._h, _p(F)))
+        return F
+
+    # ------------------------------------------------------------------ host-buffer entry points
+    def triangulate(self, obs):
+        obs = np.ascontiguousarray(obs, dtype=np.float64).reshape(-1, self.C, 2)
+        N = obs.shape[0]
+        xyz = np.empty((N, 3))
+        err = np.empty(N)
+        self._check(self.lib.mocap_triangulate(self._h, N, _p(obs), _p(xyz), _p(err)))
+        return xyz, err
+
+    def match_triangulate(self, blobs, counts, gate_px=5.0, K_max=None, G_cap=1 << 20):
+        blobs = np.ascontiguousarray(blobs, dtype=np.float32)
+        counts = np.ascontiguousarray(counts, dtype=np.int32)
+        F, C, M, _ = blobs.shape
+        assert C == self.C and counts.shape == (F, C)
+        K_max = min(C * M, 64) if K_max is None else int(K_max)
+        xyz = np.full((F, K_max, 3), np.nan)
+        err = np.full((F, K_max), np.nan)
+        corr = np.full((F, K_max, C), -1, dtype=np.int16)
+        n_out = np.zeros(F, dtype=np.int32)
+        status = np.zeros(F, dtype=np.int32)
+        n_cand = np.zeros(F, dtype=np.int32)
+        self._check(self.lib.mocap_match_triangulate(self._h, F, M, _p(blobs), _p(counts), float(gate_px), K_max,
+                                                     int(G_cap), _p(xyz), _p(err), _p(corr), _p(n_out),
+                                                     _p(status), _p(n_cand)))
+        return {"xyz": xyz, "err": err, "corr": corr, "n_out": n_out, "status": status, "n_cand": n_cand}
+
+    def match_triangulate_auto(self, blobs, counts, gate_px=5.0, K_max=None, G_cap=1 << 20):
+        """match_triangulate, then frames whose caps overflowed are re-submitted ON THE GPU with the
+        worst-case root capacity (C*M) and the largest candidate cap."""
+        res = self.match_triangulate(blobs, counts, gate_px, K_max, G_cap)
+        bad = np.nonzero(res["status"])[0]
+        if bad.size:
+            F, C, M, _ = np.shape(blobs)
+            big = self.match_triangulate(np.asarray(blobs)[bad], np.asarray(counts)[bad], gate_px, C * M, 1 << 24)
+            k0 = res["xyz"].shape[1]
+            if big["n_out"].max(initial=0) > k0:
+                grow = int(big["n_out"].max())
+                for key, fill in (("xyz", np.nan), ("err", np.nan), ("corr", -1)):
+                    shape = list(res[key].shape)
+                    shape[1] = grow
+                    new = np.full(shape, fill, dtype=res[key].dtype)
+                    new[:, :k0] = res[key]
+                    res[key] = new
+                k0 = grow
+            for j, f in enumerate(bad):
+                for key in ("xyz", "err", "corr"):
+                    res[key][f] = big[key][j][:k0]
+                for key in ("n_out", "status", "n_cand"):
+                    res[key][f] = big[key][j]
+        return res
+
+    # ------------------------------------------------------------------ device-pointer entry points
+    def match_triangulate_dev(self, n_frames, M_max, d_blobs, d_counts, gate_px, K_max, G_cap, d_xyz, d_err,
+                              d_corr, d_n_out, d_status, d_n_cand=0):
+        """Raw device pointers (ints); enqueues on the context's stream and returns."""
+        self._check(self.lib.mocap_match_triangulate_dev(
+            self._h, int(n_frames), int(M_max), _vp(d_blobs), _vp(d_counts), float(gate_px), int(K_max),
+            int(G_cap), _vp(d_xyz), _vp(d_err), _vp(d_corr), _vp(d_n_out), _vp(d_status), _vp(d_n_cand or 0)))
+
+    def triangulate_dev(self, N, d_obs, d_xyz, d_err):
+        self._check(self.lib.mocap_triangulate_dev(self._h, int(N), _vp(d_obs), _vp(d_xyz), _vp(d_err or 0)))
+
+    # ------------------------------------------------------------------ bundle adjustment
+    def n_params(self):
+        return 1 + 7 * (self.C - 1)
+
+    def ba_residuals(self, params, obs):
+        params = np.ascontiguousarray(np.atleast_2d(params), dtype=np.float64)
+        obs = np.ascontiguousarray(obs, dtype=np.float64).reshape(-1, self.C, 2)
+        P, N = params.shape[0], obs.shape[0]
+        assert params.shape[1] == self.n_params()
+        r = np.empty((P, N))
+        self._check(self.lib.mocap_ba_residuals(self._h, P, _p(params), N, _p(obs), _p(r)))
+        return r
+
+    def ba_normal_eq(self, x, obs, f32_residuals=False, use_cauchy=True, want_J=False):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        obs = np.ascontiguousarray(obs, dtype=np.float64).reshape(-1, self.C, 2)
+        n, N = self.n_params(), obs.shape[0]
+        JtJ = np.empty((n, n))
+        Jtr = np.empty(n)
+        cost = ctypes.c_double()
+        m = ctypes.c_int64()
+        J = np.zeros((N, n)) if want_J else None
+        self._check(self.lib.mocap_ba_normal_eq(self._h, _p(x), N, _p(obs), int(f32_residuals), int(use_cauchy),
+                                                _p(JtJ), _p(Jtr), ctypes.addressof(cost), _p(J),
+                                                ctypes.addressof(m)))
+        out = {"JtJ": JtJ, "Jtr": Jtr, "cost": cost.value, "m": m.value}
+        if want_J:
+            out["J"] = J[:m.value]
+        return out
+
+    def ba_solve(self, x0, obs, ftol=1e-2, xtol=1e-8, gtol=1e-8, max_iter=0, f32_residuals=True,
+                 use_cauchy=True):
+        x = np.array(x0, dtype=np.float64)
+        obs = np.ascontiguousarray(obs, dtype=np.float64).reshape(-1, self.C, 2)
+        info = np.zeros(8)
+        rc = self._check(self.lib.mocap_ba_solve(self._h, _p(x), obs.shape[0], _p(obs), float(ftol), float(xtol),
+                                                 float(gtol), int(max_iter), int(f32_residuals), int(use_cauchy),
+                                                 _p(info)), allow=(MOCAP_E_NOCONV,))
+        keys = ("iterations", "nfev", "status", "cost0", "cost", "optimality", "m", "elapsed_ms")
+        return x, dict(zip(keys, info.tolist()), converged=(rc == MOCAP_OK))

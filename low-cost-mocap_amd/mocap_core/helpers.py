@@ -1,0 +1,240 @@
+"""Host-side mirror of the reference's hot-path seam (computer_code/api/helpers.py:203-421).
+
+Same function names, argument conventions, return shapes and error behaviour as the four
+module-level functions `api/index.py:1` imports from `helpers`, so the Flask/socket.io
+layer, the UI and the drone path are untouched (INTEGRATION.md shows the 6-line patch):
+
+    find_point_correspondance_and_object_points(image_points, camera_poses, frames)   helpers.py:339
+    triangulate_points(image_points, camera_poses)                                    helpers.py:330
+    calculate_reprojection_errors(image_points, object_points, camera_poses)          helpers.py:203
+    bundle_adjustment(image_points, camera_poses, socketio)                           helpers.py:244
+  (+ the singular forms triangulate_point / calculate_reprojection_error)
+
+Everything numeric runs in the HIP core through the C ABI (mocap_core.capi); this file only
+converts between the reference's nested lists / None sentinels and the packed arrays of
+include/mocap_core.h.  There is no CPU fallback: without the .so or a GPU these raise.
+
+Intrinsics: the reference reads them from the `Cameras` singleton (helpers.py:215,295,340);
+here `set_camera_params()` takes the same list of {"intrinsic_matrix": 3x3, ...} dicts
+(the content of api/camera-params.json).
+"""
+import threading
+
+import numpy as np
+
+from . import capi
+
+_state = {
+    "core": None,
+    "camera_params": None,   # list of dicts like api/camera-params.json
+    "cam_key": None,         # bytes of (K, R, t) currently uploaded
+    "lock": threading.Lock(),
+    "ba_mode": "resident",   # "resident" (LM loop in the core) | "scipy" (reference optimizer, GPU residuals)
+}
+
+
+def get_core(device_id=0):
+    if _state["core"] is None:
+        _state["core"] = capi.MocapCore(device_id)
+    return _state["core"]
+
+
+def set_core(core):
+    """Use an existing MocapCore (e.g. one per GPU in a frame-sharded run)."""
+    _state["core"] = core
+    _state["cam_key"] = None
+
+
+def set_camera_params(camera_params):
+    """camera_params: list of {"intrinsic_matrix": 3x3 list, ...} (api/camera-params.json)."""
+    _state["camera_params"] = [dict(p) for p in camera_params]
+    _state["cam_key"] = None
+
+
+def set_bundle_adjustment_mode(mode):
+    assert mode in ("resident", "scipy")
+    _state["ba_mode"] = mode
+
+
+def _intrinsics(C):
+    params = _state["camera_params"]
+    if params is None:
+        raise RuntimeError("set_camera_params() has not been called (the reference loads camera-params.json)")
+    if len(params) < C:
+        raise IndexError("fewer camera_params entries than camera poses")  # the reference raises IndexError
+    return np.array([np.array(params[i]["intrinsic_matrix"], dtype=np.float64) for i in range(C)])
+
+
+def _pose_arrays(camera_poses):
+    R = np.array([np.array(p["R"], dtype=np.float64).reshape(3, 3) for p in camera_poses])
+    t = np.array([np.array(p["t"], dtype=np.float64).reshape(3) for p in camera_poses])
+    return R, t
+
+
+def _upload_cameras(camera_poses):
+    """mocap_set_cameras only when (K, R, t) changed -- replaces the per-call rebuild of P = K[R|t]
+    (helpers.py:305-308, :351-355) and the per-root fundamentalFromProjections (helpers.py:362)."""
+    core = get_core()
+    R, t = _pose_arrays(camera_poses)
+    K = _intrinsics(len(camera_poses))
+    key = K.tobytes() + R.tobytes() + t.tobytes()
+    if key != _state["cam_key"]:
+        core.set_cameras(K, R, t)
+        _state["cam_key"] = key
+    return core
+
+
+def _obs_array(image_points, C):
+    """(N, C, 2) list / object ndarray with None -> float64 with NaN."""
+    arr = np.asarray(image_points, dtype=object).reshape(-1, C, 2)
+    out = np.full(arr.shape, np.nan)
+    mask = np.vectorize(lambda v: v is not None)(arr) if arr.size else np.zeros(arr.shape, bool)
+    out[mask] = arr[mask].astype(np.float64)
+    bad = ~(mask[..., 0] & mask[..., 1])
+    out[bad] = np.nan
+    return out
+
+
+# ----------------------------------------------------------------------------- triangulation
+def triangulate_points(image_points, camera_poses):
+    """helpers.py:330-336.  Rows with fewer than two views are [None, None, None]."""
+    C = len(camera_poses)
+    with _state["lock"]:
+        core = _upload_cameras(camera_poses)
+        obs = _obs_array(image_points, C)
+        if obs.shape[0] == 0:
+            return np.array([])
+        xyz, _ = core.triangulate(obs)
+    missing = np.isnan(xyz[:, 0])
+    if not missing.any():
+        return xyz
+    out = xyz.astype(object)
+    out[missing] = None
+    return out
+
+
+def triangulate_point(image_points, camera_poses):
+    """helpers.py:293-327."""
+    res = triangulate_points([image_points], camera_poses)
+    row = res[0]
+    return [None, None, None] if row[0] is None else np.asarray(row, dtype=np.float64)
+
+
+def calculate_reprojection_errors(image_points, object_points, camera_poses):
+    """helpers.py:203-211: entries with fewer than two views are skipped (the result may be shorter).
+
+    NOTE: like the reference's only callers (helpers.py:272,416; index.py:275) the object points are
+    expected to be the triangulation of `image_points` under `camera_poses`; the core recomputes them."""
+    C = len(camera_poses)
+    with _state["lock"]:
+        core = _upload_cameras(camera_poses)
+        obs = _obs_array(image_points, C)
+        if obs.shape[0] == 0:
+            return np.array([])
+        _, err = core.triangulate(obs)
+    return err[~np.isnan(err)]
+
+
+def calculate_reprojection_error(image_points, object_point, camera_poses):
+    """helpers.py:214-241: None when fewer than two cameras see the point."""
+    e = calculate_reprojection_errors([image_points], [object_point], camera_poses)
+    return None if e.size == 0 else e[0]
+
+
+# ----------------------------------------------------------------------------- frame path
+def pack_frame(image_points, M_max=None):
+    """Nested lists of one frame -> (blobs f32 [1][C][M][2], counts i32 [1][C])."""
+    C = len(image_points)
+    n = [len(p) for p in image_points]
+    M = max(1, max(n) if n else 1) if M_max is None else M_max
+    blobs = np.full((1, C, M, 2), np.nan, dtype=np.float32)
+    counts = np.zeros((1, C), dtype=np.int32)
+    for c, pts in enumerate(image_points):
+        if pts:
+            blobs[0, c, :len(pts)] = np.asarray(pts, dtype=np.float32)
+        counts[0, c] = len(pts)
+    return blobs, counts
+
+
+def find_point_correspondance_and_object_points(image_points, camera_poses, frames):
+    """helpers.py:339-421.  `image_points` is mutated like the reference does (the [None, None]
+    sentinel of an empty camera is removed, helpers.py:342-346).  `frames` is returned untouched:
+    the reference only draws debug epipolar lines into it (helpers.py:365)."""
+    for image_points_i in image_points:
+        try:
+            image_points_i.remove([None, None])
+        except Exception:
+            pass
+    with _state["lock"]:
+        core = _upload_cameras(camera_poses)
+        blobs, counts = pack_frame(image_points)
+        res = core.match_triangulate_auto(blobs, counts, gate_px=5.0)
+    k = int(res["n_out"][0])
+    if k == 0:
+        return np.array([]), np.array([]), frames
+    return res["err"][0, :k].copy(), res["xyz"][0, :k].copy(), frames
+
+
+def find_point_correspondance_and_object_points_batch(blobs, counts, camera_poses, gate_px=5.0, K_max=None):
+    """Batch form on the packed layout (many frames per call); also returns the correspondence indices."""
+    with _state["lock"]:
+        core = _upload_cameras(camera_poses)
+        return core.match_triangulate_auto(blobs, counts, gate_px=gate_px, K_max=K_max)
+
+
+# ----------------------------------------------------------------------------- bundle adjustment
+def _ba_x0(camera_poses):
+    """helpers.py:278-285 (including its focal-length indexing: entry i+1 takes camera i's focal)."""
+    from scipy.spatial.transform import Rotation
+    K = _intrinsics(len(camera_poses))
+    x0 = [K[0][0, 0]]
+    for i, pose in enumerate(camera_poses[1:]):
+        rot_vec = Rotation.from_matrix(np.asarray(pose["R"], dtype=np.float64)).as_rotvec().flatten()
+        x0 += [K[i][0, 0]] + rot_vec.tolist() + np.asarray(pose["t"], dtype=np.float64).flatten().tolist()
+    return np.array(x0, dtype=np.float64)
+
+
+def _params_to_camera_poses(params):
+    """helpers.py:247-262."""
+    from scipy.spatial.transform import Rotation
+    C = int((params.size - 1) / 7) + 1
+    poses = [{"R": np.eye(3), "t": np.array([0, 0, 0], dtype=np.float32)}]
+    for i in range(C - 1):
+        poses.append({"R": Rotation.from_rotvec(params[i * 7 + 2:i * 7 + 5]).as_matrix(),
+                      "t": params[i * 7 + 5:i * 7 + 8]})
+    return poses
+
+
+def camera_pose_to_serializable(camera_poses):
+    """helpers.py:526-530."""
+    return [{k: np.asarray(v).tolist() for k, v in p.items()} for p in camera_poses]
+
+
+def bundle_adjustment(image_points, camera_poses, socketio, return_info=False):
+    """helpers.py:244-290: least_squares(residual_function, x0, loss="cauchy", ftol=1e-2).
+
+    mode "resident" (default): the whole trust-region loop runs in the core (mocap_ba_solve).
+    mode "scipy": the reference's optimizer call verbatim, only the residual evaluations are GPU.
+    `socketio.emit("camera-pose", ...)` is sent with the final poses (the reference streams one per
+    residual evaluation, helpers.py:274)."""
+    C = len(camera_poses)
+    x0 = _ba_x0(camera_poses)
+    with _state["lock"]:
+        core = _upload_cameras(camera_poses)
+        obs = _obs_array(image_points, C)
+        if _state["ba_mode"] == "resident":
+            x, info = core.ba_solve(x0, obs, ftol=1e-2, f32_residuals=True, use_cauchy=True)
+        else:
+            from scipy import optimize
+
+            def residual_function(params):
+                r = core.ba_residuals(params, obs)[0]
+                return r[~np.isnan(r)].astype(np.float32)       # helpers.py:273
+
+            res = optimize.least_squares(residual_function, x0, verbose=0, loss="cauchy", ftol=1e-2)
+            x, info = res.x, {"iterations": res.njev, "nfev": res.nfev, "status": res.status, "cost": res.cost}
+        _state["cam_key"] = None
+    poses = _params_to_camera_poses(x)
+    if socketio is not None:
+        socketio.emit("camera-pose", {"camera_poses": camera_pose_to_serializable(poses)})
+    return (poses, info) if return_info else poses
