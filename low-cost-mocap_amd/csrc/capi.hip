@@ -80,6 +80,8 @@ extern "C" int mocap_create(int device_id, mocap_ctx** out) {
     int v = atoi(t);
     if (v == 64 || v == 128 || v == 256) c->frame_threads = v;
   }
+  if ((t = getenv("MOCAP_HEAVY_THRESHOLD"))) c->heavy_threshold = atoi(t);  // 0 disables splitting
+  if ((t = getenv("MOCAP_SLICE_SIZE"))) c->slice_size = atoi(t);
   *out = c;
   return MOCAP_OK;
 }
@@ -332,15 +334,46 @@ static int match_dev_locked(mocap_ctx* ctx, int64_t n_frames, int M_max, const f
   if (lds > 160 * 1024)
     return ctx->fail(MOCAP_E_LIMIT, "frame state needs %zu B of LDS (C=%d, M_max=%d, K_max=%d): lower K_max",
                      lds, ctx->C, M_max, K_max);
-  // persistent-style grid: enough workgroups to fill every CU at the LDS-limited occupancy
+  // persistent grid: enough workgroups to fill every CU at the LDS-limited occupancy
   int per_cu = (int)((160 * 1024) / lds);
   const int wave_cap = 32 / (T / 64);
   if (per_cu > wave_cap) per_cu = wave_cap;
   if (per_cu > 8) per_cu = 8;
   if (per_cu < 1) per_cu = 1;
-  int64_t grid = (int64_t)ctx->num_cus * per_cu;
-  if (grid > n_frames) grid = n_frames;
-  HIP_TRY(ctx, launch_frame_kernel(a, T, (int)grid, ctx->stream));
+  const int64_t full_grid = (int64_t)ctx->num_cus * per_cu;
+  int64_t grid = full_grid < n_frames ? full_grid : n_frames;
+
+  // work queues: heavy-frame list + slice partials (scheduling note in frame_kernel.hip)
+  const bool batch = n_frames >= 2 * full_grid;
+  FrameQueues& q = a.q;
+  q.heavy_threshold = ctx->heavy_threshold >= 0 ? (uint32_t)ctx->heavy_threshold : (batch ? 16384u : 2u * T);
+  q.slice_size = ctx->slice_size > 0 ? (uint32_t)ctx->slice_size : (batch ? 8192u : 4u * T);
+  int64_t H = n_frames / 8;
+  if (H < 64) H = 64;
+  if (H > n_frames) H = n_frames;
+  q.H_cap = (int)H;
+  q.W_cap = (int)(H * 8 < 64 ? 64 : H * 8);
+  auto al = [](size_t x) { return (x + 255) / 256 * 256; };
+  const size_t b_cnt = al(sizeof(int32_t) * QC_COUNT), b_heavy = al(sizeof(int32_t) * 4 * (size_t)q.H_cap),
+               b_slice = al(sizeof(int32_t) * (size_t)q.W_cap), b_pe = al(sizeof(double) * (size_t)q.W_cap * K_max),
+               b_pg = al(sizeof(uint32_t) * (size_t)q.W_cap * K_max), b_px = al(sizeof(double) * 3 * (size_t)q.W_cap * K_max);
+  DevBuf& wq = ctx->scratch[3];
+  if (wq.reserve(b_cnt + b_heavy + b_slice + b_pe + b_pg + b_px))
+    return ctx->fail(MOCAP_E_HIP, "hipMalloc(frame work queues) failed");
+  char* w = (char*)wq.ptr;
+  q.counters = (int32_t*)w;     w += b_cnt;
+  q.slice_heavy = (int32_t*)w;  w += b_slice;
+  q.heavy = (int32_t*)w;        w += b_heavy;
+  q.part_e = (double*)w;        w += b_pe;
+  q.part_g = (uint32_t*)w;      w += b_pg;
+  q.part_x = (double*)w;
+  HIP_TRY(ctx, hipMemsetAsync(q.counters, 0, b_cnt, ctx->stream));
+  if (q.heavy_threshold) HIP_TRY(ctx, hipMemsetAsync(q.slice_heavy, 0xFF, b_slice, ctx->stream));
+  HIP_TRY(ctx, launch_frame_kernel(a, MODE_MAIN, T, (int)grid, ctx->stream));
+  if (q.heavy_threshold) {
+    HIP_TRY(ctx, launch_frame_kernel(a, MODE_SLICE, T, (int)(full_grid < q.W_cap ? full_grid : q.W_cap), ctx->stream));
+    HIP_TRY(ctx, launch_frame_kernel(a, MODE_MERGE, T, (int)(full_grid < q.H_cap ? full_grid : q.H_cap), ctx->stream));
+  }
   return MOCAP_OK;
 }
 

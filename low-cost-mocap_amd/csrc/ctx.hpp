@@ -19,6 +19,8 @@ struct mocap_ctx {
   int device = 0;
   int num_cus = 256;
   int frame_threads = 256;  // workgroup size of the frame kernel (MOCAP_FRAME_THREADS=64|128|256)
+  int heavy_threshold = -1; // -1 = automatic; 0 = never split heavy frames (MOCAP_HEAVY_THRESHOLD)
+  int slice_size = 0;       // 0 = automatic (MOCAP_SLICE_SIZE)
   hipStream_t own_stream = nullptr, stream = nullptr;
   std::mutex mu;            // one context = one serialised caller (include/mocap_core.h)
   std::string err;

@@ -1,9 +1,9 @@
 // frame_kernel.hip -- per-frame epipolar correspondence search + candidate triangulation +
-// per-root selection, fused in one launch.  Replaces
+// per-root selection.  Replaces
 //   find_point_correspondance_and_object_points   (reference computer_code/api/helpers.py:339-421)
-// for a batch of independent frames: one workgroup per frame, every intermediate (blobs, roots,
-// sorted hit lists, candidate bookkeeping) lives in LDS; HBM sees only the blob arrays in and
-// the kept points out (~2 KB per 8x16 frame).
+// for a batch of independent frames.  One workgroup works on one frame at a time; every
+// intermediate (blobs, roots, sorted hit lists, candidate bookkeeping) lives in LDS; HBM sees only
+// the blob arrays in and the kept points out (~2 KB per 8x16 frame).
 //
 // Phases per frame (T threads):
 //   A  coalesced load of the frame's blobs/counts into LDS
@@ -14,15 +14,28 @@
 //        B4 mark blobs equal (by value) to a root's closest hit (helpers.py:391)
 //        B5 ballot-compaction of the unclaimed blobs into new roots (helpers.py:402-406)
 //   C  per-root candidate counts (Cartesian product sizes, helpers.py:394-400), offsets
-//   D  flat candidate space [0, G) split into T contiguous runs; each lane triangulates and scores
-//      its run (csrc/mocap_device.hpp) keeping a (error, index) first-minimum per (lane, root)
-//      segment -- at most T + R segments per frame, stored in LDS, no atomics
+//   D  a range [g_lo, g_hi) of the flat candidate space is split into T contiguous runs; each lane
+//      triangulates and scores its run (csrc/mocap_device.hpp) keeping an (error, index)
+//      first-minimum per (lane, root) segment -- at most T + R segments, stored in LDS, no atomics
 //   E  one lane per kept root scans its segments (np.argmin first-minimum, helpers.py:418), decodes
 //      the winning group's blob indices and writes xyz / err / corr
+//
+// Scheduling.  The number of candidate groups per frame is heavy-tailed (8x16: median 2 k, mean
+// 3.4 k, p99 24 k, max > 200 k), so a static frame->workgroup map leaves most of the chip idle behind
+// a few monster frames.  Three launches of the same code, all fed by device-side atomic queues:
+//   MODE_MAIN   persistent workgroups pull frames from a global counter; a frame whose candidate
+//               count exceeds `heavy_threshold` is not evaluated but appended to a heavy list, cut
+//               into slices of the candidate space;
+//   MODE_SLICE  workgroups pull (heavy frame, slice) items, redo the cheap phases A-C (bit-identical
+//               by construction) and evaluate only their slice, writing per-root partial winners;
+//   MODE_MERGE  one workgroup per heavy frame redoes A-C and picks, per root, the first minimum
+//               over the slices in slice order -> same result as the single-workgroup evaluation.
 #include "mocap_device.hpp"
 #include "kernels.hpp"
 
 namespace mocap {
+
+constexpr uint16_t kNone = 0xFFFF;
 
 struct FrameLds {
   // byte offsets into dynamic LDS, computed identically on host (size) and device (carve)
@@ -32,9 +45,12 @@ struct FrameLds {
   __host__ __device__ FrameLds(int C, int M, int R, int T) {
     size_t o = 0;
     line = o;      o += sizeof(double) * 4 * R;
-    dist = o;      o += sizeof(double) * (size_t)R * M;
     seg_e = o;     o += sizeof(double) * (T + R);
     seg_x = o;     o += sizeof(double) * 3 * (T + R);
+    // dist (phase B scratch) and the segment arrays (phase D/E) are never live together
+    dist = line + sizeof(double) * 4 * R;
+    const size_t dist_end = dist + sizeof(double) * (size_t)R * M;
+    if (dist_end > o) o = dist_end;
     seg_g = o;     o += sizeof(uint32_t) * (T + R);
     goff = o;      o += sizeof(uint32_t) * (R + 1);
     gcnt = o;      o += sizeof(uint32_t) * R;
@@ -55,37 +71,48 @@ struct FrameLds {
 
 size_t frame_lds_bytes(int C, int M, int R, int T) { return FrameLds(C, M, R, T).total; }
 
-constexpr uint16_t kNone = 0xFFFF;
+// misc[] slots
+enum { MI_NROOTS = 0, MI_STATUS = 1, MI_NOUT = 2, MI_G = 3, MI_ITEM = 4, MI_DEFER = 5 };
 
 template <int T, bool UNIFORM_K>
-__global__ __launch_bounds__(T) void frame_kernel(FrameArgs p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const CamView cv = p.cv;
-  const int C = cv.C, M = p.M, R = p.K_max;
-  const int tid = threadIdx.x;
-  const FrameLds L(C, M, R, T);
-  double* line = (double*)(smem + L.line);
-  double* dist = (double*)(smem + L.dist);
-  double* seg_e = (double*)(smem + L.seg_e);
-  double* seg_x = (double*)(smem + L.seg_x);
-  uint32_t* seg_g = (uint32_t*)(smem + L.seg_g);
-  uint32_t* goff = (uint32_t*)(smem + L.goff);
-  uint32_t* gcnt = (uint32_t*)(smem + L.gcnt);
-  int32_t* outslot = (int32_t*)(smem + L.outslot);
-  float* bx = (float*)(smem + L.bx);
-  float* by = (float*)(smem + L.by);
-  int32_t* cnt = (int32_t*)(smem + L.cnt);
-  int32_t* misc = (int32_t*)(smem + L.misc);  // [0] nroots, [1] status, [2] n_out, [3] G
-  uint16_t* hits = (uint16_t*)(smem + L.hits);
-  uint16_t* sel = (uint16_t*)(smem + L.sel) + (size_t)tid * C;
-  uint16_t* nh = (uint16_t*)(smem + L.nh);
-  uint16_t* root_blob = (uint16_t*)(smem + L.root_blob);
-  uint8_t* root_cam = (uint8_t*)(smem + L.root_cam);
-  uint8_t* claimed = (uint8_t*)(smem + L.claimed);
-  const bool f32r = cv.f32_rounding != 0;
+struct FrameState {
+  const FrameArgs& p;
+  const CamView& cv;
+  const int C, M, R, tid;
+  double *line, *dist, *seg_e, *seg_x;
+  uint32_t *seg_g, *goff, *gcnt;
+  int32_t *outslot, *cnt, *misc;
+  float *bx, *by;
+  uint16_t *hits, *sel, *nh, *root_blob;
+  uint8_t *root_cam, *claimed;
 
-  for (int64_t frame = blockIdx.x; frame < p.n_frames; frame += gridDim.x) {
-    // ---------------------------------------------------------------- A: load
+  __device__ FrameState(const FrameArgs& p_, unsigned char* smem)
+      : p(p_), cv(p_.cv), C(p_.cv.C), M(p_.M), R(p_.K_max), tid(threadIdx.x) {
+    const FrameLds L(C, M, R, T);
+    line = (double*)(smem + L.line);
+    dist = (double*)(smem + L.dist);
+    seg_e = (double*)(smem + L.seg_e);
+    seg_x = (double*)(smem + L.seg_x);
+    seg_g = (uint32_t*)(smem + L.seg_g);
+    goff = (uint32_t*)(smem + L.goff);
+    gcnt = (uint32_t*)(smem + L.gcnt);
+    outslot = (int32_t*)(smem + L.outslot);
+    bx = (float*)(smem + L.bx);
+    by = (float*)(smem + L.by);
+    cnt = (int32_t*)(smem + L.cnt);
+    misc = (int32_t*)(smem + L.misc);
+    hits = (uint16_t*)(smem + L.hits);
+    sel = (uint16_t*)(smem + L.sel) + (size_t)tid * C;
+    nh = (uint16_t*)(smem + L.nh);
+    root_blob = (uint16_t*)(smem + L.root_blob);
+    root_cam = (uint8_t*)(smem + L.root_cam);
+    claimed = (uint8_t*)(smem + L.claimed);
+  }
+
+  // ---------------------------------------------------------------- phases A-C
+  // Leaves roots / hit lists / candidate offsets in LDS; returns with all lanes synchronised.
+  __device__ void match(int64_t frame) {
+    const bool f32r = cv.f32_rounding != 0;
     {
       const float2* src = (const float2*)(p.blobs + (size_t)frame * C * M * 2);
       for (int i = tid; i < C * M; i += T) {
@@ -97,26 +124,24 @@ __global__ __launch_bounds__(T) void frame_kernel(FrameArgs p) {
         int n = p.counts[(size_t)frame * C + tid];
         cnt[tid] = n < 0 ? 0 : (n > M ? M : n);
       }
-      if (tid == 0) misc[1] = 0;
+      if (tid == 0) misc[MI_STATUS] = 0;
     }
     __syncthreads();
-    // roots from camera 0 (helpers.py:349,357)
-    {
+    {  // roots from camera 0 (helpers.py:349,357)
       const int n0 = cnt[0];
       for (int r = tid; r < n0 && r < R; r += T) {
         root_cam[r] = 0;
         root_blob[r] = (uint16_t)r;
       }
       if (tid == 0) {
-        misc[0] = n0 < R ? n0 : R;
-        if (n0 > R) misc[1] |= MOCAP_ST_ROOT_OVERFLOW_;
+        misc[MI_NROOTS] = n0 < R ? n0 : R;
+        if (n0 > R) misc[MI_STATUS] |= MOCAP_ST_ROOT_OVERFLOW_;
       }
     }
     __syncthreads();
 
-    // ---------------------------------------------------------------- B: camera sweep
     for (int i = 1; i < C; i++) {
-      const int nroots = misc[0];
+      const int nroots = misc[MI_NROOTS];
       const int Mi = cnt[i];
       const float* pxs = bx + (size_t)i * M;
       const float* pys = by + (size_t)i * M;
@@ -124,7 +149,7 @@ __global__ __launch_bounds__(T) void frame_kernel(FrameArgs p) {
       // point: double math, scale by 1/sqrt(a^2+b^2), float32 result (helpers.py:363-364).
       for (int r = tid; r < nroots; r += T) {
         const int rc = root_cam[r], rb = root_blob[r];
-        const double* Fm = cv.F + 9 * ((size_t)rc * C + i);
+        ctab_t Fm = as_ctab(cv.F + 9 * ((size_t)rc * C + i));
         const double x = (double)bx[(size_t)rc * M + rb], y = (double)by[(size_t)rc * M + rb];
         double a = Fm[0] * x + Fm[1] * y + Fm[2];
         double b = Fm[3] * x + Fm[4] * y + Fm[5];
@@ -205,17 +230,17 @@ __global__ __launch_bounds__(T) void frame_kernel(FrameArgs p) {
         }
         if (tid == 0) {
           if (base_root > R) {
-            misc[1] |= MOCAP_ST_ROOT_OVERFLOW_;
+            misc[MI_STATUS] |= MOCAP_ST_ROOT_OVERFLOW_;
             base_root = R;
           }
-          misc[0] = base_root;
+          misc[MI_NROOTS] = base_root;
         }
       }
       __syncthreads();
     }
 
-    // ---------------------------------------------------------------- C: candidate counts
-    const int nroots = misc[0];
+    // C: candidate counts per root
+    const int nroots = misc[MI_NROOTS];
     for (int r = tid; r < nroots; r += T) {
       const int rc = root_cam[r];
       unsigned long long total = 1;
@@ -232,7 +257,7 @@ __global__ __launch_bounds__(T) void frame_kernel(FrameArgs p) {
           }
         }
       }
-      if (over) atomicOr(&misc[1], MOCAP_ST_CAND_OVERFLOW_);
+      if (over) atomicOr(&misc[MI_STATUS], MOCAP_ST_CAND_OVERFLOW_);
       gcnt[r] = (views > 1 && !over) ? (uint32_t)total : 0u;  // helpers.py:413-414 drops 1-view roots
     }
     __syncthreads();
@@ -244,155 +269,291 @@ __global__ __launch_bounds__(T) void frame_kernel(FrameArgs p) {
         outslot[r] = gcnt[r] ? slot : -1;
         slot += gcnt[r] ? 1 : 0;
         const uint32_t nxt = acc + gcnt[r];
-        if (nxt < acc) misc[1] |= MOCAP_ST_CAND_OVERFLOW_;
+        if (nxt < acc) misc[MI_STATUS] |= MOCAP_ST_CAND_OVERFLOW_;
         acc = nxt;
       }
       goff[nroots] = acc;
-      misc[2] = slot;
-      misc[3] = (int32_t)acc;
-    }
-    __syncthreads();
-    const int status = misc[1];
-    const uint32_t G = status ? 0u : (uint32_t)misc[3];
-
-    // ---------------------------------------------------------------- D: evaluate candidates
-    if (G) {
-      const uint32_t q = (G + T - 1) / T;
-      uint32_t g = (uint32_t)tid * q;
-      const uint32_t g_end = (g + q < G) ? g + q : G;
-      if (g < g_end) {
-        // first root whose range contains g
-        int lo = 0, hi = nroots - 1;
-        while (lo < hi) {
-          const int mid = (lo + hi + 1) >> 1;
-          if (goff[mid] <= g) lo = mid; else hi = mid - 1;
-        }
-        int r = lo;
-        while (goff[r + 1] <= g) r++;  // skip empty roots sharing the offset
-        double best_e = 0.0, best_X[3] = {0, 0, 0};
-        uint32_t best_g = 0;
-        bool have = false;
-        for (; g < g_end; g++) {
-          if (g >= goff[r + 1]) {
-            // leaving root r: flush the segment (lane, root)
-            const int s = tid + outslot[r];
-            seg_e[s] = best_e;
-            seg_g[s] = best_g;
-            seg_x[3 * s + 0] = best_X[0];
-            seg_x[3 * s + 1] = best_X[1];
-            seg_x[3 * s + 2] = best_X[2];
-            have = false;
-            do { r++; } while (goff[r + 1] <= g);
-          }
-          const uint32_t gl = g - goff[r];
-          const int rc = root_cam[r];
-          const uint16_t rb = root_blob[r];
-          const uint16_t* nhr = nh + (size_t)r * C;
-          const uint16_t* hr = hits + (size_t)r * C * M;
-          uint32_t rem = gl;
-          // pass 1 decodes the mixed-radix group index (camera rc+1 = fastest digit,
-          // helpers.py:394-400) and parks the blob index per camera for pass 2
-          auto obs1 = [&](int c, double& x, double& y) -> bool {
-            uint16_t s = kNone;
-            if (c == rc) {
-              s = rb;
-            } else if (c > rc) {
-              const uint32_t n = nhr[c];
-              if (n) {
-                const uint32_t qd = rem / n;
-                const uint32_t dgt = rem - qd * n;
-                rem = qd;
-                s = hr[(size_t)c * M + dgt];
-              }
-            }
-            sel[c] = s;
-            if (s == kNone) return false;
-            x = (double)bx[(size_t)c * M + s];
-            y = (double)by[(size_t)c * M + s];
-            return true;
-          };
-          auto obs2 = [&](int c, double& x, double& y) -> bool {
-            const uint16_t s = sel[c];
-            if (s == kNone) return false;
-            x = (double)bx[(size_t)c * M + s];
-            y = (double)by[(size_t)c * M + s];
-            return true;
-          };
-          double X[3], e;
-          triangulate_and_score<UNIFORM_K, true>(cv, obs1, obs2, X, e);
-          if (!have || e < best_e) {  // strict <: first minimum within the lane's ascending run
-            have = true;
-            best_e = e;
-            best_g = gl;
-            best_X[0] = X[0];
-            best_X[1] = X[1];
-            best_X[2] = X[2];
-          }
-        }
-        const int s = tid + outslot[r];
-        seg_e[s] = best_e;
-        seg_g[s] = best_g;
-        seg_x[3 * s + 0] = best_X[0];
-        seg_x[3 * s + 1] = best_X[1];
-        seg_x[3 * s + 2] = best_X[2];
-      }
-    }
-    __syncthreads();
-
-    // ---------------------------------------------------------------- E: select + write out
-    if (tid == 0) {
-      p.n_out[frame] = status ? 0 : misc[2];
-      p.status[frame] = status;
-      if (p.n_cand) p.n_cand[frame] = (int32_t)G;
-    }
-    if (G) {
-      const uint32_t q = (G + T - 1) / T;
-      for (int r = tid; r < nroots; r += T) {
-        const int k = outslot[r];
-        if (k < 0) continue;
-        const uint32_t t0 = goff[r] / q, t1 = (goff[r + 1] - 1) / q;
-        int sbest = (int)t0 + k;
-        double eb = seg_e[sbest];
-        for (uint32_t t = t0 + 1; t <= t1; t++) {
-          const int s = (int)t + k;
-          const double e = seg_e[s];
-          if (e < eb) {  // NaN never wins; earlier segment wins ties (np.argmin, helpers.py:418)
-            eb = e;
-            sbest = s;
-          }
-        }
-        const size_t o = (size_t)frame * R + k;
-        p.xyz[o * 3 + 0] = seg_x[3 * sbest + 0];
-        p.xyz[o * 3 + 1] = seg_x[3 * sbest + 1];
-        p.xyz[o * 3 + 2] = seg_x[3 * sbest + 2];
-        p.err[o] = eb;
-        // decode the winning group
-        uint32_t rem = seg_g[sbest];
-        const int rc = root_cam[r];
-        int16_t* co = p.corr + o * C;
-        for (int c = 0; c < C; c++) {
-          int16_t s = -1;
-          if (c == rc) {
-            s = (int16_t)root_blob[r];
-          } else if (c > rc) {
-            const uint32_t n = nh[(size_t)r * C + c];
-            if (n) {
-              const uint32_t qd = rem / n;
-              s = (int16_t)hits[((size_t)r * C + c) * M + (rem - qd * n)];
-              rem = qd;
-            }
-          }
-          co[c] = s;
-        }
-      }
+      misc[MI_NOUT] = slot;
+      misc[MI_G] = misc[MI_STATUS] ? 0 : (int32_t)acc;
     }
     __syncthreads();
   }
+
+  // ---------------------------------------------------------------- phase D
+  // Evaluate candidates [g_lo, g_hi); per (lane, root) segment winners land in seg_* .
+  __device__ void evaluate(uint32_t g_lo, uint32_t g_hi) {
+    const int nroots = misc[MI_NROOTS];
+    const uint32_t q = (g_hi - g_lo + T - 1) / T;
+    uint32_t g = g_lo + (uint32_t)tid * q;
+    const uint32_t g_end = (g + q < g_hi) ? g + q : g_hi;
+    if (g < g_end) {
+      int lo = 0, hi = nroots - 1;  // last root whose offset is <= g (empty roots share offsets)
+      while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (goff[mid] <= g) lo = mid; else hi = mid - 1;
+      }
+      int r = lo;
+      double best_e = 0.0, best_X[3] = {0, 0, 0};
+      uint32_t best_g = 0;
+      bool have = false;
+      for (; g < g_end; g++) {
+        if (g >= goff[r + 1]) {  // leaving root r: flush the (lane, root) segment
+          const int s = tid + outslot[r];
+          seg_e[s] = best_e;
+          seg_g[s] = best_g;
+          seg_x[3 * s + 0] = best_X[0];
+          seg_x[3 * s + 1] = best_X[1];
+          seg_x[3 * s + 2] = best_X[2];
+          have = false;
+          do { r++; } while (goff[r + 1] <= g);
+        }
+        const uint32_t gl = g - goff[r];
+        const int rc = root_cam[r];
+        const uint16_t rb = root_blob[r];
+        const uint16_t* nhr = nh + (size_t)r * C;
+        const uint16_t* hr = hits + (size_t)r * C * M;
+        uint32_t rem = gl;
+        // pass 1 decodes the mixed-radix group index (camera rc+1 = fastest digit,
+        // helpers.py:394-400) and parks the blob index per camera for pass 2
+        auto obs1 = [&](int c, double& x, double& y) -> bool {
+          uint16_t s = kNone;
+          if (c == rc) {
+            s = rb;
+          } else if (c > rc) {
+            const uint32_t n = nhr[c];
+            if (n) {
+              const uint32_t qd = rem / n;
+              const uint32_t dgt = rem - qd * n;
+              rem = qd;
+              s = hr[(size_t)c * M + dgt];
+            }
+          }
+          sel[c] = s;
+          if (s == kNone) return false;
+          x = (double)bx[(size_t)c * M + s];
+          y = (double)by[(size_t)c * M + s];
+          return true;
+        };
+        auto obs2 = [&](int c, double& x, double& y) -> bool {
+          const uint16_t s = sel[c];
+          if (s == kNone) return false;
+          x = (double)bx[(size_t)c * M + s];
+          y = (double)by[(size_t)c * M + s];
+          return true;
+        };
+        double X[3], e;
+        triangulate_and_score<UNIFORM_K, true>(cv, obs1, obs2, X, e);
+        if (!have || e < best_e) {  // strict <: first minimum within the lane's ascending run
+          have = true;
+          best_e = e;
+          best_g = gl;
+          best_X[0] = X[0];
+          best_X[1] = X[1];
+          best_X[2] = X[2];
+        }
+      }
+      const int s = tid + outslot[r];
+      seg_e[s] = best_e;
+      seg_g[s] = best_g;
+      seg_x[3 * s + 0] = best_X[0];
+      seg_x[3 * s + 1] = best_X[1];
+      seg_x[3 * s + 2] = best_X[2];
+    }
+    __syncthreads();
+  }
+
+  // first minimum over the (lane, root) segments of root r inside [g_lo, g_hi); false if the
+  // root has no candidate in the range
+  __device__ bool root_winner(int r, uint32_t g_lo, uint32_t g_hi, double& eb, uint32_t& gb, double (&Xb)[3]) {
+    const uint32_t a = goff[r] > g_lo ? goff[r] : g_lo;
+    const uint32_t b = goff[r + 1] < g_hi ? goff[r + 1] : g_hi;
+    if (a >= b) return false;
+    const uint32_t q = (g_hi - g_lo + T - 1) / T;
+    const int k = outslot[r];
+    const uint32_t t0 = (a - g_lo) / q, t1 = (b - 1 - g_lo) / q;
+    int sbest = (int)t0 + k;
+    eb = seg_e[sbest];
+    for (uint32_t t = t0 + 1; t <= t1; t++) {
+      const int s = (int)t + k;
+      const double e = seg_e[s];
+      if (e < eb) {  // earlier segment wins ties (np.argmin, helpers.py:418)
+        eb = e;
+        sbest = s;
+      }
+    }
+    gb = seg_g[sbest];
+    Xb[0] = seg_x[3 * sbest + 0];
+    Xb[1] = seg_x[3 * sbest + 1];
+    Xb[2] = seg_x[3 * sbest + 2];
+    return true;
+  }
+
+  // ---------------------------------------------------------------- phase E
+  __device__ void write_point(int64_t frame, int r, double e, uint32_t gl, const double (&X)[3]) {
+    const size_t o = (size_t)frame * R + outslot[r];
+    p.xyz[o * 3 + 0] = X[0];
+    p.xyz[o * 3 + 1] = X[1];
+    p.xyz[o * 3 + 2] = X[2];
+    p.err[o] = e;
+    uint32_t rem = gl;  // decode the winning group
+    const int rc = root_cam[r];
+    int16_t* co = p.corr + o * C;
+    for (int c = 0; c < C; c++) {
+      int16_t s = -1;
+      if (c == rc) {
+        s = (int16_t)root_blob[r];
+      } else if (c > rc) {
+        const uint32_t n = nh[(size_t)r * C + c];
+        if (n) {
+          const uint32_t qd = rem / n;
+          s = (int16_t)hits[((size_t)r * C + c) * M + (rem - qd * n)];
+          rem = qd;
+        }
+      }
+      co[c] = s;
+    }
+  }
+
+  __device__ void write_frame_header(int64_t frame) {
+    if (tid == 0) {
+      const int status = misc[MI_STATUS];
+      p.n_out[frame] = status ? 0 : misc[MI_NOUT];
+      p.status[frame] = status;
+      if (p.n_cand) p.n_cand[frame] = misc[MI_G];
+    }
+  }
+};
+
+template <int T, bool UNIFORM_K, int MODE>
+__global__ __launch_bounds__(T) void frame_kernel(FrameArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  FrameState<T, UNIFORM_K> st(p, smem);
+  const int tid = threadIdx.x;
+  const FrameQueues& q = p.q;
+  const int R = p.K_max;
+
+  while (true) {
+    // ------------------------------------------------------------ pull a work item
+    if (tid == 0) {
+      int item;
+      if (MODE == MODE_MAIN) {
+        item = atomicAdd(&q.counters[QC_NEXT_FRAME], 1);
+        if (item >= p.n_frames) item = -1;
+      } else if (MODE == MODE_SLICE) {
+        int n = q.counters[QC_N_SLICES];
+        if (n > q.W_cap) n = q.W_cap;
+        item = atomicAdd(&q.counters[QC_NEXT_SLICE], 1);
+        if (item >= n) item = -1;
+      } else {
+        int n = q.counters[QC_N_HEAVY];
+        if (n > q.H_cap) n = q.H_cap;
+        item = atomicAdd(&q.counters[QC_NEXT_MERGE], 1);
+        if (item >= n) item = -1;
+      }
+      st.misc[MI_ITEM] = item;
+    }
+    __syncthreads();
+    const int item = st.misc[MI_ITEM];
+    __syncthreads();  // every lane has read the slot before lane 0 can overwrite it
+    if (item < 0) break;
+
+    if (MODE == MODE_MAIN) {
+      const int64_t frame = item;
+      st.match(frame);
+      const uint32_t G = (uint32_t)st.misc[MI_G];
+      // heavy frame: hand its candidate space to the slice pass instead of evaluating here
+      if (tid == 0) {
+        int defer = 0;
+        if (q.heavy_threshold && G > q.heavy_threshold) {
+          uint32_t S = (G + q.slice_size - 1) / q.slice_size;
+          if (S > 64) S = 64;
+          const int h = atomicAdd(&q.counters[QC_N_HEAVY], 1);
+          if (h < q.H_cap) {
+            const int base = atomicAdd(&q.counters[QC_N_SLICES], (int)S);
+            if (base + (int)S <= q.W_cap) {
+              q.heavy[4 * h + 0] = (int32_t)frame;
+              q.heavy[4 * h + 1] = base;
+              q.heavy[4 * h + 2] = (int32_t)S;
+              for (uint32_t s = 0; s < S; s++) q.slice_heavy[base + s] = h;
+              defer = 1;
+            } else {
+              q.heavy[4 * h + 0] = -1;  // no room for its slices: evaluated in place below
+            }
+          }
+        }
+        st.misc[MI_DEFER] = defer;
+      }
+      __syncthreads();
+      if (st.misc[MI_DEFER]) continue;  // uniform
+      st.write_frame_header(frame);
+      if (G) {
+        st.evaluate(0, G);
+        const int nroots = st.misc[MI_NROOTS];
+        for (int r = tid; r < nroots; r += T) {
+          if (st.outslot[r] < 0) continue;
+          double e, X[3];
+          uint32_t gl;
+          if (st.root_winner(r, 0, G, e, gl, X)) st.write_point(frame, r, e, gl, X);
+        }
+      }
+      __syncthreads();
+    } else if (MODE == MODE_SLICE) {
+      const int h = q.slice_heavy[item];
+      if (h < 0 || q.heavy[4 * h + 0] < 0) continue;  // uniform (same value for all lanes)
+      const int64_t frame = q.heavy[4 * h + 0];
+      const int base = q.heavy[4 * h + 1], S = q.heavy[4 * h + 2];
+      const int sl = item - base;
+      st.match(frame);
+      const uint64_t G = (uint32_t)st.misc[MI_G];
+      const uint32_t g_lo = (uint32_t)(G * (uint64_t)sl / S), g_hi = (uint32_t)(G * (uint64_t)(sl + 1) / S);
+      if (g_hi > g_lo) st.evaluate(g_lo, g_hi);
+      const int nroots = st.misc[MI_NROOTS];
+      for (int r = tid; r < nroots; r += T) {
+        const int k = st.outslot[r];
+        if (k < 0) continue;
+        double e = __longlong_as_double(0x7ff0000000000000ll), X[3] = {0, 0, 0};  // +inf: no candidate here
+        uint32_t gl = 0;
+        if (g_hi > g_lo) st.root_winner(r, g_lo, g_hi, e, gl, X);
+        const size_t o = (size_t)item * R + k;
+        q.part_e[o] = e;
+        q.part_g[o] = gl;
+        q.part_x[3 * o + 0] = X[0];
+        q.part_x[3 * o + 1] = X[1];
+        q.part_x[3 * o + 2] = X[2];
+      }
+      __syncthreads();
+    } else {  // MODE_MERGE
+      const int h = item;
+      if (q.heavy[4 * h + 0] < 0) continue;
+      const int64_t frame = q.heavy[4 * h + 0];
+      const int base = q.heavy[4 * h + 1], S = q.heavy[4 * h + 2];
+      st.match(frame);
+      st.write_frame_header(frame);
+      const int nroots = st.misc[MI_NROOTS];
+      for (int r = tid; r < nroots; r += T) {
+        const int k = st.outslot[r];
+        if (k < 0) continue;
+        size_t ob = (size_t)base * R + k;
+        double eb = q.part_e[ob];
+        for (int s = 1; s < S; s++) {
+          const size_t o = (size_t)(base + s) * R + k;
+          const double e = q.part_e[o];
+          if (e < eb) {  // strict <: the earliest slice wins ties, slices ascend in candidate index
+            eb = e;
+            ob = o;
+          }
+        }
+        const double X[3] = {q.part_x[3 * ob + 0], q.part_x[3 * ob + 1], q.part_x[3 * ob + 2]};
+        st.write_point(frame, r, eb, q.part_g[ob], X);
+      }
+      __syncthreads();
+    }
+  }
 }
 
-template <int T>
-static hipError_t launch_T(const FrameArgs& a, int grid, size_t lds, hipStream_t stream) {
-  auto k = a.cv.uniformK ? frame_kernel<T, true> : frame_kernel<T, false>;
+template <int T, int MODE>
+static hipError_t launch_TM(const FrameArgs& a, int grid, size_t lds, hipStream_t stream) {
+  auto k = a.cv.uniformK ? frame_kernel<T, true, MODE> : frame_kernel<T, false, MODE>;
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
@@ -401,12 +562,21 @@ static hipError_t launch_T(const FrameArgs& a, int grid, size_t lds, hipStream_t
   return hipGetLastError();
 }
 
-hipError_t launch_frame_kernel(const FrameArgs& a, int threads, int grid, hipStream_t stream) {
+template <int T>
+static hipError_t launch_T(const FrameArgs& a, int mode, int grid, size_t lds, hipStream_t stream) {
+  switch (mode) {
+    case MODE_MAIN: return launch_TM<T, MODE_MAIN>(a, grid, lds, stream);
+    case MODE_SLICE: return launch_TM<T, MODE_SLICE>(a, grid, lds, stream);
+    default: return launch_TM<T, MODE_MERGE>(a, grid, lds, stream);
+  }
+}
+
+hipError_t launch_frame_kernel(const FrameArgs& a, int mode, int threads, int grid, hipStream_t stream) {
   const size_t lds = frame_lds_bytes(a.cv.C, a.M, a.K_max, threads);
   switch (threads) {
-    case 64: return launch_T<64>(a, grid, lds, stream);
-    case 128: return launch_T<128>(a, grid, lds, stream);
-    case 256: return launch_T<256>(a, grid, lds, stream);
+    case 64: return launch_T<64>(a, mode, grid, lds, stream);
+    case 128: return launch_T<128>(a, mode, grid, lds, stream);
+    case 256: return launch_T<256>(a, mode, grid, lds, stream);
     default: return hipErrorInvalidValue;
   }
 }

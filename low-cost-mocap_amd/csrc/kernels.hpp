@@ -11,8 +11,24 @@ namespace mocap {
 constexpr int MOCAP_ST_ROOT_OVERFLOW_ = 1;
 constexpr int MOCAP_ST_CAND_OVERFLOW_ = 2;
 
+// device-side work queues of the frame path (see the scheduling note in frame_kernel.hip)
+constexpr int MODE_MAIN = 0, MODE_SLICE = 1, MODE_MERGE = 2;
+enum { QC_NEXT_FRAME = 0, QC_N_HEAVY = 1, QC_N_SLICES = 2, QC_NEXT_SLICE = 3, QC_NEXT_MERGE = 4, QC_COUNT = 8 };
+struct FrameQueues {
+  int32_t* counters;     // [QC_COUNT], zeroed before every batch
+  int32_t* heavy;        // [H_cap][4]: frame (or -1), first slice id, slice count, -
+  int32_t* slice_heavy;  // [W_cap]: heavy-list index of each slice id (-1 = unused)
+  double* part_e;        // [W_cap][K_max]     per-slice, per-root partial winners
+  uint32_t* part_g;      // [W_cap][K_max]
+  double* part_x;        // [W_cap][K_max][3]
+  int H_cap, W_cap;
+  uint32_t heavy_threshold;  // candidate count above which a frame is deferred (0 = never)
+  uint32_t slice_size;       // target candidates per slice
+};
+
 struct FrameArgs {
   CamView cv;
+  FrameQueues q;
   int64_t n_frames;
   int M;      // blob slots per camera
   int K_max;  // root / output capacity per frame
@@ -29,7 +45,7 @@ struct FrameArgs {
 };
 
 size_t frame_lds_bytes(int C, int M, int R, int T);
-hipError_t launch_frame_kernel(const FrameArgs& a, int threads, int grid, hipStream_t stream);
+hipError_t launch_frame_kernel(const FrameArgs& a, int mode, int threads, int grid, hipStream_t stream);
 
 // explicit-correspondence triangulation, optionally batched over P camera sets (bundle adjustment)
 struct TriArgs {

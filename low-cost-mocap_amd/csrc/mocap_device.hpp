@@ -23,6 +23,12 @@ namespace mocap {
 constexpr int kMaxCameras = 64;
 constexpr int kMaxBlobs = 256;
 
+// Camera tables are frame-invariant and never written by the kernels that read them, so they are
+// addressed through the CONSTANT address space: wave-uniform reads then compile to scalar-cache
+// loads (s_load_dwordx4/x8 into SGPRs) instead of 64-lane vector loads of one address.
+typedef const double __attribute__((address_space(4))) * ctab_t;
+__host__ __device__ inline ctab_t as_ctab(const double* p) { return (ctab_t)(uintptr_t)p; }
+
 // Device view of the camera tables built by mocap_set_cameras (csrc/capi.hip).
 struct CamView {
   int C;
@@ -48,12 +54,18 @@ __device__ __forceinline__ void jacobi_rot(double (&a)[10], double (&v)[16]) {
   const double apq = a[sidx(P, Q)];
   if (apq != 0.0) {
     const double app = a[sidx(P, P)], aqq = a[sidx(Q, Q)];
-    const double h = aqq - app;
-    // t = sgn(theta) / (|theta| + sqrt(theta^2 + 1)), theta = h / (2 apq), with one sqrt + one divide
-    const double den = fabs(h) + sqrt(fma(h, h, 4.0 * apq * apq));
-    const double t = (h < 0.0 ? -2.0 : 2.0) * apq / den;
-    const double c = rsqrt(fma(t, t, 1.0));
-    const double s = t * c;
+    // Rotation angle from the double-angle identities, division- and sqrt-free (two v_rsq_f64):
+    //   h = aqq - app, w = 2 apq, r = hypot(h, w):  cos 2θ = |h| / r,  sin 2θ = sgn(h) w / r
+    //   cos²θ = (1 + cos 2θ) / 2 = u,  c = sqrt(u) = u * rsqrt(u),  s = sin 2θ / (2c),  t = s / c
+    const double h = aqq - app, w = apq + apq;
+    const double ir = rsqrt(fma(h, h, w * w));
+    const double c2 = fabs(h) * ir;
+    const double s2 = (h < 0.0 ? -w : w) * ir;
+    const double u = fma(0.5, c2, 0.5);
+    const double ic = rsqrt(u);
+    const double c = u * ic;
+    const double s = 0.5 * s2 * ic;
+    const double t = s * ic;
     a[sidx(P, P)] = fma(-t, apq, app);
     a[sidx(Q, Q)] = fma(t, apq, aqq);
     a[sidx(P, Q)] = 0.0;
@@ -103,7 +115,7 @@ __device__ __forceinline__ void smallest_eigvec4(double (&a)[10], double (&out)[
 }
 
 // DLT accumulation of one view: rows y*P2 - P1 and P0 - x*P2 (helpers.py:315-316) into B.
-__device__ __forceinline__ void dlt_accumulate(double (&B)[10], const double* __restrict__ P, double x,
+__device__ __forceinline__ void dlt_accumulate(double (&B)[10], ctab_t P, double x,
                                                double y) {
   double ra[4], rb[4];
 #pragma unroll
@@ -119,7 +131,7 @@ __device__ __forceinline__ void dlt_accumulate(double (&B)[10], const double* __
 
 // cv.projectPoints restated (helpers.py:231-237; OpenCV cvProjectPoints2, 3x3 R, no distortion):
 // squared pixel residuals of one view.  X already rounded to float32 when f32_rounding.
-__device__ __forceinline__ void reproject_sq(const double* __restrict__ RT, const double* __restrict__ K4,
+__device__ __forceinline__ void reproject_sq(ctab_t RT, ctab_t K4,
                                              const double (&X)[3], double ox, double oy, bool f32r,
                                              double& du2, double& dv2) {
   double x = RT[0] * X[0] + RT[1] * X[1] + RT[2] * X[2] + RT[9];
@@ -154,7 +166,7 @@ __device__ __forceinline__ int triangulate_and_score(const CamView& cv, Obs1&& o
   for (int c = 0; c < C; c++) {
     double x, y;
     if (obs1(c, x, y)) {
-      const double* P = UNIFORM_K ? cv.Pq + 12 * c : cv.Pq + 12 * ((size_t)v * C + c);
+      ctab_t P = as_ctab(UNIFORM_K ? cv.Pq + 12 * c : cv.Pq + 12 * ((size_t)v * C + c));
       dlt_accumulate(B, P, x, y);
       v++;
     }
@@ -186,7 +198,7 @@ __device__ __forceinline__ int triangulate_and_score(const CamView& cv, Obs1&& o
         double x, y;
         if (obs2(c, x, y)) {
           double du2, dv2;
-          reproject_sq(cv.RT + 12 * c, cv.K4 + 4 * (UNIFORM_K ? 0 : j), Xp, x, y, f32r, du2, dv2);
+          reproject_sq(as_ctab(cv.RT + 12 * c), as_ctab(cv.K4 + 4 * (UNIFORM_K ? 0 : j)), Xp, x, y, f32r, du2, dv2);
           seq = seq + du2;
           seq = seq + dv2;
           if (full_chunk) {
