@@ -122,6 +122,17 @@ extern "C" int mocap_set_options(mocap_ctx* ctx, uint32_t flags) {
   return MOCAP_OK;
 }
 
+extern "C" int mocap_set_tuning(mocap_ctx* ctx, int frame_threads, int heavy_threshold, int slice_size) {
+  if (!ctx) return MOCAP_E_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (frame_threads != 0 && frame_threads != 64 && frame_threads != 128 && frame_threads != 256)
+    return ctx->fail(MOCAP_E_ARG, "mocap_set_tuning: frame_threads must be 0, 64, 128 or 256");
+  if (frame_threads) ctx->frame_threads = frame_threads;
+  ctx->heavy_threshold = heavy_threshold < 0 ? -1 : heavy_threshold;
+  ctx->slice_size = slice_size < 0 ? 0 : slice_size;
+  return MOCAP_OK;
+}
+
 extern "C" void mocap_limits(int* max_cameras, int* max_blobs) {
   if (max_cameras) *max_cameras = kMaxCameras;
   if (max_blobs) *max_blobs = kMaxBlobs;

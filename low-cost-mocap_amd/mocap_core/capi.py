@@ -29,6 +29,7 @@ SIGNATURES = {
     "mocap_set_stream": (_i32, [_vp, _vp]),
     "mocap_synchronize": (_i32, [_vp]),
     "mocap_set_options": (_i32, [_vp, _u32]),
+    "mocap_set_tuning": (_i32, [_vp, _i32, _i32, _i32]),
     "mocap_limits": (None, [ctypes.POINTER(_i32), ctypes.POINTER(_i32)]),
     "mocap_set_cameras": (_i32, [_vp, _i32, _vp, _vp, _vp]),
     "mocap_get_fundamental": (_i32, [_vp, _vp]),
@@ -112,6 +113,9 @@ class MocapCore:
 
     def set_options(self, f32_rounding=True):
         self._check(self.lib.mocap_set_options(self._h, OPT_F32_ROUNDING if f32_rounding else 0))
+
+    def set_tuning(self, frame_threads=0, heavy_threshold=-1, slice_size=0):
+        self._check(self.lib.mocap_set_tuning(self._h, int(frame_threads), int(heavy_threshold), int(slice_size)))
 
     def set_stream(self, hip_stream_handle):
         self._check(self.lib.mocap_set_stream(self._h, ctypes.c_void_p(hip_stream_handle or 0)))

@@ -6,7 +6,7 @@ from scipy import optimize
 from mocap_core import capi, helpers, synth
 from oracle import c_oracle
 core = capi.MocapCore(0)
-C, N = 4, 200
+C, N = 8, 1000
 rig = synth.ring_rig(C)
 rng = np.random.default_rng(65 + C)
 obs, _ = synth.make_ba_observations(rig, N, seed=65 + C, noise_px=0.0)

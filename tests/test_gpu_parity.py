@@ -208,6 +208,29 @@ def test_properties_full_bench_size(core):
     np.testing.assert_allclose(res["xyz"][:n][v], ref["xyz"][v], rtol=XYZ_RTOL_TIGHT, atol=1e-12)
 
 
+def test_scheduling_knobs_do_not_change_results(core):
+    """Workgroup size, heavy-frame slicing on/off and slice size only change who computes what:
+    every output bit must be identical (this is also what makes N-GPU == 1-GPU hold)."""
+    from mocap_core import synth
+    rig = synth.ring_rig(8)
+    blobs, counts, _ = synth.make_blob_stream(rig, 3000, 16, seed=81)
+    core.set_cameras(rig["K"], rig["R"], rig["t"])
+    try:
+        core.set_tuning(256, 0, 0)                       # no slicing: one workgroup per frame
+        base = core.match_triangulate(blobs, counts, K_max=48)
+        assert base["n_cand"].max() > 20000               # the batch does contain heavy frames
+        valid = np.arange(48)[None, :] < base["n_out"][:, None]
+        for threads, thr, sl in [(256, 2048, 512), (128, 4096, 1024), (64, 1024, 256), (256, 300, 300), (256, -1, 0)]:
+            core.set_tuning(threads, thr, sl)
+            res = core.match_triangulate(blobs, counts, K_max=48)
+            for key in ("n_out", "status", "n_cand"):
+                assert np.array_equal(res[key], base[key]), (threads, thr, sl, key)
+            for key in ("xyz", "err", "corr"):
+                assert np.array_equal(res[key][valid], base[key][valid]), (threads, thr, sl, key)
+    finally:
+        core.set_tuning(256, -1, 0)
+
+
 def test_triangulate_vs_c_oracle_large(core):
     from mocap_core import synth
     from oracle import c_oracle
