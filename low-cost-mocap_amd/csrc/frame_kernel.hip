@@ -37,6 +37,22 @@ namespace mocap {
 
 constexpr uint16_t kNone = 0xFFFF;
 
+// Exact quotient/remainder for rem < 2^24, 1 <= n <= 2^16: float(rem) is exact and the float
+// quotient (1-ulp v_rcp_f32, one rounded multiply, truncation) is within [-2, +1] of the true one
+// (|error| <= 3/n, exact for n = 1, 2), so two correction steps per direction make it exact at about
+// half the instructions of a 32-bit integer division.  Candidate indices per root are < 2^24 (G_cap).
+__device__ __forceinline__ void divmod_small(uint32_t rem, uint32_t n, uint32_t& q, uint32_t& r) {
+  const float inv = __builtin_amdgcn_rcpf((float)n);
+  q = (uint32_t)((float)rem * inv);
+  int32_t rr = (int32_t)(rem - q * n);
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    if (rr < 0) { rr += (int32_t)n; q--; }
+    if (rr >= (int32_t)n) { rr -= (int32_t)n; q++; }
+  }
+  r = (uint32_t)rr;
+}
+
 struct FrameLds {
   // byte offsets into dynamic LDS, computed identically on host (size) and device (carve)
   size_t line, dist, seg_e, seg_x, seg_g, goff, gcnt, outslot, bx, by, hits, sel, nh, root_blob,
@@ -322,8 +338,8 @@ struct FrameState {
           } else if (c > rc) {
             const uint32_t n = nhr[c];
             if (n) {
-              const uint32_t qd = rem / n;
-              const uint32_t dgt = rem - qd * n;
+              uint32_t qd, dgt;
+              divmod_small(rem, n, qd, dgt);
               rem = qd;
               s = hr[(size_t)c * M + dgt];
             }
@@ -405,8 +421,9 @@ struct FrameState {
       } else if (c > rc) {
         const uint32_t n = nh[(size_t)r * C + c];
         if (n) {
-          const uint32_t qd = rem / n;
-          s = (int16_t)hits[((size_t)r * C + c) * M + (rem - qd * n)];
+          uint32_t qd, dgt;
+          divmod_small(rem, n, qd, dgt);
+          s = (int16_t)hits[((size_t)r * C + c) * M + dgt];
           rem = qd;
         }
       }
