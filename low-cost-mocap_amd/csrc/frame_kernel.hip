@@ -15,8 +15,10 @@
 //        B5 ballot-compaction of the unclaimed blobs into new roots (helpers.py:402-406)
 //   C  per-root candidate counts (Cartesian product sizes, helpers.py:394-400), offsets
 //   D  a range [g_lo, g_hi) of the flat candidate space is split into T contiguous runs; each lane
-//      triangulates and scores its run (csrc/mocap_device.hpp) keeping an (error, index)
-//      first-minimum per (lane, root) segment -- at most T + R segments, stored in LDS, no atomics
+//      walks its run with a mixed-radix odometer (only the digits that change are re-read), keeps
+//      the group's observations in its own LDS column, triangulates and scores every group
+//      (csrc/mocap_device.hpp) and keeps an (error, index) first-minimum per (lane, root) segment
+//      -- at most T + R segments, stored in LDS, no atomics
 //   E  one lane per kept root scans its segments (np.argmin first-minimum, helpers.py:418), decodes
 //      the winning group's blob indices and writes xyz / err / corr
 //
@@ -37,6 +39,12 @@ namespace mocap {
 
 constexpr uint16_t kNone = 0xFFFF;
 
+// register budget: 4 waves per SIMD (<= 128 VGPRs); the LDS footprint at 8 x 16 allows 4 workgroups
+// of 256 lanes per CU, so both limits meet at 16 waves per CU
+#ifndef MOCAP_FRAME_WAVES_PER_EU
+#define MOCAP_FRAME_WAVES_PER_EU 4
+#endif
+
 // Exact quotient/remainder for rem < 2^24, 1 <= n <= 2^16: float(rem) is exact and the float
 // quotient (1-ulp v_rcp_f32, one rounded multiply, truncation) is within [-2, +1] of the true one
 // (|error| <= 3/n, exact for n = 1, 2), so two correction steps per direction make it exact at about
@@ -53,34 +61,48 @@ __device__ __forceinline__ void divmod_small(uint32_t rem, uint32_t n, uint32_t&
   r = (uint32_t)rr;
 }
 
+// per-root epipolar line record in LDS: a, b, c, sqrt(a^2+b^2), its reciprocal, pad
+constexpr int kLineStride = 6;
+
+// LDS accesses of one wave execute in order; this only stops the compiler from moving them across
+// the point where lanes of the same wave exchange data through LDS (no s_barrier needed)
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 struct FrameLds {
   // byte offsets into dynamic LDS, computed identically on host (size) and device (carve)
-  size_t line, dist, seg_e, seg_x, seg_g, goff, gcnt, outslot, bx, by, hits, sel, nh, root_blob,
-      root_cam, claimed, cnt, misc, total;
+  size_t line, dist, seg_e, seg_x, seg_g, goff, gcnt, outslot, bxy, cxy, hits, dig, nh, root_blob,
+      root_cam, claimed, act, nact, cnt, misc, total;
   __host__ __device__ static size_t align(size_t x, size_t a) { return (x + a - 1) / a * a; }
   __host__ __device__ FrameLds(int C, int M, int R, int T) {
     size_t o = 0;
-    line = o;      o += sizeof(double) * 4 * R;
+    line = o;      o += sizeof(double) * kLineStride * R;
     seg_e = o;     o += sizeof(double) * (T + R);
     seg_x = o;     o += sizeof(double) * 3 * (T + R);
     // dist (phase B scratch) and the segment arrays (phase D/E) are never live together
-    dist = line + sizeof(double) * 4 * R;
-    const size_t dist_end = dist + sizeof(double) * (size_t)R * M;
+    dist = line + sizeof(double) * kLineStride * R;
+    const size_t dist_n = (size_t)R * M > (size_t)T ? (size_t)R * M : (size_t)T;
+    const size_t dist_end = dist + sizeof(double) * dist_n;
     if (dist_end > o) o = dist_end;
     seg_g = o;     o += sizeof(uint32_t) * (T + R);
     goff = o;      o += sizeof(uint32_t) * (R + 1);
     gcnt = o;      o += sizeof(uint32_t) * R;
     outslot = o;   o += sizeof(int32_t) * R;
-    bx = o;        o += sizeof(float) * (size_t)C * M;
-    by = o;        o += sizeof(float) * (size_t)C * M;
+    bxy = o;       o += sizeof(float2) * (size_t)C * M;
+    cxy = o;       o += sizeof(float2) * (size_t)C * T;
     cnt = o;       o += sizeof(int32_t) * C;
     misc = o;      o += sizeof(int32_t) * 8;
-    hits = o;      o += sizeof(uint16_t) * (size_t)R * C * M;
-    sel = o;       o += sizeof(uint16_t) * (size_t)T * C;
+    hits = o;      o += (size_t)R * C * M;
+    dig = o;       o += (size_t)C * T;
     nh = o;        o += sizeof(uint16_t) * (size_t)R * C;
     root_blob = o; o += sizeof(uint16_t) * R;
     root_cam = o;  o += R;
     claimed = o;   o += M;
+    act = o;       o += (size_t)R * C;
+    nact = o;      o += R;
     total = align(o, 16);
   }
 };
@@ -90,7 +112,7 @@ size_t frame_lds_bytes(int C, int M, int R, int T) { return FrameLds(C, M, R, T)
 // misc[] slots
 enum { MI_NROOTS = 0, MI_STATUS = 1, MI_NOUT = 2, MI_G = 3, MI_ITEM = 4, MI_DEFER = 5 };
 
-template <int T, bool UNIFORM_K>
+template <int T, bool UNIFORM_K, bool F32R>
 struct FrameState {
   const FrameArgs& p;
   const CamView& cv;
@@ -98,9 +120,12 @@ struct FrameState {
   double *line, *dist, *seg_e, *seg_x;
   uint32_t *seg_g, *goff, *gcnt;
   int32_t *outslot, *cnt, *misc;
-  float *bx, *by;
-  uint16_t *hits, *sel, *nh, *root_blob;
-  uint8_t *root_cam, *claimed;
+  float2 *bxy;  // [C][M]  the frame's blobs
+  float2 *cxy;  // [C][T]  this lane's current group: observation per camera (NaN = none)
+  uint16_t *nh, *root_blob;
+  uint8_t *hits;  // [R][C][M] blob indices of the gated hits, ascending distance (M <= 256)
+  uint8_t *dig;   // [C][T]    this lane's odometer digits
+  uint8_t *root_cam, *claimed, *act, *nact;  // act [R][C]: cameras of root r with >= 2 hits
 
   __device__ FrameState(const FrameArgs& p_, unsigned char* smem)
       : p(p_), cv(p_.cv), C(p_.cv.C), M(p_.M), R(p_.K_max), tid(threadIdx.x) {
@@ -113,29 +138,26 @@ struct FrameState {
     goff = (uint32_t*)(smem + L.goff);
     gcnt = (uint32_t*)(smem + L.gcnt);
     outslot = (int32_t*)(smem + L.outslot);
-    bx = (float*)(smem + L.bx);
-    by = (float*)(smem + L.by);
+    bxy = (float2*)(smem + L.bxy);
+    cxy = (float2*)(smem + L.cxy) + tid;
     cnt = (int32_t*)(smem + L.cnt);
     misc = (int32_t*)(smem + L.misc);
-    hits = (uint16_t*)(smem + L.hits);
-    sel = (uint16_t*)(smem + L.sel) + (size_t)tid * C;
+    hits = (uint8_t*)(smem + L.hits);
+    dig = (uint8_t*)(smem + L.dig) + tid;
     nh = (uint16_t*)(smem + L.nh);
     root_blob = (uint16_t*)(smem + L.root_blob);
     root_cam = (uint8_t*)(smem + L.root_cam);
     claimed = (uint8_t*)(smem + L.claimed);
+    act = (uint8_t*)(smem + L.act);
+    nact = (uint8_t*)(smem + L.nact);
   }
 
   // ---------------------------------------------------------------- phases A-C
   // Leaves roots / hit lists / candidate offsets in LDS; returns with all lanes synchronised.
   __device__ void match(int64_t frame) {
-    const bool f32r = cv.f32_rounding != 0;
     {
       const float2* src = (const float2*)(p.blobs + (size_t)frame * C * M * 2);
-      for (int i = tid; i < C * M; i += T) {
-        const float2 b = src[i];
-        bx[i] = b.x;
-        by[i] = b.y;
-      }
+      for (int i = tid; i < C * M; i += T) bxy[i] = src[i];
       if (tid < C) {
         int n = p.counts[(size_t)frame * C + tid];
         cnt[tid] = n < 0 ? 0 : (n > M ? M : n);
@@ -156,74 +178,132 @@ struct FrameState {
     }
     __syncthreads();
 
+    // group geometry of the fused B2-B4 step: the blobs of one root occupy GS = 2^gs_shift >= M
+    // consecutive lanes; when that fits a wave (M <= 64) gate, order and claim need no LDS round
+    // trips through the whole workgroup, only wave-level ballots
+    int gs_shift = 0;
+    while ((1 << gs_shift) < M) gs_shift++;
+    const bool fused = gs_shift <= 6;
+
     for (int i = 1; i < C; i++) {
-      const int nroots = misc[MI_NROOTS];
       const int Mi = cnt[i];
-      const float* pxs = bx + (size_t)i * M;
-      const float* pys = by + (size_t)i * M;
-      // B1: epipolar line of every root in camera i.  cv.computeCorrespondEpilines on a float32
+      const float2* pts = bxy + (size_t)i * M;
+      // B1 (wave 0, which also owns B5: no workgroup barrier between B5 of camera i-1 and this):
+      // epipolar line of every root in camera i.  cv.computeCorrespondEpilines on a float32
       // point: double math, scale by 1/sqrt(a^2+b^2), float32 result (helpers.py:363-364).
-      for (int r = tid; r < nroots; r += T) {
-        const int rc = root_cam[r], rb = root_blob[r];
-        ctab_t Fm = as_ctab(cv.F + 9 * ((size_t)rc * C + i));
-        const double x = (double)bx[(size_t)rc * M + rb], y = (double)by[(size_t)rc * M + rb];
-        double a = Fm[0] * x + Fm[1] * y + Fm[2];
-        double b = Fm[3] * x + Fm[4] * y + Fm[5];
-        double c = Fm[6] * x + Fm[7] * y + Fm[8];
-        double nu = a * a + b * b;
-        nu = nu != 0.0 ? 1.0 / sqrt(nu) : 1.0;
-        a *= nu;
-        b *= nu;
-        c *= nu;
-        if (f32r) {
-          a = (double)(float)a;
-          b = (double)(float)b;
-          c = (double)(float)c;
-        }
-        line[4 * r + 0] = a;
-        line[4 * r + 1] = b;
-        line[4 * r + 2] = c;
-        line[4 * r + 3] = sqrt(a * a + b * b);  // helpers.py:373 divides by it again
-        nh[(size_t)r * C + i] = 0;
-      }
-      for (int k = tid; k < M; k += T) claimed[k] = 0;
-      __syncthreads();
-      // B2: |a x + b y + c| / sqrt(a^2 + b^2) for every (root, blob) pair (helpers.py:373)
-      const int npairs = nroots * Mi;
-      for (int idx = tid; idx < npairs; idx += T) {
-        const int r = idx / Mi, k = idx - r * Mi;
-        const double a = line[4 * r + 0], b = line[4 * r + 1], c = line[4 * r + 2], den = line[4 * r + 3];
-        const double px = (double)pxs[k], py = (double)pys[k];
-        dist[(size_t)r * M + k] = fabs(a * px + b * py + c) / den;
-      }
-      __syncthreads();
-      // B3: gate (strict <, helpers.py:375,383) and order by (distance, index) via rank counting
-      for (int idx = tid; idx < npairs; idx += T) {
-        const int r = idx / Mi, k = idx - r * Mi;
-        const double* dr = dist + (size_t)r * M;
-        const double d = dr[k];
-        if (d < p.gate_px) {
-          int rank = 0;
-          for (int k2 = 0; k2 < Mi; k2++) {
-            const double d2 = dr[k2];
-            rank += (d2 < d || (d2 == d && k2 < k)) ? 1 : 0;
+      if (tid < 64) {
+        const int nr = misc[MI_NROOTS];
+        for (int r = tid; r < nr; r += 64) {
+          const int rc = root_cam[r], rb = root_blob[r];
+          ctab_t Fm = as_ctab(cv.F + 9 * ((size_t)rc * C + i));
+          const float2 rp = bxy[(size_t)rc * M + rb];
+          const double x = (double)rp.x, y = (double)rp.y;
+          double a = Fm[0] * x + Fm[1] * y + Fm[2];
+          double b = Fm[3] * x + Fm[4] * y + Fm[5];
+          double c = Fm[6] * x + Fm[7] * y + Fm[8];
+          double nu = a * a + b * b;
+          nu = nu != 0.0 ? 1.0 / sqrt(nu) : 1.0;
+          a *= nu;
+          b *= nu;
+          c *= nu;
+          if (F32R) {
+            a = (double)(float)a;
+            b = (double)(float)b;
+            c = (double)(float)c;
           }
-          hits[((size_t)r * C + i) * M + rank] = (uint16_t)k;
+          const double den = sqrt(a * a + b * b);  // helpers.py:373 divides by it again
+          line[kLineStride * r + 0] = a;
+          line[kLineStride * r + 1] = b;
+          line[kLineStride * r + 2] = c;
+          line[kLineStride * r + 3] = den;
+          line[kLineStride * r + 4] = recip_refined(den);  // shared by the M quotients of B2
+          nh[(size_t)r * C + i] = 0;
         }
-        if (k == 0) {
-          int n = 0;
-          for (int k2 = 0; k2 < Mi; k2++) n += dr[k2] < p.gate_px ? 1 : 0;
-          nh[(size_t)r * C + i] = (uint16_t)n;
-        }
+        for (int k = tid; k < M; k += 64) claimed[k] = 0;
       }
       __syncthreads();
-      // B4: the closest hit of every matched root is removed *by value* from the unmatched set
-      // (helpers.py:391): flag every blob with the same coordinates.
-      for (int idx = tid; idx < npairs; idx += T) {
-        const int r = idx / Mi, k = idx - r * Mi;
-        if (nh[(size_t)r * C + i] > 0) {
-          const int k0 = hits[((size_t)r * C + i) * M];
-          if (pxs[k] == pxs[k0] && pys[k] == pys[k0]) claimed[k] = 1;
+      const int nroots = misc[MI_NROOTS];
+      if (fused) {
+        // B2-B4, one lane per (root, blob): |a x + b y + c| / sqrt(a^2 + b^2) (helpers.py:373), gate
+        // (strict <, helpers.py:375,383), rank among the root's hits by (distance, index), and the
+        // closest hit's removal *by value* from the unmatched set (helpers.py:391)
+        const int GS = 1 << gs_shift;
+        const int k = tid & (GS - 1);
+        const int gl0 = (tid & 63) & ~(GS - 1);  // first lane of the group inside its wave
+        const unsigned long long gall = gs_shift == 6 ? ~0ull : ((1ull << GS) - 1ull);
+        const int roots_per_pass = T >> gs_shift;
+        for (int base = 0; base < nroots; base += roots_per_pass) {  // uniform trip count
+          const int r = base + (tid >> gs_shift);
+          const bool valid = r < nroots && k < Mi;
+          double d = 0.0;
+          bool hit = false;
+          if (valid) {
+            const double* ln = line + kLineStride * r;
+            const double px = (double)pts[k].x, py = (double)pts[k].y;
+            const double num = fabs(ln[0] * px + ln[1] * py + ln[2]);
+            d = div_by(num, ln[3], ln[4]);
+            hit = d < p.gate_px;
+          }
+          dist[tid] = d;
+          const unsigned long long gm = (__ballot(hit) >> gl0) & gall;
+          wave_lds_sync();
+          int rank = -1;
+          if (hit) {
+            rank = 0;
+            unsigned long long mm = gm & ~(1ull << k);
+            while (mm) {
+              const int j = __ffsll(mm) - 1;
+              mm &= mm - 1;
+              const double d2 = dist[tid - k + j];
+              rank += (d2 < d || (d2 == d && j < k)) ? 1 : 0;
+            }
+            hits[((size_t)r * C + i) * M + rank] = (uint8_t)k;
+          }
+          const unsigned long long g0 = (__ballot(rank == 0) >> gl0) & gall;
+          if (valid) {
+            if (k == 0) nh[(size_t)r * C + i] = (uint16_t)__popcll(gm);
+            if (g0) {
+              const int k0 = __ffsll(g0) - 1;
+              if (pts[k].x == pts[k0].x && pts[k].y == pts[k0].y) claimed[k] = 1;
+            }
+          }
+          wave_lds_sync();  // dist[] is reused by the next pass
+        }
+      } else {
+        // generic path (a root's blobs span several waves): same steps through LDS + barriers
+        const int npairs = nroots * Mi;
+        for (int idx = tid; idx < npairs; idx += T) {
+          const int r = idx / Mi, k = idx - r * Mi;
+          const double* ln = line + kLineStride * r;
+          const double px = (double)pts[k].x, py = (double)pts[k].y;
+          dist[(size_t)r * M + k] = fabs(ln[0] * px + ln[1] * py + ln[2]) / ln[3];
+        }
+        __syncthreads();
+        for (int idx = tid; idx < npairs; idx += T) {
+          const int r = idx / Mi, k = idx - r * Mi;
+          const double* dr = dist + (size_t)r * M;
+          const double d = dr[k];
+          if (d < p.gate_px) {
+            int rank = 0;
+            for (int k2 = 0; k2 < Mi; k2++) {
+              const double d2 = dr[k2];
+              rank += (d2 < d || (d2 == d && k2 < k)) ? 1 : 0;
+            }
+            hits[((size_t)r * C + i) * M + rank] = (uint8_t)k;
+          }
+          if (k == 0) {
+            int n = 0;
+            for (int k2 = 0; k2 < Mi; k2++) n += dr[k2] < p.gate_px ? 1 : 0;
+            nh[(size_t)r * C + i] = (uint16_t)n;
+          }
+        }
+        __syncthreads();
+        for (int idx = tid; idx < npairs; idx += T) {
+          const int r = idx / Mi, k = idx - r * Mi;
+          if (nh[(size_t)r * C + i] > 0) {
+            const int k0 = hits[((size_t)r * C + i) * M];
+            if (pts[k].x == pts[k0].x && pts[k].y == pts[k0].y) claimed[k] = 1;
+          }
         }
       }
       __syncthreads();
@@ -251,19 +331,21 @@ struct FrameState {
           }
           misc[MI_NROOTS] = base_root;
         }
+        wave_lds_sync();  // B1 of the next camera runs in this wave
       }
-      __syncthreads();
     }
+    __syncthreads();
 
     // C: candidate counts per root
     const int nroots = misc[MI_NROOTS];
     for (int r = tid; r < nroots; r += T) {
       const int rc = root_cam[r];
       unsigned long long total = 1;
-      int views = 1;
+      int views = 1, na = 0;
       bool over = false;
       for (int c = rc + 1; c < C; c++) {
         const unsigned n = nh[(size_t)r * C + c];
+        if (n > 1) act[(size_t)r * C + na++] = (uint8_t)c;  // the digits an odometer step can change
         if (n) {
           views++;
           total *= n;
@@ -274,6 +356,7 @@ struct FrameState {
         }
       }
       if (over) atomicOr(&misc[MI_STATUS], MOCAP_ST_CAND_OVERFLOW_);
+      nact[r] = (uint8_t)na;
       gcnt[r] = (views > 1 && !over) ? (uint32_t)total : 0u;  // helpers.py:413-414 drops 1-view roots
     }
     __syncthreads();
@@ -296,6 +379,57 @@ struct FrameState {
   }
 
   // ---------------------------------------------------------------- phase D
+  // Group index -> observations.  The reference materialises every group as a nested list
+  // (copy.deepcopy, helpers.py:394-400); here a group is the mixed-radix number gl whose digit for
+  // camera c (> root camera, >= 1 hit) picks the gl_c-th closest hit; camera rc+1 is the fastest
+  // digit (probed against the reference).  Each lane keeps the digits and the observations of ITS
+  // current group in its own LDS column (dig / cxy, [C][T]: conflict-free), so stepping to the next
+  // group rewrites only the digits that change instead of decoding all C of them.
+  template <bool FIRST>  // FIRST: gl == 0, every digit is 0 (root crossing inside a lane's run)
+  __device__ void load_group(int r, uint32_t gl) {
+    const int rc = root_cam[r];
+    const uint16_t rb = root_blob[r];
+    const uint16_t* nhr = nh + (size_t)r * C;
+    const uint8_t* hr = hits + (size_t)r * C * M;
+    const float qn = __int_as_float(0x7fc00000);
+    uint32_t rem = gl;
+    for (int c = 0; c < C; c++) {
+      uint16_t s = kNone;
+      uint32_t dgt = 0;
+      if (c == rc) {
+        s = rb;
+      } else if (c > rc) {
+        const uint32_t n = nhr[c];
+        if (n) {
+          if (!FIRST) {
+            uint32_t qd;
+            divmod_small(rem, n, qd, dgt);
+            rem = qd;
+          }
+          s = hr[(size_t)c * M + dgt];
+        }
+      }
+      dig[(size_t)c * T] = (uint8_t)dgt;
+      cxy[(size_t)c * T] = s == kNone ? make_float2(qn, qn) : bxy[(size_t)c * M + s];
+    }
+  }
+
+  __device__ void next_group(int r) {
+    const uint8_t* a = act + (size_t)r * C;
+    const int na = nact[r];
+    const uint16_t* nhr = nh + (size_t)r * C;
+    const uint8_t* hr = hits + (size_t)r * C * M;
+    for (int k = 0; k < na; k++) {
+      const int c = a[k];
+      uint32_t d = (uint32_t)dig[(size_t)c * T] + 1u;
+      const bool wrap = d >= nhr[c];
+      if (wrap) d = 0;
+      dig[(size_t)c * T] = (uint8_t)d;
+      cxy[(size_t)c * T] = bxy[(size_t)c * M + hr[(size_t)c * M + d]];
+      if (!wrap) break;
+    }
+  }
+
   // Evaluate candidates [g_lo, g_hi); per (lane, root) segment winners land in seg_* .
   __device__ void evaluate(uint32_t g_lo, uint32_t g_hi) {
     const int nroots = misc[MI_NROOTS];
@@ -309,11 +443,33 @@ struct FrameState {
         if (goff[mid] <= g) lo = mid; else hi = mid - 1;
       }
       int r = lo;
+      uint32_t r_beg = goff[r], r_end = goff[r + 1];
+      load_group<false>(r, g - r_beg);
       double best_e = 0.0, best_X[3] = {0, 0, 0};
       uint32_t best_g = 0;
       bool have = false;
-      for (; g < g_end; g++) {
-        if (g >= goff[r + 1]) {  // leaving root r: flush the (lane, root) segment
+      // a blob never has NaN coordinates inside a multi-view group (NaN fails the gate), so NaN
+      // marks "camera not in the group"
+      auto obs = [&](int c, double& x, double& y) -> bool {
+        const float2 v = cxy[(size_t)c * T];
+        if (v.x != v.x) return false;
+        x = (double)v.x;
+        y = (double)v.y;
+        return true;
+      };
+      while (true) {
+        double X[3], e;
+        triangulate_and_score<UNIFORM_K, true, F32R>(cv, obs, obs, X, e);
+        if (!have || e < best_e) {  // strict <: first minimum within the lane's ascending run
+          have = true;
+          best_e = e;
+          best_g = g - r_beg;
+          best_X[0] = X[0];
+          best_X[1] = X[1];
+          best_X[2] = X[2];
+        }
+        if (++g >= g_end) break;
+        if (g >= r_end) {  // leaving root r: flush the (lane, root) segment
           const int s = tid + outslot[r];
           seg_e[s] = best_e;
           seg_g[s] = best_g;
@@ -322,50 +478,11 @@ struct FrameState {
           seg_x[3 * s + 2] = best_X[2];
           have = false;
           do { r++; } while (goff[r + 1] <= g);
-        }
-        const uint32_t gl = g - goff[r];
-        const int rc = root_cam[r];
-        const uint16_t rb = root_blob[r];
-        const uint16_t* nhr = nh + (size_t)r * C;
-        const uint16_t* hr = hits + (size_t)r * C * M;
-        uint32_t rem = gl;
-        // pass 1 decodes the mixed-radix group index (camera rc+1 = fastest digit,
-        // helpers.py:394-400) and parks the blob index per camera for pass 2
-        auto obs1 = [&](int c, double& x, double& y) -> bool {
-          uint16_t s = kNone;
-          if (c == rc) {
-            s = rb;
-          } else if (c > rc) {
-            const uint32_t n = nhr[c];
-            if (n) {
-              uint32_t qd, dgt;
-              divmod_small(rem, n, qd, dgt);
-              rem = qd;
-              s = hr[(size_t)c * M + dgt];
-            }
-          }
-          sel[c] = s;
-          if (s == kNone) return false;
-          x = (double)bx[(size_t)c * M + s];
-          y = (double)by[(size_t)c * M + s];
-          return true;
-        };
-        auto obs2 = [&](int c, double& x, double& y) -> bool {
-          const uint16_t s = sel[c];
-          if (s == kNone) return false;
-          x = (double)bx[(size_t)c * M + s];
-          y = (double)by[(size_t)c * M + s];
-          return true;
-        };
-        double X[3], e;
-        triangulate_and_score<UNIFORM_K, true>(cv, obs1, obs2, X, e);
-        if (!have || e < best_e) {  // strict <: first minimum within the lane's ascending run
-          have = true;
-          best_e = e;
-          best_g = gl;
-          best_X[0] = X[0];
-          best_X[1] = X[1];
-          best_X[2] = X[2];
+          r_beg = goff[r];
+          r_end = goff[r + 1];
+          load_group<true>(r, 0);
+        } else {
+          next_group(r);
         }
       }
       const int s = tid + outslot[r];
@@ -441,10 +558,10 @@ struct FrameState {
   }
 };
 
-template <int T, bool UNIFORM_K, int MODE>
-__global__ __launch_bounds__(T) void frame_kernel(FrameArgs p) {
+template <int T, bool UNIFORM_K, bool F32R, int MODE>
+__global__ __launch_bounds__(T, MOCAP_FRAME_WAVES_PER_EU) void frame_kernel(FrameArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  FrameState<T, UNIFORM_K> st(p, smem);
+  FrameState<T, UNIFORM_K, F32R> st(p, smem);
   const int tid = threadIdx.x;
   const FrameQueues& q = p.q;
   const int R = p.K_max;
@@ -570,7 +687,11 @@ __global__ __launch_bounds__(T) void frame_kernel(FrameArgs p) {
 
 template <int T, int MODE>
 static hipError_t launch_TM(const FrameArgs& a, int grid, size_t lds, hipStream_t stream) {
-  auto k = a.cv.uniformK ? frame_kernel<T, true, MODE> : frame_kernel<T, false, MODE>;
+  void (*k)(FrameArgs);
+  if (a.cv.f32_rounding)
+    k = a.cv.uniformK ? frame_kernel<T, true, true, MODE> : frame_kernel<T, false, true, MODE>;
+  else
+    k = a.cv.uniformK ? frame_kernel<T, true, false, MODE> : frame_kernel<T, false, false, MODE>;
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;

@@ -49,6 +49,38 @@ __host__ __device__ constexpr int sidx(int i, int j) {
                 : (j == 0 ? i : j == 1 ? 3 + i : j == 2 ? 5 + i : 9);
 }
 
+// ---- FP64 building blocks written against the gfx950 instruction set.
+// v_rsq_f64 / v_rcp_f64 deliver ~2^-26 relative accuracy; HIP's rsqrt()/sqrt()/operator/ wrap them
+// in Newton steps PLUS range scaling and class fix-ups (9-20 instructions).  Where the operand range
+// is known those wrappers are dead weight:
+
+// 1/sqrt(d) for finite d > 0 away from the exponent limits (Cholesky pivots clamped from below):
+// raw estimate + one third-order step -> < 1 ulp.  6 instructions instead of 9.
+__device__ __forceinline__ double rsqrt_pos(double d) {
+  const double y = __builtin_amdgcn_rsq(d);
+  const double e = fma(-(d * y), y, 1.0);
+  return fma(y * e, fma(e, 0.375, 0.5), y);
+}
+
+// r ~ 1/b refined to working precision (two Newton steps from v_rcp_f64), b finite, normal, non-zero
+__device__ __forceinline__ double recip_refined(double b) {
+  double r = __builtin_amdgcn_rcp(b);
+  r = fma(fma(-b, r, 1.0), r, r);
+  r = fma(fma(-b, r, 1.0), r, r);
+  return r;
+}
+
+// a / b with the final residual correction of the IEEE sequence the compiler emits for operator/
+// (v_div_scale -> v_rcp -> 2 Newton -> q = a r -> q += (a - b q) r -> v_div_fmas -> v_div_fixup),
+// minus the exponent scaling and the special-case fix-up: identical bits whenever neither operand
+// nor the quotient comes near the exponent limits (|x| in 2^-500 .. 2^500, b != 0), i.e. for every
+// camera depth and homogeneous coordinate this path sees.  r = recip_refined(b) is shared by
+// quotients with the same denominator.
+__device__ __forceinline__ double div_by(double a, double b, double r) {
+  const double q = a * r;
+  return fma(fma(-b, q, a), r, q);
+}
+
 // One Jacobi rotation in the (P,Q) plane; indices are compile-time so a[] / v[] stay in VGPRs.
 template <int P, int Q>
 __device__ __forceinline__ void jacobi_rot(double (&a)[10], double (&v)[16]) {
@@ -115,40 +147,40 @@ __device__ __forceinline__ void smallest_eigvec4_jacobi(double (&a)[10], double 
     out[k] = m == 0 ? v[k * 4 + 0] : m == 1 ? v[k * 4 + 1] : m == 2 ? v[k * 4 + 2] : v[k * 4 + 3];
 }
 
-// Same vector, ~5x fewer instructions: shifted Cholesky + Laguerre + inverse iteration.
+// Same vector, ~6x fewer instructions: shifted Cholesky + Laguerre + inverse iteration.
 //   B is symmetric positive semi-definite, so p(x) = det(B - x I) has four real roots >= 0 and
 //   Laguerre's iteration started at x = 0 climbs monotonically to the smallest one without ever
 //   overshooting it (B - x I stays positive definite -> plain Cholesky is backward stable):
 //       L L^T = B - x I,  M = L^{-1},  (B - x I)^{-1} = M^T M
 //       s1 = tr (B - x I)^{-1} = |M|_F^2 = -p'/p,      s2 = tr (B - x I)^{-2} = |M^T M|_F^2
 //       x += 4 / (s1 + sqrt(3 (4 s2 - s1^2)))                          (cubic convergence)
-//   s2 / s1^2 -> 1 exactly when the smallest root dominates the resolvent; once 1 - s2/s1^2 < 1e-7
-//   the shift is within ~5e-8 of the gap and two steps of inverse iteration from e4 (the first one
-//   is free: it is the last row of M) leave a contamination below 1e-15.  Typical: 3 factorisations.
-//   Checked against LAPACK dgesdd on 15 k candidate matrices: max 1.1e-14 relative on X.
+//   With rho = (lam1 - x) / (lam2 - x) the contraction of one inverse-iteration step,
+//   1 - s2/s1^2 ~ 2 rho.  A factorisation costs ~160 instructions, an inverse-iteration step ~25,
+//   so the shift only has to be good enough for a handful of steps: stop once 1 - s2/s1^2 < 1e-3
+//   (rho < 5e-4) and run kInvIters = 5 steps from e4 (the first one is free: it is the last row
+//   of M): rho^5 < 4e-17.  On 71 k candidate matrices of the 8 x 16 bench stream that is exactly
+//   two factorisations for every lane of every wave (lam1/lam2 is ~1e-2 for the wrong groups that
+//   dominate the candidate set, so shift 0 alone is never enough, and one Laguerre step always
+//   is); max 2.3e-14 relative on X against LAPACK dgesdd.
+constexpr int kInvIters = 5;
 __device__ __forceinline__ void smallest_eigvec4_cholesky(const double (&a)[10], double (&out)[4]) {
   const double tr = (a[0] + a[4]) + (a[7] + a[9]);
+  // pivots are clamped from below (fmax also swallows NaN): a shift that rounding pushed past lam1
+  // yields one tiny pivot, i.e. a huge last row of M -- still the wanted vector -- and s2/s1^2 -> 1,
+  // which ends the loop through the ordinary convergence test
   const double floor_piv = tr * 1e-30 + 1e-300;
-  double lam = 0.0;
+  double lam = 0.0, piv3 = 1.0;
   double m[10];  // M = L^{-1}, lower triangular, packed like sidx with (row >= col) -> sidx(col,row)
   for (int it = 0; it < 8; it++) {
     // ---- Cholesky of B - lam I; r_i = 1 / l_ii
-    bool clamped = false;
-    double d = a[0] - lam;
-    if (!(d > floor_piv)) { d = floor_piv; clamped = true; }
-    const double r0 = rsqrt(d);
+    const double r0 = rsqrt_pos(fmax(a[0] - lam, floor_piv));
     const double l10 = a[1] * r0, l20 = a[2] * r0, l30 = a[3] * r0;
-    d = fma(-l10, l10, a[4] - lam);
-    if (!(d > floor_piv)) { d = floor_piv; clamped = true; }
-    const double r1 = rsqrt(d);
+    const double r1 = rsqrt_pos(fmax(fma(-l10, l10, a[4] - lam), floor_piv));
     const double l21 = fma(-l20, l10, a[5]) * r1, l31 = fma(-l30, l10, a[6]) * r1;
-    d = fma(-l21, l21, fma(-l20, l20, a[7] - lam));
-    if (!(d > floor_piv)) { d = floor_piv; clamped = true; }
-    const double r2 = rsqrt(d);
+    const double r2 = rsqrt_pos(fmax(fma(-l21, l21, fma(-l20, l20, a[7] - lam)), floor_piv));
     const double l32 = fma(-l31, l21, fma(-l30, l20, a[8])) * r2;
-    d = fma(-l32, l32, fma(-l31, l31, fma(-l30, l30, a[9] - lam)));
-    if (!(d > floor_piv)) { d = floor_piv; clamped = true; }
-    const double r3 = rsqrt(d);
+    piv3 = fmax(fma(-l32, l32, fma(-l31, l31, fma(-l30, l30, a[9] - lam))), floor_piv);
+    const double r3 = rsqrt_pos(piv3);
     // ---- M = L^{-1}
     const double m00 = r0, m11 = r1, m22 = r2, m33 = r3;
     const double m10 = -(l10 * m00) * m11;
@@ -160,36 +192,48 @@ __device__ __forceinline__ void smallest_eigvec4_cholesky(const double (&a)[10],
     m[0] = m00; m[1] = m10; m[2] = m20; m[3] = m30; m[4] = m11; m[5] = m21; m[6] = m31; m[7] = m22;
     m[8] = m32; m[9] = m33;
     // ---- s1 = |M|_F^2 ; W = M^T M ; s2 = |W|_F^2
-    const double s1 = fma(m00, m00, fma(m10, m10, fma(m20, m20, fma(m30, m30, fma(m11, m11,
-                      fma(m21, m21, fma(m31, m31, fma(m22, m22, fma(m32, m32, m33 * m33)))))))));
     const double w00 = fma(m00, m00, fma(m10, m10, fma(m20, m20, m30 * m30)));
+    const double w11 = fma(m11, m11, fma(m21, m21, m31 * m31));
+    const double w22 = fma(m22, m22, m32 * m32);
+    const double w33 = m33 * m33;
+    const double s1 = (w00 + w11) + (w22 + w33);
     const double w01 = fma(m10, m11, fma(m20, m21, m30 * m31));
     const double w02 = fma(m20, m22, m30 * m32);
     const double w03 = m30 * m33;
-    const double w11 = fma(m11, m11, fma(m21, m21, m31 * m31));
     const double w12 = fma(m21, m22, m31 * m32);
     const double w13 = m31 * m33;
-    const double w22 = fma(m22, m22, m32 * m32);
     const double w23 = m32 * m33;
-    const double w33 = m33 * m33;
     const double sd = fma(w00, w00, fma(w11, w11, fma(w22, w22, w33 * w33)));
     const double so = fma(w01, w01, fma(w02, w02, fma(w03, w03, fma(w12, w12, fma(w13, w13, w23 * w23)))));
     const double s2 = fma(2.0, so, sd);
     const double s1sq = s1 * s1;
-    if (clamped || !(s1sq - s2 > 1e-7 * s1sq)) break;
-    const double disc = fmax(3.0 * fma(4.0, s2, -s1sq), 0.0);
-    lam += 4.0 / (s1 + sqrt(disc));
+    if (!(s1sq - s2 > 1e-3 * s1sq)) break;
+    // Laguerre step 4 / (s1 + sqrt(3 (4 s2 - s1^2))).  Only the shift depends on it, so raw
+    // v_rsq / v_rcp estimates (2^-26) are plenty; the step is shortened by 2^-20 so the estimate
+    // errors can never carry the shift past lam1.
+    const double disc = fmax(3.0 * fma(4.0, s2, -s1sq), 1e-300);
+    const double den = fma(disc, __builtin_amdgcn_rsq(disc), s1);
+    lam = fma(4.0 - 0x1p-18, __builtin_amdgcn_rcp(den), lam);
   }
-  // ---- inverse iteration: x1 = (B - lam I)^{-1} e4 ~ last row of M ; x2 = M^T (M x1)
-  const double x0 = m[3], x1 = m[6], x2 = m[8], x3 = m[9];
-  const double y0 = m[0] * x0;
-  const double y1 = fma(m[1], x0, m[4] * x1);
-  const double y2 = fma(m[2], x0, fma(m[5], x1, m[7] * x2));
-  const double y3 = fma(m[3], x0, fma(m[6], x1, fma(m[8], x2, m[9] * x3)));
-  out[0] = fma(m[0], y0, fma(m[1], y1, fma(m[2], y2, m[3] * y3)));
-  out[1] = fma(m[4], y1, fma(m[5], y2, m[6] * y3));
-  out[2] = fma(m[7], y2, m[8] * y3);
-  out[3] = m[9] * y3;
+  // ---- inverse iteration: x_1 = (B - lam I)^{-1} e4 ~ last row of M ; x_{k+1} = M^T (sc M x_k).
+  // sc = last Cholesky pivot = (lam1 - lam) / v4^2 up to O(rho): |x| stays of order one however
+  // tight the shift is (no overflow), at 4 multiplies per step.
+  double x0 = m[3], x1 = m[6], x2 = m[8], x3 = m[9];
+#pragma unroll
+  for (int k = 1; k < kInvIters; k++) {
+    const double y0 = (m[0] * x0) * piv3;
+    const double y1 = fma(m[1], x0, m[4] * x1) * piv3;
+    const double y2 = fma(m[2], x0, fma(m[5], x1, m[7] * x2)) * piv3;
+    const double y3 = fma(m[3], x0, fma(m[6], x1, fma(m[8], x2, m[9] * x3))) * piv3;
+    x0 = fma(m[0], y0, fma(m[1], y1, fma(m[2], y2, m[3] * y3)));
+    x1 = fma(m[4], y1, fma(m[5], y2, m[6] * y3));
+    x2 = fma(m[7], y2, m[8] * y3);
+    x3 = m[9] * y3;
+  }
+  out[0] = x0;
+  out[1] = x1;
+  out[2] = x2;
+  out[3] = x3;
 }
 
 #ifdef MOCAP_EIG_JACOBI
@@ -204,8 +248,8 @@ __device__ __forceinline__ void dlt_accumulate(double (&B)[10], ctab_t P, double
   double ra[4], rb[4];
 #pragma unroll
   for (int k = 0; k < 4; k++) {
-    ra[k] = y * P[8 + k] - P[4 + k];
-    rb[k] = P[k] - x * P[8 + k];
+    ra[k] = y * P[8 + k] - P[4 + k];  // unfused on purpose: an fma would need two SGPR operands
+    rb[k] = P[k] - x * P[8 + k];      // (constant-bus limit 1 on gfx9 -> extra v_mov pairs)
   }
 #pragma unroll
   for (int i = 0; i < 4; i++)
@@ -214,19 +258,19 @@ __device__ __forceinline__ void dlt_accumulate(double (&B)[10], ctab_t P, double
 }
 
 // cv.projectPoints restated (helpers.py:231-237; OpenCV cvProjectPoints2, 3x3 R, no distortion):
-// squared pixel residuals of one view.  X already rounded to float32 when f32_rounding.
-__device__ __forceinline__ void reproject_sq(ctab_t RT, ctab_t K4,
-                                             const double (&X)[3], double ox, double oy, bool f32r,
-                                             double& du2, double& dv2) {
+// squared pixel residuals of one view.  X already rounded to float32 when F32R.
+template <bool F32R>
+__device__ __forceinline__ void reproject_sq(ctab_t RT, ctab_t K4, const double (&X)[3], double ox,
+                                             double oy, double& du2, double& dv2) {
   double x = RT[0] * X[0] + RT[1] * X[1] + RT[2] * X[2] + RT[9];
   double y = RT[3] * X[0] + RT[4] * X[1] + RT[5] * X[2] + RT[10];
   double z = RT[6] * X[0] + RT[7] * X[1] + RT[8] * X[2] + RT[11];
-  z = z != 0.0 ? 1.0 / z : 1.0;
+  z = z != 0.0 ? div_by(1.0, z, recip_refined(z)) : 1.0;  // OpenCV: z = z ? 1./z : 1
   x *= z;
   y *= z;
   double pu = x * K4[0] + K4[2];
   double pv = y * K4[1] + K4[3];
-  if (f32r) {
+  if (F32R) {
     pu = (double)(float)pu;
     pv = (double)(float)pv;
   }
@@ -240,8 +284,9 @@ __device__ __forceinline__ void reproject_sq(ctab_t RT, ctab_t K4,
 //   obs2 the reprojection pass (each called once per camera, ascending, c wave-uniform).
 //   PAIRWISE: sum the squared residuals in NumPy's pairwise order when every camera is seen
 //   (float64 array path of errors.mean(), helpers.py:241); otherwise left to right.
+//   F32R: reproduce OpenCV's float32 roundings (MOCAP_OPT_F32_ROUNDING).
 // Returns the number of views; X / err are valid when it is >= 2.
-template <bool UNIFORM_K, bool PAIRWISE, class Obs1, class Obs2>
+template <bool UNIFORM_K, bool PAIRWISE, bool F32R, class Obs1, class Obs2>
 __device__ __forceinline__ int triangulate_and_score(const CamView& cv, Obs1&& obs1, Obs2&& obs2,
                                                      double (&X)[3], double& err) {
   const int C = cv.C;
@@ -258,46 +303,56 @@ __device__ __forceinline__ int triangulate_and_score(const CamView& cv, Obs1&& o
   if (v <= 1) return v;  // helpers.py:300
   double vec[4];
   smallest_eigvec4(B, vec);
-  X[0] = vec[0] / vec[3];  // helpers.py:321
-  X[1] = vec[1] / vec[3];
-  X[2] = vec[2] / vec[3];
+  const double rw = recip_refined(vec[3]);
+  X[0] = div_by(vec[0], vec[3], rw);  // helpers.py:321
+  X[1] = div_by(vec[1], vec[3], rw);
+  X[2] = div_by(vec[2], vec[3], rw);
 
-  const bool f32r = cv.f32_rounding != 0;
   double Xp[3] = {X[0], X[1], X[2]};
-  if (f32r) {
+  if (F32R) {
     Xp[0] = (double)(float)X[0];  // helpers.py:232 `.astype(np.float32)`
     Xp[1] = (double)(float)X[1];
     Xp[2] = (double)(float)X[2];
   }
+  // NumPy's pairwise sum of the n = 2C residual components (n < 8: plain loop; else eight partial
+  // sums over the leading n - n % 8 values, a fixed tree, then the rest one by one).  Cameras come
+  // in fours (8 components); `seq` is the left-to-right sum used when a view is missing.
   const bool pw = PAIRWISE && v == C && 2 * C >= 8;
-  double seq = 0.0, r[8] = {0, 0, 0, 0, 0, 0, 0, 0}, spw = 0.0;
+  const int C4 = C & ~3;
+  double seq = 0.0, r[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   int j = 0;
-  for (int c0 = 0; c0 < C; c0 += 4) {
-    const bool full_chunk = c0 + 4 <= C;
-    if (!full_chunk) spw = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+  for (int c0 = 0; c0 < C4; c0 += 4) {
 #pragma unroll
     for (int u = 0; u < 4; u++) {
-      const int c = c0 + u;
-      if (c < C) {
-        double x, y;
-        if (obs2(c, x, y)) {
-          double du2, dv2;
-          reproject_sq(as_ctab(cv.RT + 12 * c), as_ctab(cv.K4 + 4 * (UNIFORM_K ? 0 : j)), Xp, x, y, f32r, du2, dv2);
-          seq = seq + du2;
-          seq = seq + dv2;
-          if (full_chunk) {
-            r[2 * u] = r[2 * u] + du2;
-            r[2 * u + 1] = r[2 * u + 1] + dv2;
-          } else {
-            spw = spw + du2;
-            spw = spw + dv2;
-          }
-          j++;
+      double x, y;
+      if (obs2(c0 + u, x, y)) {
+        double du2, dv2;
+        reproject_sq<F32R>(as_ctab(cv.RT + 12 * (c0 + u)), as_ctab(cv.K4 + 4 * (UNIFORM_K ? 0 : j)), Xp, x, y, du2, dv2);
+        seq = seq + du2;
+        seq = seq + dv2;
+        if (PAIRWISE) {
+          r[2 * u] = r[2 * u] + du2;
+          r[2 * u + 1] = r[2 * u + 1] + dv2;
         }
+        j++;
       }
     }
   }
-  if ((C & 3) == 0) spw = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+  double spw = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+  for (int c = C4; c < C; c++) {
+    double x, y;
+    if (obs2(c, x, y)) {
+      double du2, dv2;
+      reproject_sq<F32R>(as_ctab(cv.RT + 12 * c), as_ctab(cv.K4 + 4 * (UNIFORM_K ? 0 : j)), Xp, x, y, du2, dv2);
+      seq = seq + du2;
+      seq = seq + dv2;
+      if (PAIRWISE) {
+        spw = spw + du2;
+        spw = spw + dv2;
+      }
+      j++;
+    }
+  }
   err = (pw ? spw : seq) / (double)(2 * v);
   return v;
 }

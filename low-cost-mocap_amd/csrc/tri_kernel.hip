@@ -8,7 +8,7 @@
 
 namespace mocap {
 
-template <bool UNIFORM_K>
+template <bool UNIFORM_K, bool F32R>
 __global__ __launch_bounds__(256) void tri_kernel(TriArgs a) {
   CamView cv = a.cv;
   const int p = blockIdx.y;
@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256) void tri_kernel(TriArgs a) {
     double X[3] = {qnan, qnan, qnan}, e = qnan;
     // explicit captures arrive as object ndarrays in the reference (index.py:232): errors.mean()
     // sums left to right there, so PAIRWISE = false
-    const int v = triangulate_and_score<UNIFORM_K, false>(cv, obs, obs, X, e);
+    const int v = triangulate_and_score<UNIFORM_K, false, F32R>(cv, obs, obs, X, e);
     if (v < 2) {
       X[0] = X[1] = X[2] = qnan;  // the reference yields [None, None, None] (helpers.py:300-301)
       e = qnan;                   // and skips the error entry (helpers.py:207-208)
@@ -47,10 +47,12 @@ hipError_t launch_triangulate(const TriArgs& a, hipStream_t stream) {
   int64_t blocks = (a.N + 255) / 256;
   if (blocks > 8192) blocks = 8192;
   dim3 grid((unsigned)blocks, (unsigned)a.P);
-  if (a.cv.uniformK)
-    hipLaunchKernelGGL(tri_kernel<true>, grid, dim3(256), 0, stream, a);
+  void (*k)(TriArgs);
+  if (a.cv.f32_rounding)
+    k = a.cv.uniformK ? tri_kernel<true, true> : tri_kernel<false, true>;
   else
-    hipLaunchKernelGGL(tri_kernel<false>, grid, dim3(256), 0, stream, a);
+    k = a.cv.uniformK ? tri_kernel<true, false> : tri_kernel<false, false>;
+  hipLaunchKernelGGL(k, grid, dim3(256), 0, stream, a);
   return hipGetLastError();
 }
 

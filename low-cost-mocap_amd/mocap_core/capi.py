@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(_PKG_ROOT, "lib", "libmocap_core.so")
+# MOCAP_CORE_LIB points at another build of the same C ABI (A/B measurements of kernel variants)
+LIB_PATH = os.environ.get("MOCAP_CORE_LIB") or os.path.join(_PKG_ROOT, "lib", "libmocap_core.so")
 
 MOCAP_OK = 0
 MOCAP_E_NOCONV = -5
