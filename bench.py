@@ -41,6 +41,19 @@ def algorithmic_bytes(counts, n_out, C, M):
     return F * (8 * C * M + 4 * C) + int(n_out.sum()) * (24 + 8 + 2 * C)
 
 
+def measured_traffic(frames):
+    """HBM bytes per launch from the committed PMC pass (profiles/r01_hbm_traffic.json: rocprofv3
+    FETCH_SIZE x2 [gfx950 correction] + WRITE_SIZE per frame, measured on this kernel at 20 k frames),
+    scaled to this launch's frame count.  PMC counters cannot be read inside the timed run, so this
+    is the profile's figure, not a live one; None if the summary is absent."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")) as f:
+            t = json.load(f)
+        return float(t["hbm_bytes_per_frame"]) * frames
+    except Exception:
+        return None
+
+
 def cpu_baseline(rig, blobs, counts, budget_s=15.0):
     """The oracle's C restatement of the reference path ("port"), single thread, on a bounded
     prefix of the SAME frames.  Reported baseline only -- never the thing measured or shipped."""
@@ -207,7 +220,8 @@ def main():
                        "markers_per_frame": total_markers / (F * world),
                        "candidates_per_frame": float(n_cand.mean()), "overflow_frames": int(allv[:, 2].sum())},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                         "frac": ach / HBM_PEAK_GBS, "traffic": measured_traffic(F),
+                         "traffic_source": "profiles/r01_hbm_traffic.json (rocprofv3 PMC, per frame x frames)",
                          "kernel": "mocap::frame_kernel (MODE 0+1+2 launches of one pass, HIP events)",
                          "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": abytes,
@@ -215,7 +229,9 @@ def main():
             "roofline_fp64": {"bound": "fp64_valu", "achieved": flops / (kernel_ms * 1e-3) / 1e12,
                               "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s",
                               "frac": flops / (kernel_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TF,
-                              "model": "candidates x (92 v + 1500) flop, v = mean views", "v_mean": v_mean,
+                              "model": "SURVEY 8d work model: candidates x (92 v + 1500) flop, v = mean views "
+                                       "(the kernel now needs fewer instructions than the model's Jacobi "
+                                       "eigen-solve; issue-slot utilisation from PMC: profiles/)", "v_mean": v_mean,
                               "candidates_per_launch": float(n_cand.sum())},
         }
         if world == 1:

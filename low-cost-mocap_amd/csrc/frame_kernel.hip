@@ -620,7 +620,11 @@ __global__ __launch_bounds__(T, MOCAP_FRAME_WAVES_PER_EU) void frame_kernel(Fram
       __syncthreads();
       if (st.misc[MI_DEFER]) continue;  // uniform
       st.write_frame_header(frame);
+#ifdef MOCAP_DEBUG_NO_EVAL  // timing experiments only: phases A-C without candidate evaluation
+      if (false) {
+#else
       if (G) {
+#endif
         st.evaluate(0, G);
         const int nroots = st.misc[MI_NROOTS];
         for (int r = tid; r < nroots; r += T) {
