@@ -45,7 +45,8 @@ enum {
 enum {
   MOCAP_ST_ROOT_OVERFLOW = 1, /* more roots than K_max: frame output invalid          */
   MOCAP_ST_CAND_OVERFLOW = 2, /* a root has more than G_cap candidate groups: invalid */
-  MOCAP_ST_HIT_OVERFLOW = 4   /* reserved                                             */
+  MOCAP_ST_HIT_OVERFLOW = 4   /* wide frames only: a (root, camera) pair has more gated hits
+                                 than hit_cap (mocap_set_frame_limits): invalid          */
 };
 
 /* flags for mocap_set_options */
@@ -71,6 +72,12 @@ int mocap_set_options(mocap_ctx* ctx, uint32_t flags);
  *                    workgroups (-1 = automatic, 0 = never split)
  *   slice_size       target candidates per slice (0 = automatic) */
 int mocap_set_tuning(mocap_ctx* ctx, int frame_threads, int heavy_threshold, int slice_size);
+/* Frames whose state does not fit the 160 KB of LDS (e.g. 64 cameras x 256 blobs) run through a
+ * "wide" variant that keeps hit lists and per-lane group columns in an HBM workspace and caps the
+ * gated hits kept per (root, camera) at hit_cap (default 16, 0 = keep; the reference has no cap:
+ * overflow sets MOCAP_ST_HIT_OVERFLOW and the frame is re-submitted with a larger cap).
+ * force_wide != 0 routes every batch through that variant (tests).  Results are identical. */
+int mocap_set_frame_limits(mocap_ctx* ctx, int hit_cap, int force_wide);
 /* compiled limits: max cameras, max blobs per camera */
 void mocap_limits(int* max_cameras, int* max_blobs);
 

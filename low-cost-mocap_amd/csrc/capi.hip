@@ -82,6 +82,7 @@ extern "C" int mocap_create(int device_id, mocap_ctx** out) {
   }
   if ((t = getenv("MOCAP_HEAVY_THRESHOLD"))) c->heavy_threshold = atoi(t);  // 0 disables splitting
   if ((t = getenv("MOCAP_SLICE_SIZE"))) c->slice_size = atoi(t);
+  if ((t = getenv("MOCAP_FORCE_WIDE"))) c->force_wide = atoi(t) ? 1 : 0;
   *out = c;
   return MOCAP_OK;
 }
@@ -92,6 +93,7 @@ extern "C" void mocap_destroy(mocap_ctx* ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   ctx->tables.release();
   for (auto& b : ctx->scratch) b.release();
+  ctx->frame_ws.release();
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
 }
@@ -130,6 +132,15 @@ extern "C" int mocap_set_tuning(mocap_ctx* ctx, int frame_threads, int heavy_thr
   if (frame_threads) ctx->frame_threads = frame_threads;
   ctx->heavy_threshold = heavy_threshold < 0 ? -1 : heavy_threshold;
   ctx->slice_size = slice_size < 0 ? 0 : slice_size;
+  return MOCAP_OK;
+}
+
+extern "C" int mocap_set_frame_limits(mocap_ctx* ctx, int hit_cap, int force_wide) {
+  if (!ctx) return MOCAP_E_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (hit_cap < 0 || hit_cap > kMaxBlobs) return ctx->fail(MOCAP_E_ARG, "mocap_set_frame_limits: hit_cap must be 0..%d", kMaxBlobs);
+  if (hit_cap) ctx->hit_cap = hit_cap;
+  ctx->force_wide = force_wide ? 1 : 0;
   return MOCAP_OK;
 }
 
@@ -337,22 +348,42 @@ static int match_dev_locked(mocap_ctx* ctx, int64_t n_frames, int M_max, const f
   a.status = d_status;
   a.n_cand = d_n_cand;
   int T = ctx->frame_threads;
-  size_t lds = frame_lds_bytes(ctx->C, M_max, K_max, T);
-  while (lds > 160 * 1024 && T > 64) {
-    T /= 2;
-    lds = frame_lds_bytes(ctx->C, M_max, K_max, T);
+  const int hit_cap = ctx->hit_cap < 1 ? 1 : (ctx->hit_cap > M_max ? M_max : ctx->hit_cap);
+  bool wide = ctx->force_wide != 0;
+  size_t lds = 0;
+  if (!wide) {
+    lds = frame_lds_bytes(ctx->C, M_max, K_max, T, hit_cap, false);
+    while (lds > 160 * 1024 && T > 64) {
+      T /= 2;
+      lds = frame_lds_bytes(ctx->C, M_max, K_max, T, hit_cap, false);
+    }
+    wide = lds > 160 * 1024;  // the frame state does not fit LDS: big tables go to an HBM workspace
   }
-  if (lds > 160 * 1024)
-    return ctx->fail(MOCAP_E_LIMIT, "frame state needs %zu B of LDS (C=%d, M_max=%d, K_max=%d): lower K_max",
-                     lds, ctx->C, M_max, K_max);
+  if (wide) {
+    T = kWideThreads;
+    lds = frame_lds_bytes(ctx->C, M_max, K_max, T, hit_cap, true);
+    if (lds > 160 * 1024)
+      return ctx->fail(MOCAP_E_LIMIT, "frame state needs %zu B of LDS (C=%d, M_max=%d, K_max=%d): lower K_max",
+                       lds, ctx->C, M_max, K_max);
+  }
+  a.H = hit_cap;
+  a.wide = wide ? 1 : 0;
+  a.ws = nullptr;
+  a.ws_stride = 0;
   // persistent grid: enough workgroups to fill every CU at the LDS-limited occupancy
   int per_cu = (int)((160 * 1024) / lds);
-  const int wave_cap = 32 / (T / 64);
+  const int wave_cap = 16 / (T / 64) > 0 ? 16 / (T / 64) : 1;  // 128 VGPRs -> 16 waves per CU
   if (per_cu > wave_cap) per_cu = wave_cap;
   if (per_cu > 8) per_cu = 8;
   if (per_cu < 1) per_cu = 1;
   const int64_t full_grid = (int64_t)ctx->num_cus * per_cu;
   int64_t grid = full_grid < n_frames ? full_grid : n_frames;
+  if (wide) {
+    a.ws_stride = frame_ws_bytes(ctx->C, M_max, K_max, T, hit_cap, true);
+    if (ctx->frame_ws.reserve((size_t)full_grid * a.ws_stride))
+      return ctx->fail(MOCAP_E_HIP, "hipMalloc(wide-frame workspace, %zu B) failed", (size_t)full_grid * a.ws_stride);
+    a.ws = (unsigned char*)ctx->frame_ws.ptr;
+  }
 
   // work queues: heavy-frame list + slice partials (scheduling note in frame_kernel.hip)
   const bool batch = n_frames >= 2 * full_grid;

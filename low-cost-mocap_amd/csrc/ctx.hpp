@@ -21,6 +21,8 @@ struct mocap_ctx {
   int frame_threads = 256;  // workgroup size of the frame kernel (MOCAP_FRAME_THREADS=64|128|256)
   int heavy_threshold = -1; // -1 = automatic; 0 = never split heavy frames (MOCAP_HEAVY_THRESHOLD)
   int slice_size = 0;       // 0 = automatic (MOCAP_SLICE_SIZE)
+  int hit_cap = 16;         // wide frames: hits kept per (root, camera) (mocap_set_frame_limits)
+  int force_wide = 0;       // route every frame batch through the wide (HBM workspace) variant
   hipStream_t own_stream = nullptr, stream = nullptr;
   std::mutex mu;            // one context = one serialised caller (include/mocap_core.h)
   std::string err;
@@ -30,6 +32,7 @@ struct mocap_ctx {
   DevBuf tables;            // Pq | RT | K4 | F | K9
   const double* d_K9 = nullptr;
   mocap::CamView cv{};
+  DevBuf frame_ws;          // wide-frame workspace: [workgroup][hit lists | group columns | ...]
   DevBuf scratch[4];        // [0] host-API staging, [1..3] bundle adjustment workspace
 
   int fail(int code, const char* fmt, ...);

@@ -72,51 +72,69 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-struct FrameLds {
-  // byte offsets into dynamic LDS, computed identically on host (size) and device (carve)
-  size_t line, dist, seg_e, seg_x, seg_g, goff, gcnt, outslot, bxy, cxy, hits, dig, nh, root_blob,
-      root_cam, claimed, act, nact, cnt, misc, total;
+// Where the per-frame state lives.  Narrow frames (the realistic rigs: 8 cameras x 16 markers needs
+// 39 KB) keep everything in LDS.  Wide frames (up to 64 cameras x 256 blobs: the blobs alone are
+// 131 KB) keep the small, hot tables in LDS and move the big ones -- hit lists, per-lane group
+// columns -- to a per-workgroup workspace in HBM that stays L2-resident; the blobs are then read in
+// place from the input batch.  Same code either way: the arrays are reached through pointers.
+struct FrameLayout {
+  // byte offsets, computed identically on host (sizes) and device (carving)
+  size_t line, dist, seg_e, seg_x, seg_g, goff, gcnt, outslot, hcount, root_blob, root_cam, claimed, nact,
+      cnt, misc, lds_total;                          // always LDS
+  size_t bxy, cxy, hits, dig, nh, act, hb_d, hb_k;   // LDS when narrow, workspace when wide
+  size_t ws_total;
+  int Hs;  // hit-list capacity per (root, camera): M when narrow (no cap), H when wide
   __host__ __device__ static size_t align(size_t x, size_t a) { return (x + a - 1) / a * a; }
-  __host__ __device__ FrameLds(int C, int M, int R, int T) {
+  __host__ __device__ FrameLayout(int C, int M, int R, int T, int H, bool wide) {
+    Hs = wide ? H : M;
     size_t o = 0;
     line = o;      o += sizeof(double) * kLineStride * R;
     seg_e = o;     o += sizeof(double) * (T + R);
     seg_x = o;     o += sizeof(double) * 3 * (T + R);
     // dist (phase B scratch) and the segment arrays (phase D/E) are never live together
     dist = line + sizeof(double) * kLineStride * R;
-    const size_t dist_n = (size_t)R * M > (size_t)T ? (size_t)R * M : (size_t)T;
+    const size_t dist_n = wide ? 0 : ((size_t)R * M > (size_t)T ? (size_t)R * M : (size_t)T);
     const size_t dist_end = dist + sizeof(double) * dist_n;
     if (dist_end > o) o = dist_end;
     seg_g = o;     o += sizeof(uint32_t) * (T + R);
     goff = o;      o += sizeof(uint32_t) * (R + 1);
     gcnt = o;      o += sizeof(uint32_t) * R;
     outslot = o;   o += sizeof(int32_t) * R;
-    bxy = o;       o += sizeof(float2) * (size_t)C * M;
-    cxy = o;       o += sizeof(float2) * (size_t)C * T;
+    hcount = o;    o += wide ? sizeof(int32_t) * R : 0;
     cnt = o;       o += sizeof(int32_t) * C;
     misc = o;      o += sizeof(int32_t) * 8;
-    hits = o;      o += (size_t)R * C * M;
-    dig = o;       o += (size_t)C * T;
-    nh = o;        o += sizeof(uint16_t) * (size_t)R * C;
     root_blob = o; o += sizeof(uint16_t) * R;
     root_cam = o;  o += R;
     claimed = o;   o += M;
-    act = o;       o += (size_t)R * C;
     nact = o;      o += R;
-    total = align(o, 16);
+    o = align(o, 16);
+    size_t w = wide ? 0 : o;  // the movable arrays continue in LDS, or start a workspace
+    cxy = w;       w += sizeof(float2) * (size_t)C * T;
+    hb_d = w;      w += wide ? sizeof(double) * (size_t)R * H : 0;
+    bxy = w;       w += wide ? 0 : sizeof(float2) * (size_t)C * M;
+    nh = w;        w += sizeof(uint16_t) * (size_t)R * C;
+    hits = w;      w += (size_t)R * C * Hs;
+    dig = w;       w += (size_t)C * T;
+    act = w;       w += (size_t)R * C;
+    hb_k = w;      w += wide ? (size_t)R * H : 0;
+    w = align(w, 256);
+    lds_total = wide ? o : align(w, 16);
+    ws_total = wide ? w : 0;
   }
 };
 
-size_t frame_lds_bytes(int C, int M, int R, int T) { return FrameLds(C, M, R, T).total; }
+size_t frame_lds_bytes(int C, int M, int R, int T, int H, bool wide) { return FrameLayout(C, M, R, T, H, wide).lds_total; }
+size_t frame_ws_bytes(int C, int M, int R, int T, int H, bool wide) { return FrameLayout(C, M, R, T, H, wide).ws_total; }
 
 // misc[] slots
 enum { MI_NROOTS = 0, MI_STATUS = 1, MI_NOUT = 2, MI_G = 3, MI_ITEM = 4, MI_DEFER = 5 };
 
-template <int T, bool UNIFORM_K, bool F32R>
+template <int T, bool UNIFORM_K, bool F32R, bool WIDE>
 struct FrameState {
   const FrameArgs& p;
   const CamView& cv;
   const int C, M, R, tid;
+  int Hs;  // hit-list stride per (root, camera)
   double *line, *dist, *seg_e, *seg_x;
   uint32_t *seg_g, *goff, *gcnt;
   int32_t *outslot, *cnt, *misc;
@@ -126,10 +144,14 @@ struct FrameState {
   uint8_t *hits;  // [R][C][M] blob indices of the gated hits, ascending distance (M <= 256)
   uint8_t *dig;   // [C][T]    this lane's odometer digits
   uint8_t *root_cam, *claimed, *act, *nact;  // act [R][C]: cameras of root r with >= 2 hits
+  int32_t *hcount;  // wide: [R] hits found so far for the camera being matched
+  double *hb_d;     // wide: [R][H] unsorted hit distances ...
+  uint8_t *hb_k;    // wide: [R][H] ... and blob indices
 
   __device__ FrameState(const FrameArgs& p_, unsigned char* smem)
       : p(p_), cv(p_.cv), C(p_.cv.C), M(p_.M), R(p_.K_max), tid(threadIdx.x) {
-    const FrameLds L(C, M, R, T);
+    const FrameLayout L(C, M, R, T, p_.H, WIDE);
+    Hs = L.Hs;
     line = (double*)(smem + L.line);
     dist = (double*)(smem + L.dist);
     seg_e = (double*)(smem + L.seg_e);
@@ -138,18 +160,23 @@ struct FrameState {
     goff = (uint32_t*)(smem + L.goff);
     gcnt = (uint32_t*)(smem + L.gcnt);
     outslot = (int32_t*)(smem + L.outslot);
-    bxy = (float2*)(smem + L.bxy);
-    cxy = (float2*)(smem + L.cxy) + tid;
+    hcount = (int32_t*)(smem + L.hcount);
     cnt = (int32_t*)(smem + L.cnt);
     misc = (int32_t*)(smem + L.misc);
-    hits = (uint8_t*)(smem + L.hits);
-    dig = (uint8_t*)(smem + L.dig) + tid;
-    nh = (uint16_t*)(smem + L.nh);
     root_blob = (uint16_t*)(smem + L.root_blob);
     root_cam = (uint8_t*)(smem + L.root_cam);
     claimed = (uint8_t*)(smem + L.claimed);
-    act = (uint8_t*)(smem + L.act);
     nact = (uint8_t*)(smem + L.nact);
+    // the movable arrays: LDS, or this workgroup's slice of the HBM workspace
+    unsigned char* big = WIDE ? p_.ws + (size_t)blockIdx.x * p_.ws_stride : smem;
+    bxy = (float2*)(big + L.bxy);  // wide: re-pointed at the input frame in match()
+    cxy = (float2*)(big + L.cxy) + tid;
+    hits = (uint8_t*)(big + L.hits);
+    dig = (uint8_t*)(big + L.dig) + tid;
+    nh = (uint16_t*)(big + L.nh);
+    act = (uint8_t*)(big + L.act);
+    hb_d = (double*)(big + L.hb_d);
+    hb_k = (uint8_t*)(big + L.hb_k);
   }
 
   // ---------------------------------------------------------------- phases A-C
@@ -157,7 +184,11 @@ struct FrameState {
   __device__ void match(int64_t frame) {
     {
       const float2* src = (const float2*)(p.blobs + (size_t)frame * C * M * 2);
-      for (int i = tid; i < C * M; i += T) bxy[i] = src[i];
+      if (WIDE) {
+        bxy = const_cast<float2*>(src);  // read in place (L1/L2), never written
+      } else {
+        for (int i = tid; i < C * M; i += T) bxy[i] = src[i];
+      }
       if (tid < C) {
         int n = p.counts[(size_t)frame * C + tid];
         cnt[tid] = n < 0 ? 0 : (n > M ? M : n);
@@ -183,7 +214,7 @@ struct FrameState {
     // trips through the whole workgroup, only wave-level ballots
     int gs_shift = 0;
     while ((1 << gs_shift) < M) gs_shift++;
-    const bool fused = gs_shift <= 6;
+    const bool fused = !WIDE && gs_shift <= 6;
 
     for (int i = 1; i < C; i++) {
       const int Mi = cnt[i];
@@ -218,6 +249,7 @@ struct FrameState {
           line[kLineStride * r + 3] = den;
           line[kLineStride * r + 4] = recip_refined(den);  // shared by the M quotients of B2
           nh[(size_t)r * C + i] = 0;
+          if (WIDE) hcount[r] = 0;
         }
         for (int k = tid; k < M; k += 64) claimed[k] = 0;
       }
@@ -257,7 +289,7 @@ struct FrameState {
               const double d2 = dist[tid - k + j];
               rank += (d2 < d || (d2 == d && j < k)) ? 1 : 0;
             }
-            hits[((size_t)r * C + i) * M + rank] = (uint8_t)k;
+            hits[((size_t)r * C + i) * Hs + rank] = (uint8_t)k;
           }
           const unsigned long long g0 = (__ballot(rank == 0) >> gl0) & gall;
           if (valid) {
@@ -268,6 +300,66 @@ struct FrameState {
             }
           }
           wave_lds_sync();  // dist[] is reused by the next pass
+        }
+      } else if (WIDE) {
+        // wide path: hits are rare among the R x M pairs, so lanes append them to a small per-root
+        // buffer (LDS counter, any order) and one lane per root then orders its few hits by
+        // (distance, index) -- the same total order, whatever order the appends landed in
+        const int GS = 1 << gs_shift;
+        const int k = tid & (GS - 1);
+        const int roots_per_pass = T >> gs_shift;
+        const int H = p.H;
+        double px = 0.0, py = 0.0;
+        if (k < Mi) {
+          px = (double)pts[k].x;
+          py = (double)pts[k].y;
+        }
+        for (int r = tid >> gs_shift; r < nroots; r += roots_per_pass) {
+          if (k < Mi) {
+            const double* ln = line + kLineStride * r;
+            const double d = div_by(fabs(ln[0] * px + ln[1] * py + ln[2]), ln[3], ln[4]);
+            if (d < p.gate_px) {
+              const int pos = atomicAdd(&hcount[r], 1);
+              if (pos < H) {
+                hb_d[(size_t)r * H + pos] = d;
+                hb_k[(size_t)r * H + pos] = (uint8_t)k;
+              }
+            }
+          }
+        }
+        __syncthreads();
+        for (int r = tid; r < nroots; r += T) {
+          int n = hcount[r];
+          if (n > H) {
+            atomicOr(&misc[MI_STATUS], MOCAP_ST_HIT_OVERFLOW_);
+            n = H;
+          }
+          double* hd = hb_d + (size_t)r * H;
+          uint8_t* hk = hb_k + (size_t)r * H;
+          for (int a = 1; a < n; a++) {  // insertion sort, n is a handful
+            const double da = hd[a];
+            const uint8_t ka = hk[a];
+            int b = a - 1;
+            while (b >= 0 && (hd[b] > da || (hd[b] == da && hk[b] > ka))) {
+              hd[b + 1] = hd[b];
+              hk[b + 1] = hk[b];
+              b--;
+            }
+            hd[b + 1] = da;
+            hk[b + 1] = ka;
+          }
+          uint8_t* dst = hits + ((size_t)r * C + i) * Hs;
+          for (int a = 0; a < n; a++) dst[a] = hk[a];
+          nh[(size_t)r * C + i] = (uint16_t)n;
+          if (n > 0) {
+            // removal by value (helpers.py:391): a blob with the closest hit's coordinates has its
+            // distance, so it is one of this root's hits
+            const float2 p0 = pts[hk[0]];
+            for (int a = 0; a < n; a++) {
+              const float2 q = pts[hk[a]];
+              if (q.x == p0.x && q.y == p0.y) claimed[hk[a]] = 1;
+            }
+          }
         }
       } else {
         // generic path (a root's blobs span several waves): same steps through LDS + barriers
@@ -289,7 +381,7 @@ struct FrameState {
               const double d2 = dr[k2];
               rank += (d2 < d || (d2 == d && k2 < k)) ? 1 : 0;
             }
-            hits[((size_t)r * C + i) * M + rank] = (uint8_t)k;
+            hits[((size_t)r * C + i) * Hs + rank] = (uint8_t)k;
           }
           if (k == 0) {
             int n = 0;
@@ -301,7 +393,7 @@ struct FrameState {
         for (int idx = tid; idx < npairs; idx += T) {
           const int r = idx / Mi, k = idx - r * Mi;
           if (nh[(size_t)r * C + i] > 0) {
-            const int k0 = hits[((size_t)r * C + i) * M];
+            const int k0 = hits[((size_t)r * C + i) * Hs];
             if (pts[k].x == pts[k0].x && pts[k].y == pts[k0].y) claimed[k] = 1;
           }
         }
@@ -390,7 +482,7 @@ struct FrameState {
     const int rc = root_cam[r];
     const uint16_t rb = root_blob[r];
     const uint16_t* nhr = nh + (size_t)r * C;
-    const uint8_t* hr = hits + (size_t)r * C * M;
+    const uint8_t* hr = hits + (size_t)r * C * Hs;
     const float qn = __int_as_float(0x7fc00000);
     uint32_t rem = gl;
     for (int c = 0; c < C; c++) {
@@ -406,7 +498,7 @@ struct FrameState {
             divmod_small(rem, n, qd, dgt);
             rem = qd;
           }
-          s = hr[(size_t)c * M + dgt];
+          s = hr[(size_t)c * Hs + dgt];
         }
       }
       dig[(size_t)c * T] = (uint8_t)dgt;
@@ -418,14 +510,14 @@ struct FrameState {
     const uint8_t* a = act + (size_t)r * C;
     const int na = nact[r];
     const uint16_t* nhr = nh + (size_t)r * C;
-    const uint8_t* hr = hits + (size_t)r * C * M;
+    const uint8_t* hr = hits + (size_t)r * C * Hs;
     for (int k = 0; k < na; k++) {
       const int c = a[k];
       uint32_t d = (uint32_t)dig[(size_t)c * T] + 1u;
       const bool wrap = d >= nhr[c];
       if (wrap) d = 0;
       dig[(size_t)c * T] = (uint8_t)d;
-      cxy[(size_t)c * T] = bxy[(size_t)c * M + hr[(size_t)c * M + d]];
+      cxy[(size_t)c * T] = bxy[(size_t)c * M + hr[(size_t)c * Hs + d]];
       if (!wrap) break;
     }
   }
@@ -540,7 +632,7 @@ struct FrameState {
         if (n) {
           uint32_t qd, dgt;
           divmod_small(rem, n, qd, dgt);
-          s = (int16_t)hits[((size_t)r * C + c) * M + dgt];
+          s = (int16_t)hits[((size_t)r * C + c) * Hs + dgt];
           rem = qd;
         }
       }
@@ -558,10 +650,10 @@ struct FrameState {
   }
 };
 
-template <int T, bool UNIFORM_K, bool F32R, int MODE>
+template <int T, bool UNIFORM_K, bool F32R, bool WIDE, int MODE>
 __global__ __launch_bounds__(T, MOCAP_FRAME_WAVES_PER_EU) void frame_kernel(FrameArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  FrameState<T, UNIFORM_K, F32R> st(p, smem);
+  FrameState<T, UNIFORM_K, F32R, WIDE> st(p, smem);
   const int tid = threadIdx.x;
   const FrameQueues& q = p.q;
   const int R = p.K_max;
@@ -689,13 +781,13 @@ __global__ __launch_bounds__(T, MOCAP_FRAME_WAVES_PER_EU) void frame_kernel(Fram
   }
 }
 
-template <int T, int MODE>
+template <int T, bool WIDE, int MODE>
 static hipError_t launch_TM(const FrameArgs& a, int grid, size_t lds, hipStream_t stream) {
   void (*k)(FrameArgs);
   if (a.cv.f32_rounding)
-    k = a.cv.uniformK ? frame_kernel<T, true, true, MODE> : frame_kernel<T, false, true, MODE>;
+    k = a.cv.uniformK ? frame_kernel<T, true, true, WIDE, MODE> : frame_kernel<T, false, true, WIDE, MODE>;
   else
-    k = a.cv.uniformK ? frame_kernel<T, true, false, MODE> : frame_kernel<T, false, false, MODE>;
+    k = a.cv.uniformK ? frame_kernel<T, true, false, WIDE, MODE> : frame_kernel<T, false, false, WIDE, MODE>;
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
@@ -704,21 +796,22 @@ static hipError_t launch_TM(const FrameArgs& a, int grid, size_t lds, hipStream_
   return hipGetLastError();
 }
 
-template <int T>
+template <int T, bool WIDE>
 static hipError_t launch_T(const FrameArgs& a, int mode, int grid, size_t lds, hipStream_t stream) {
   switch (mode) {
-    case MODE_MAIN: return launch_TM<T, MODE_MAIN>(a, grid, lds, stream);
-    case MODE_SLICE: return launch_TM<T, MODE_SLICE>(a, grid, lds, stream);
-    default: return launch_TM<T, MODE_MERGE>(a, grid, lds, stream);
+    case MODE_MAIN: return launch_TM<T, WIDE, MODE_MAIN>(a, grid, lds, stream);
+    case MODE_SLICE: return launch_TM<T, WIDE, MODE_SLICE>(a, grid, lds, stream);
+    default: return launch_TM<T, WIDE, MODE_MERGE>(a, grid, lds, stream);
   }
 }
 
 hipError_t launch_frame_kernel(const FrameArgs& a, int mode, int threads, int grid, hipStream_t stream) {
-  const size_t lds = frame_lds_bytes(a.cv.C, a.M, a.K_max, threads);
+  const size_t lds = frame_lds_bytes(a.cv.C, a.M, a.K_max, threads, a.H, a.wide != 0);
+  if (a.wide) return threads == kWideThreads ? launch_T<kWideThreads, true>(a, mode, grid, lds, stream) : hipErrorInvalidValue;
   switch (threads) {
-    case 64: return launch_T<64>(a, mode, grid, lds, stream);
-    case 128: return launch_T<128>(a, mode, grid, lds, stream);
-    case 256: return launch_T<256>(a, mode, grid, lds, stream);
+    case 64: return launch_T<64, false>(a, mode, grid, lds, stream);
+    case 128: return launch_T<128, false>(a, mode, grid, lds, stream);
+    case 256: return launch_T<256, false>(a, mode, grid, lds, stream);
     default: return hipErrorInvalidValue;
   }
 }

@@ -10,6 +10,7 @@ namespace mocap {
 // status bits, mirrored from include/mocap_core.h (MOCAP_ST_*)
 constexpr int MOCAP_ST_ROOT_OVERFLOW_ = 1;
 constexpr int MOCAP_ST_CAND_OVERFLOW_ = 2;
+constexpr int MOCAP_ST_HIT_OVERFLOW_ = 4;
 
 // device-side work queues of the frame path (see the scheduling note in frame_kernel.hip)
 constexpr int MODE_MAIN = 0, MODE_SLICE = 1, MODE_MERGE = 2;
@@ -42,9 +43,16 @@ struct FrameArgs {
   int32_t* n_out;         // [F]
   int32_t* status;        // [F]
   int32_t* n_cand;        // [F] or null
+  // wide frames (state does not fit LDS): per-workgroup workspace in HBM, hit-list cap per (root, camera)
+  unsigned char* ws;
+  size_t ws_stride;
+  int H;
+  int wide;
 };
 
-size_t frame_lds_bytes(int C, int M, int R, int T);
+constexpr int kWideThreads = 1024;  // workgroup size of the wide-frame variant (one workgroup per CU)
+size_t frame_lds_bytes(int C, int M, int R, int T, int H, bool wide);
+size_t frame_ws_bytes(int C, int M, int R, int T, int H, bool wide);
 hipError_t launch_frame_kernel(const FrameArgs& a, int mode, int threads, int grid, hipStream_t stream);
 
 // explicit-correspondence triangulation, optionally batched over P camera sets (bundle adjustment)

@@ -17,6 +17,7 @@ MOCAP_OK = 0
 MOCAP_E_NOCONV = -5
 ST_ROOT_OVERFLOW = 1
 ST_CAND_OVERFLOW = 2
+ST_HIT_OVERFLOW = 4
 OPT_F32_ROUNDING = 1
 
 _vp, _i32, _i64, _dbl, _u32 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_double, ctypes.c_uint32
@@ -31,6 +32,7 @@ SIGNATURES = {
     "mocap_synchronize": (_i32, [_vp]),
     "mocap_set_options": (_i32, [_vp, _u32]),
     "mocap_set_tuning": (_i32, [_vp, _i32, _i32, _i32]),
+    "mocap_set_frame_limits": (_i32, [_vp, _i32, _i32]),
     "mocap_limits": (None, [ctypes.POINTER(_i32), ctypes.POINTER(_i32)]),
     "mocap_set_cameras": (_i32, [_vp, _i32, _vp, _vp, _vp]),
     "mocap_get_fundamental": (_i32, [_vp, _vp]),
@@ -86,6 +88,7 @@ class MocapCore:
         self._h = h
         self.device_id = int(device_id)
         self.C = 0
+        self._hit_cap, self._force_wide = 16, False
 
     def close(self):
         if getattr(self, "_h", None):
@@ -117,6 +120,17 @@ class MocapCore:
 
     def set_tuning(self, frame_threads=0, heavy_threshold=-1, slice_size=0):
         self._check(self.lib.mocap_set_tuning(self._h, int(frame_threads), int(heavy_threshold), int(slice_size)))
+
+    def set_frame_limits(self, hit_cap=0, force_wide=False):
+        """hit_cap: gated hits kept per (root, camera) by the wide-frame variant (0 = keep the current
+        value); force_wide: run every batch through that variant (tests)."""
+        self._apply_frame_limits(hit_cap, force_wide)
+        if hit_cap:
+            self._hit_cap = int(hit_cap)
+        self._force_wide = bool(force_wide)
+
+    def _apply_frame_limits(self, hit_cap, force_wide):
+        self._check(self.lib.mocap_set_frame_limits(self._h, int(hit_cap), int(bool(force_wide))))
 
     def set_stream(self, hip_stream_handle):
         self._check(self.lib.mocap_set_stream(self._h, ctypes.c_void_p(hip_stream_handle or 0)))
@@ -157,12 +171,17 @@ class MocapCore:
 
     def match_triangulate_auto(self, blobs, counts, gate_px=5.0, K_max=None, G_cap=1 << 20):
         """match_triangulate, then frames whose caps overflowed are re-submitted ON THE GPU with the
-        worst-case root capacity (C*M) and the largest candidate cap."""
+        worst-case root capacity (C*M), the largest candidate cap and (wide frames) an uncapped hit list."""
         res = self.match_triangulate(blobs, counts, gate_px, K_max, G_cap)
         bad = np.nonzero(res["status"])[0]
         if bad.size:
             F, C, M, _ = np.shape(blobs)
-            big = self.match_triangulate(np.asarray(blobs)[bad], np.asarray(counts)[bad], gate_px, C * M, 1 << 24)
+            self._apply_frame_limits(M, self._force_wide)
+            try:
+                big = self.match_triangulate(np.asarray(blobs)[bad], np.asarray(counts)[bad], gate_px,
+                                             min(C * M, 1024), 1 << 24)
+            finally:
+                self._apply_frame_limits(self._hit_cap, self._force_wide)
             k0 = res["xyz"].shape[1]
             if big["n_out"].max(initial=0) > k0:
                 grow = int(big["n_out"].max())

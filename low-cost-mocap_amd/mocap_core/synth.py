@@ -15,6 +15,22 @@ import numpy as np
 
 DEFAULT_K = [[320.0, 0.0, 160.0], [0.0, 320.0, 160.0], [0.0, 0.0, 1.0]]  # camera-params.json:3-5
 VGA_K = [[640.0, 0.0, 320.0], [0.0, 640.0, 240.0], [0.0, 0.0, 1.0]]
+# Stress config (BASELINE.json configs[4], 64 cams x 256 markers): the reference enumerates the full
+# Cartesian product of gated hits over all cameras (helpers.py:394-400), so with 63 other cameras
+# even 0.1 false hits per camera explodes.  The virtual sensor is therefore 16 k x 16 k px with
+# sub-pixel (float) centroids and the gate is STRESS_GATE_PX: ~0.02 false hits per (root, camera).
+STRESS_K = [[12000.0, 0.0, 8000.0], [0.0, 12000.0, 8000.0], [0.0, 0.0, 1.0]]
+STRESS_GATE_PX = 0.5
+
+
+def stress_rig(num_cameras=64):
+    return ring_rig(num_cameras, K=STRESS_K, image_size=(16000, 16000))
+
+
+def make_stress_stream(rig, n_frames, n_markers=256, seed=0):
+    """64 x 256-style stream: float centroids, 0.02 px noise, markers in a +-1.5 m cube."""
+    return make_blob_stream(rig, n_frames, n_markers, seed=seed, noise_px=0.02, dropout=0.05,
+                            half_extent=1.5, min_sep=0.05, truncate=False)
 
 
 def _look_at(cam_pos, target=np.zeros(3)):

@@ -256,3 +256,72 @@ def test_triangulate_vs_c_oracle_large(core):
     okc = ~np.isnan(xyz_c[:, 0])
     np.testing.assert_allclose(xyz_c[okc], X0[okc], rtol=1e-9, atol=1e-9)
     assert err_c[okc].max() < 1e-8
+
+
+def test_wide_variant_bit_identical_to_narrow(core):
+    """The wide-frame variant (big tables in an HBM workspace, 1024-lane workgroups, capped hit
+    lists ordered by insertion sort) must reproduce the LDS-resident variant bit for bit."""
+    from mocap_core import synth
+    rig = synth.ring_rig(8)
+    blobs, counts, _ = synth.make_blob_stream(rig, 1200, 16, seed=91)
+    core.set_cameras(rig["K"], rig["R"], rig["t"])
+    base = core.match_triangulate(blobs, counts, K_max=48)
+    assert not base["status"].any() and base["n_cand"].max() > 16384
+    valid = np.arange(48)[None, :] < base["n_out"][:, None]
+    try:
+        core.set_frame_limits(hit_cap=16, force_wide=True)
+        res = core.match_triangulate(blobs, counts, K_max=48)
+        for key in ("n_out", "status", "n_cand"):
+            assert np.array_equal(res[key], base[key]), key
+        for key in ("xyz", "err", "corr"):
+            assert np.array_equal(res[key][valid], base[key][valid]), key
+        # a hit cap below the longest hit list is reported per frame and repaired by the auto path
+        core.set_frame_limits(hit_cap=1, force_wide=True)
+        capped = core.match_triangulate(blobs, counts, K_max=48)
+        assert ((capped["status"] & 4) != 0).any() and (capped["n_out"][capped["status"] != 0] == 0).all()
+        auto = core.match_triangulate_auto(blobs, counts, K_max=48)
+        assert not auto["status"].any()
+        assert np.array_equal(auto["n_out"], base["n_out"])
+        assert np.array_equal(auto["corr"][:, :48][valid], base["corr"][valid])
+        assert np.array_equal(auto["xyz"][:, :48][valid], base["xyz"][valid])
+    finally:
+        core.set_frame_limits(hit_cap=16, force_wide=False)
+
+
+def test_stress_config_64_cams_256_markers_vs_c_oracle(core):
+    """BASELINE.json configs[4] shape: 64 cameras x 256 markers per frame (state far beyond LDS ->
+    wide variant chosen automatically).  Indices bit-exact, points to 1e-9, against the C restatement."""
+    from mocap_core import synth
+    from oracle import c_oracle
+    C, M, F = 64, 256, 3
+    rig = synth.stress_rig(C)
+    blobs, counts, _ = synth.make_stress_stream(rig, F, M, seed=101)
+    core.set_cameras(rig["K"], rig["R"], rig["t"])
+    res = core.match_triangulate_auto(blobs, counts, gate_px=synth.STRESS_GATE_PX, K_max=384, G_cap=1 << 20)
+    ref = c_oracle.COracle(rig["K"], rig["R"], rig["t"]).match_triangulate(
+        blobs, counts, gate_px=synth.STRESS_GATE_PX, K_max=384, G_cap=1 << 20)
+    assert not res["status"].any() and not ref["status"].any()
+    assert np.array_equal(res["n_out"], ref["n_out"]) and res["n_out"].min() > 200
+    assert np.array_equal(res["n_cand"], ref["n_cand"])
+    kk = min(res["corr"].shape[1], ref["corr"].shape[1])
+    valid = np.arange(kk)[None, :] < ref["n_out"][:, None]
+    assert np.array_equal(res["corr"][:, :kk][valid], ref["corr"][:, :kk][valid])
+    np.testing.assert_allclose(res["xyz"][:, :kk][valid], ref["xyz"][:, :kk][valid], rtol=XYZ_RTOL_TIGHT, atol=1e-12)
+    np.testing.assert_allclose(res["err"][:, :kk][valid], ref["err"][:, :kk][valid], rtol=ERR_RTOL, atol=1e-12)
+
+
+def test_medium_config_spills_to_wide_automatically(core):
+    """16 cameras x 96 blobs: too big for LDS, far from the limits -- must just work."""
+    from mocap_core import synth
+    from oracle import c_oracle
+    C, M, F = 16, 96, 6
+    rig = synth.ring_rig(C, K=synth.STRESS_K, image_size=(16000, 16000))
+    blobs, counts, _ = synth.make_stress_stream(rig, F, M, seed=111)
+    core.set_cameras(rig["K"], rig["R"], rig["t"])
+    res = core.match_triangulate_auto(blobs, counts, gate_px=2.0, K_max=160)
+    ref = c_oracle.COracle(rig["K"], rig["R"], rig["t"]).match_triangulate(blobs, counts, gate_px=2.0, K_max=160)
+    assert not res["status"].any()
+    assert np.array_equal(res["n_out"], ref["n_out"]) and res["n_out"].min() > 80
+    valid = np.arange(160)[None, :] < ref["n_out"][:, None]
+    assert np.array_equal(res["corr"][valid], ref["corr"][valid])
+    np.testing.assert_allclose(res["xyz"][valid], ref["xyz"][valid], rtol=XYZ_RTOL_TIGHT, atol=1e-12)
