@@ -31,6 +31,20 @@ CAMS, MARKERS = 8, 16
 FRAMES_PER_GPU = 100_000      # BASELINE.json configs[2] / SURVEY.md 8d cfg3
 K_MAX = 48
 G_CAP = 1 << 20
+# --workload selects one of BASELINE.json's configs; the default (the driver's) is the metric's own
+# configuration, 8 cams x 16 markers.  The others are secondary measurements of the same path.
+WORKLOADS = {
+    "8x16": dict(C=8, M=16, frames=100_000, K_max=48, gate=5.0, stress=False,
+                 desc="8 cams x 16 markers, synthetic ring rig f=320 c=160 (camera-params.json), "
+                      "int-truncated blobs, sigma=0.3px, 5% dropout (BASELINE.json configs[2])"),
+    "4x4": dict(C=4, M=4, frames=1_000_000, K_max=16, gate=5.0, stress=False,
+                desc="4 cams x 4 markers, synthetic ring rig f=320 c=160, int-truncated blobs, sigma=0.3px, "
+                     "5% dropout (BASELINE.json configs[1])"),
+    "64x256": dict(C=64, M=256, frames=1_024, K_max=384, gate=None, stress=True,
+                   desc="stress: 64 virtual cams x 256 markers, 16k x 16k px virtual sensor, float centroids, "
+                        "sigma=0.02px, gate 0.5px (bounded ambiguity), 5% dropout (BASELINE.json configs[4]; "
+                        "frames per GPU reduced from 12.5k to keep host-side generation short)"),
+}
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: 8 TB/s spec
 FP64_VALU_PEAK_TF = 78.6      # MI355X FP64 vector peak
 
@@ -89,6 +103,24 @@ def cpu_baseline(rig, blobs, counts, budget_s=15.0):
     return out
 
 
+def frame_latency(core, blobs, counts, n=300):
+    """Live-tracking use (BASELINE.json configs[2], "@120 fps"): ONE frame per call through the
+    host-buffer C entry point the reference's per-frame seam maps to (helpers.py:94 ->
+    mocap_match_triangulate): H2D of the frame's blobs, the kernels, D2H of the points, sync.
+    Wall-clock per call, successive frames of the bench stream."""
+    core.match_triangulate(blobs[:1], counts[:1], K_max=K_MAX)          # warm (allocations)
+    ts = []
+    for f in range(1, n + 1):
+        t0 = time.perf_counter()
+        core.match_triangulate(blobs[f:f + 1], counts[f:f + 1], K_max=K_MAX)
+        ts.append(time.perf_counter() - t0)
+    ts = np.sort(np.array(ts)) * 1e3
+    return {"calls": n, "p50_ms": float(ts[n // 2]), "p99_ms": float(ts[int(n * 0.99)]), "max_ms": float(ts[-1]),
+            "frame_budget_ms_at_120fps": 1e3 / 120.0,
+            "path": "mocap_match_triangulate (host buffers, 1 frame per call, incl. PCIe copies and sync; "
+                    "includes the Python/ctypes call overhead)"}
+
+
 def ba_bench(core, iters=200):
     """Secondary metric: LM iterations/sec, 8 cams x 1000 points, reference settings
     (cauchy loss, float32 residual cast, 2-point Jacobian incl. the dead focal columns)."""
@@ -121,7 +153,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--frames", type=int, default=FRAMES_PER_GPU, help="frames per GPU per step")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="8x16")
+    ap.add_argument("--frames", type=int, default=0, help="frames per GPU per step (0 = the workload's default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ba", action="store_true")
     args = ap.parse_args()
@@ -137,9 +170,18 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     # ---- synthetic workload: each rank owns its own block of frames (seed differs per rank)
-    C, M, F = CAMS, MARKERS, args.frames
-    rig = synth.ring_rig(C)
-    blobs, counts, _ = synth.make_blob_stream(rig, F, M, seed=1 + rank)
+    wl = WORKLOADS[args.workload]
+    C, M, F = wl["C"], wl["M"], (args.frames or wl["frames"])
+    K_MAX = wl["K_max"]
+    if wl["stress"]:
+        rig = synth.stress_rig(C)
+        blobs, counts, _ = synth.make_stress_stream(rig, F, M, seed=1 + rank)
+        gate = synth.STRESS_GATE_PX
+    else:
+        rig = synth.ring_rig(C)
+        blobs, counts, _ = synth.make_blob_stream(rig, F, M, seed=1 + rank)
+        gate = wl["gate"]
+    default_wl = args.workload == "8x16"
     core = capi.MocapCore(local_rank)
     core.set_cameras(rig["K"], rig["R"], rig["t"])
     stream = torch.cuda.current_stream(dev)
@@ -155,7 +197,7 @@ def main():
     d_ncand = torch.zeros(F, dtype=torch.int32, device=dev)
 
     def hot_path():
-        core.match_triangulate_dev(F, M, d_blobs.data_ptr(), d_counts.data_ptr(), 5.0, K_MAX, G_CAP,
+        core.match_triangulate_dev(F, M, d_blobs.data_ptr(), d_counts.data_ptr(), gate, K_MAX, G_CAP,
                                    d_xyz.data_ptr(), d_err.data_ptr(), d_corr.data_ptr(), d_nout.data_ptr(),
                                    d_status.data_ptr(), d_ncand.data_ptr())
 
@@ -209,18 +251,18 @@ def main():
         v_mean = float((corr[valid] >= 0).sum(axis=1).mean()) if valid.any() else float(C)
         flops = float(n_cand.sum()) * (92.0 * v_mean + 1500.0)
         line = {
-            "metric": "triangulated 3D markers/sec at 8 cams x 16 markers",
+            "metric": "triangulated 3D markers/sec at 8 cams x 16 markers" if default_wl
+                      else f"triangulated 3D markers/sec at {C} cams x {M} markers",
             "value": value, "unit": "markers/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * t_max / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "8 cams x 16 markers, synthetic ring rig f=320 c=160 (camera-params.json), "
-                                   "int-truncated blobs, sigma=0.3px, 5% dropout (BASELINE.json configs[2])",
-                       "frames_per_gpu": F, "cams": C, "markers": M, "K_max": K_MAX, "gate_px": 5.0,
+            "config": {"workload": wl["desc"],
+                       "frames_per_gpu": F, "cams": C, "markers": M, "K_max": K_MAX, "gate_px": gate,
                        "parallelism": f"frame-shard x{world}", "frames_per_s": F * world * args.steps / t_max,
                        "markers_per_frame": total_markers / (F * world),
                        "candidates_per_frame": float(n_cand.mean()), "overflow_frames": int(allv[:, 2].sum())},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": measured_traffic(F),
+                         "frac": ach / HBM_PEAK_GBS, "traffic": measured_traffic(F) if default_wl else None,
                          "traffic_source": "profiles/r01_hbm_traffic.json (rocprofv3 PMC, per frame x frames)",
                          "kernel": "mocap::frame_kernel (MODE 0+1+2 launches of one pass, HIP events)",
                          "kernel_ms": kernel_ms,
@@ -238,7 +280,9 @@ def main():
             # parity gate next to the number: a prefix of the very batch that was timed, vs the oracle
             from oracle import c_oracle
             nchk = 300
-            ref = c_oracle.COracle(rig["K"], rig["R"], rig["t"]).match_triangulate(blobs[:nchk], counts[:nchk], K_max=K_MAX)
+            nchk = nchk if default_wl else min(F, 300 if C * M <= 64 else 4)
+            ref = c_oracle.COracle(rig["K"], rig["R"], rig["t"]).match_triangulate(blobs[:nchk], counts[:nchk],
+                                                                                   gate_px=gate, K_max=K_MAX)
             vv = valid[:nchk]
             xyz = d_xyz[:nchk].cpu().numpy()
             line["parity"] = {
@@ -247,10 +291,13 @@ def main():
                 "corr_bit_exact": bool(np.array_equal(ref["corr"][vv], corr[:nchk][vv])),
                 "xyz_max_rel": float(np.abs(xyz[vv] - ref["xyz"][vv]).max() / np.abs(ref["xyz"][vv]).max()),
             }
-            if not args.no_cpu_baseline:
+            if not args.no_cpu_baseline and default_wl:
                 line["cpu_baseline"] = cpu_baseline(rig, blobs, counts)
                 line["config"]["host_cores"] = os.cpu_count()
-            if not args.no_ba:
+            if default_wl:
+                core.set_stream(0)
+                line["latency"] = frame_latency(core, blobs, counts)
+            if not args.no_ba and default_wl:
                 core.set_stream(0)
                 line["ba"] = ba_bench(core)
         print(json.dumps(line), flush=True)
