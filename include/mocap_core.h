@@ -128,6 +128,29 @@ int mocap_match_triangulate_dev(mocap_ctx* ctx, int64_t n_frames, int M_max, con
                                 double* d_xyz, double* d_err, int16_t* d_corr, int32_t* d_n_out,
                                 int32_t* d_status, int32_t* d_n_cand);
 
+/* ---------------------------------------------------------------- after the path
+ * World-coordinate epilogue of the frame loop (helpers.py:96-103), fused into the frame path's store:
+ * with a matrix set, `xyz` of mocap_match_triangulate* leaves the kernel as
+ *   p' = diag(-1,-1,1) p ;  h = to_world [p'; 1] ;  q = h[:3] / h[3] ;  (q.x, q.z, q.y)
+ * to_world: 16 doubles row-major (Cameras.to_world_coords_matrix), copied; NULL switches it off. */
+int mocap_set_world_transform(mocap_ctx* ctx, const double* to_world);
+
+/* locate_objects (helpers.py:424-480): the 3-LED drone patterns among each frame's points.
+ *   xyz [F][K_max][3], err [F][K_max], n_pts [F]   the frame path's outputs (world coordinates)
+ *   pos [F][O_max][3]   midpoint of the 0.15 m pair            ("pos")
+ *   heading [F][O_max]  -atan2 of the pair direction, folded into [-pi/2, pi/2]   ("heading")
+ *   oerr [F][O_max]     mean error of the three points          ("error")
+ *   drone [F][O_max]    0 / 1 by the side the lead point is on  ("droneIndex")
+ *   lead [F][O_max]     (may be NULL) index of the lead point
+ *   n_obj [F]           objects found (entries beyond O_max are dropped, the count is not) */
+int mocap_locate_objects(mocap_ctx* ctx, int64_t n_frames, int K_max, const double* xyz, const double* err,
+                         const int32_t* n_pts, int O_max, double* pos, double* heading, double* oerr,
+                         int32_t* drone, int32_t* lead, int32_t* n_obj);
+int mocap_locate_objects_dev(mocap_ctx* ctx, int64_t n_frames, int K_max, const double* d_xyz,
+                             const double* d_err, const int32_t* d_n_pts, int O_max, double* d_pos,
+                             double* d_heading, double* d_oerr, int32_t* d_drone, int32_t* d_lead,
+                             int32_t* d_n_obj);
+
 /* ---------------------------------------------------------------- bundle adjustment
  * Parameter vector as the reference (helpers.py:278-285):
  *   x = [f0, (f_i, rotvec_i[3], t_i[3]) for i = 1..C-1],  n = 1 + 7 (C-1); camera 0 = (I, 0).

@@ -94,6 +94,7 @@ extern "C" void mocap_destroy(mocap_ctx* ctx) {
   ctx->tables.release();
   for (auto& b : ctx->scratch) b.release();
   ctx->frame_ws.release();
+  ctx->world.release();
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
 }
@@ -264,6 +265,22 @@ extern "C" int mocap_set_cameras(mocap_ctx* ctx, int C, const double* K, const d
   return MOCAP_OK;
 }
 
+extern "C" int mocap_set_world_transform(mocap_ctx* ctx, const double* to_world) {
+  if (!ctx) return MOCAP_E_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (!to_world) {
+    ctx->world_on = false;
+    return MOCAP_OK;
+  }
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // a queued frame batch may still read the old matrix
+  if (ctx->world.reserve(16 * sizeof(double))) return ctx->fail(MOCAP_E_HIP, "hipMalloc(world matrix) failed");
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->world.ptr, to_world, 16 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->world_on = true;
+  return MOCAP_OK;
+}
+
 extern "C" int mocap_get_fundamental(mocap_ctx* ctx, double* F) {
   if (!ctx || !F) return MOCAP_E_ARG;
   std::lock_guard<std::mutex> lk(ctx->mu);
@@ -347,6 +364,7 @@ static int match_dev_locked(mocap_ctx* ctx, int64_t n_frames, int M_max, const f
   a.n_out = d_n_out;
   a.status = d_status;
   a.n_cand = d_n_cand;
+  a.world = ctx->world_on ? (const double*)ctx->world.ptr : nullptr;
   int T = ctx->frame_threads;
   const int hit_cap = ctx->hit_cap < 1 ? 1 : (ctx->hit_cap > M_max ? M_max : ctx->hit_cap);
   bool wide = ctx->force_wide != 0;
@@ -471,6 +489,85 @@ extern "C" int mocap_match_triangulate(mocap_ctx* ctx, int64_t n_frames, int M_m
   HIP_TRY(ctx, hipMemcpyAsync(n_out, d_n_out, b_i, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(status, d_status, b_i, hipMemcpyDeviceToHost, ctx->stream));
   if (n_cand) HIP_TRY(ctx, hipMemcpyAsync(n_cand, d_n_cand, b_i, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return MOCAP_OK;
+}
+
+// ------------------------------------------------------------------ object locator
+static int locate_dev_locked(mocap_ctx* ctx, int64_t n_frames, int K_max, const double* d_xyz, const double* d_err,
+                             const int32_t* d_n_pts, int O_max, double* d_pos, double* d_heading, double* d_oerr,
+                             int32_t* d_drone, int32_t* d_lead, int32_t* d_n_obj) {
+  if (n_frames < 0 || K_max < 1 || O_max < 1) return ctx->fail(MOCAP_E_ARG, "mocap_locate_objects: bad size argument");
+  if (K_max > 256) return ctx->fail(MOCAP_E_LIMIT, "mocap_locate_objects: K_max=%d exceeds 256", K_max);
+  if (n_frames == 0) return MOCAP_OK;
+  if (!d_xyz || !d_err || !d_n_pts || !d_pos || !d_heading || !d_oerr || !d_drone || !d_n_obj)
+    return ctx->fail(MOCAP_E_ARG, "mocap_locate_objects: null buffer");
+  LocateArgs a;
+  a.n_frames = n_frames;
+  a.K_max = K_max;
+  a.O_max = O_max;
+  a.xyz = d_xyz;
+  a.err = d_err;
+  a.n_pts = d_n_pts;
+  a.obj_pos = d_pos;
+  a.obj_heading = d_heading;
+  a.obj_err = d_oerr;
+  a.obj_drone = d_drone;
+  a.obj_lead = d_lead;
+  a.n_obj = d_n_obj;
+  HIP_TRY(ctx, launch_locate_objects(a, ctx->stream));
+  return MOCAP_OK;
+}
+
+extern "C" int mocap_locate_objects_dev(mocap_ctx* ctx, int64_t n_frames, int K_max, const double* d_xyz,
+                                        const double* d_err, const int32_t* d_n_pts, int O_max, double* d_pos,
+                                        double* d_heading, double* d_oerr, int32_t* d_drone, int32_t* d_lead,
+                                        int32_t* d_n_obj) {
+  if (!ctx) return MOCAP_E_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  return locate_dev_locked(ctx, n_frames, K_max, d_xyz, d_err, d_n_pts, O_max, d_pos, d_heading, d_oerr, d_drone,
+                           d_lead, d_n_obj);
+}
+
+extern "C" int mocap_locate_objects(mocap_ctx* ctx, int64_t n_frames, int K_max, const double* xyz, const double* err,
+                                    const int32_t* n_pts, int O_max, double* pos, double* heading, double* oerr,
+                                    int32_t* drone, int32_t* lead, int32_t* n_obj) {
+  if (!ctx) return MOCAP_E_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (n_frames < 0 || K_max < 1 || O_max < 1) return ctx->fail(MOCAP_E_ARG, "mocap_locate_objects: bad size argument");
+  if (n_frames == 0) return MOCAP_OK;
+  if (!xyz || !err || !n_pts || !pos || !heading || !oerr || !drone || !n_obj)
+    return ctx->fail(MOCAP_E_ARG, "mocap_locate_objects: null buffer");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const size_t F = (size_t)n_frames;
+  auto al = [](size_t x) { return (x + 255) / 256 * 256; };
+  const size_t b_xyz = al(sizeof(double) * F * K_max * 3), b_err = al(sizeof(double) * F * K_max),
+               b_n = al(sizeof(int32_t) * F), b_pos = al(sizeof(double) * F * O_max * 3),
+               b_o = al(sizeof(double) * F * O_max), b_i = al(sizeof(int32_t) * F * O_max);
+  DevBuf& s = ctx->scratch[0];
+  if (s.reserve(b_xyz + b_err + 2 * b_n + b_pos + 2 * b_o + 2 * b_i)) return ctx->fail(MOCAP_E_HIP, "hipMalloc failed");
+  char* p = (char*)s.ptr;
+  double* d_xyz = (double*)p;        p += b_xyz;
+  double* d_err = (double*)p;        p += b_err;
+  double* d_pos = (double*)p;        p += b_pos;
+  double* d_head = (double*)p;       p += b_o;
+  double* d_oerr = (double*)p;       p += b_o;
+  int32_t* d_n = (int32_t*)p;        p += b_n;
+  int32_t* d_nobj = (int32_t*)p;     p += b_n;
+  int32_t* d_drone = (int32_t*)p;    p += b_i;
+  int32_t* d_lead = (int32_t*)p;
+  HIP_TRY(ctx, hipMemcpyAsync(d_xyz, xyz, sizeof(double) * F * K_max * 3, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(d_err, err, sizeof(double) * F * K_max, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(d_n, n_pts, sizeof(int32_t) * F, hipMemcpyHostToDevice, ctx->stream));
+  int rc = locate_dev_locked(ctx, n_frames, K_max, d_xyz, d_err, d_n, O_max, d_pos, d_head, d_oerr, d_drone, d_lead, d_nobj);
+  if (rc) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(pos, d_pos, sizeof(double) * F * O_max * 3, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(heading, d_head, sizeof(double) * F * O_max, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(oerr, d_oerr, sizeof(double) * F * O_max, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(drone, d_drone, sizeof(int32_t) * F * O_max, hipMemcpyDeviceToHost, ctx->stream));
+  if (lead) HIP_TRY(ctx, hipMemcpyAsync(lead, d_lead, sizeof(int32_t) * F * O_max, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(n_obj, d_nobj, sizeof(int32_t) * F, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return MOCAP_OK;
 }

@@ -32,6 +32,8 @@ struct mocap_ctx {
   DevBuf tables;            // Pq | RT | K4 | F | K9
   const double* d_K9 = nullptr;
   mocap::CamView cv{};
+  DevBuf world;             // 16 doubles: the to-world matrix of the fused epilogue
+  bool world_on = false;
   DevBuf frame_ws;          // wide-frame workspace: [workgroup][hit lists | group columns | ...]
   DevBuf scratch[4];        // [0] host-API staging, [1..3] bundle adjustment workspace
 

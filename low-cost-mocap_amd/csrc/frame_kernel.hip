@@ -616,9 +616,23 @@ struct FrameState {
   // ---------------------------------------------------------------- phase E
   __device__ void write_point(int64_t frame, int r, double e, uint32_t gl, const double (&X)[3]) {
     const size_t o = (size_t)frame * R + outslot[r];
-    p.xyz[o * 3 + 0] = X[0];
-    p.xyz[o * 3 + 1] = X[1];
-    p.xyz[o * 3 + 2] = X[2];
+    if (p.world) {
+      // world-coordinate epilogue of the frame loop (helpers.py:96-103), fused into the store:
+      // p' = diag(-1,-1,1) p ; h = W [p'; 1] ; q = h[:3] / h[3] ; swap y <-> z
+      ctab_t W = as_ctab(p.world);
+      const double x = -X[0], y = -X[1], z = X[2];
+      const double h0 = W[0] * x + W[1] * y + W[2] * z + W[3];
+      const double h1 = W[4] * x + W[5] * y + W[6] * z + W[7];
+      const double h2 = W[8] * x + W[9] * y + W[10] * z + W[11];
+      const double h3 = W[12] * x + W[13] * y + W[14] * z + W[15];
+      p.xyz[o * 3 + 0] = h0 / h3;
+      p.xyz[o * 3 + 1] = h2 / h3;
+      p.xyz[o * 3 + 2] = h1 / h3;
+    } else {
+      p.xyz[o * 3 + 0] = X[0];
+      p.xyz[o * 3 + 1] = X[1];
+      p.xyz[o * 3 + 2] = X[2];
+    }
     p.err[o] = e;
     uint32_t rem = gl;  // decode the winning group
     const int rc = root_cam[r];

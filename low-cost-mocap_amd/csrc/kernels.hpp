@@ -43,6 +43,7 @@ struct FrameArgs {
   int32_t* n_out;         // [F]
   int32_t* status;        // [F]
   int32_t* n_cand;        // [F] or null
+  const double* world;    // null, or the 4x4 to-world matrix: xyz leaves the kernel in world coordinates
   // wide frames (state does not fit LDS): per-workgroup workspace in HBM, hit-list cap per (root, camera)
   unsigned char* ws;
   size_t ws_stride;
@@ -54,6 +55,22 @@ constexpr int kWideThreads = 1024;  // workgroup size of the wide-frame variant 
 size_t frame_lds_bytes(int C, int M, int R, int T, int H, bool wide);
 size_t frame_ws_bytes(int C, int M, int R, int T, int H, bool wide);
 hipError_t launch_frame_kernel(const FrameArgs& a, int mode, int threads, int grid, hipStream_t stream);
+
+// object (drone) locator over the frame path's output (reference helpers.py:424-480), csrc/post_kernels.hip
+struct LocateArgs {
+  int64_t n_frames;
+  int K_max, O_max;
+  const double* xyz;     // [F][K_max][3] (world coordinates)
+  const double* err;     // [F][K_max]
+  const int32_t* n_pts;  // [F]
+  double* obj_pos;       // [F][O_max][3]
+  double* obj_heading;   // [F][O_max]
+  double* obj_err;       // [F][O_max]
+  int32_t* obj_drone;    // [F][O_max]
+  int32_t* obj_lead;     // [F][O_max] index of the point the pattern was found from, or null
+  int32_t* n_obj;        // [F]
+};
+hipError_t launch_locate_objects(const LocateArgs& a, hipStream_t stream);
 
 // explicit-correspondence triangulation, optionally batched over P camera sets (bundle adjustment)
 struct TriArgs {

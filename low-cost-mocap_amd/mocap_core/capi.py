@@ -40,6 +40,9 @@ SIGNATURES = {
     "mocap_triangulate_dev": (_i32, [_vp, _i64, _vp, _vp, _vp]),
     "mocap_match_triangulate": (_i32, [_vp, _i64, _i32, _vp, _vp, _dbl, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mocap_match_triangulate_dev": (_i32, [_vp, _i64, _i32, _vp, _vp, _dbl, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mocap_set_world_transform": (_i32, [_vp, _vp]),
+    "mocap_locate_objects": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mocap_locate_objects_dev": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mocap_ba_residuals": (_i32, [_vp, _i32, _vp, _i64, _vp, _vp]),
     "mocap_ba_normal_eq": (_i32, [_vp, _vp, _i64, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "mocap_ba_solve": (_i32, [_vp, _vp, _i64, _vp, _dbl, _dbl, _dbl, _i32, _i32, _i32, _vp]),
@@ -198,6 +201,29 @@ class MocapCore:
                 for key in ("n_out", "status", "n_cand"):
                     res[key][f] = big[key][j]
         return res
+
+    # ------------------------------------------------------------------ after the path
+    def set_world_transform(self, to_world):
+        """4x4 to-world matrix (Cameras.to_world_coords_matrix) -> frame-path points leave the kernel in
+        world coordinates (helpers.py:96-103); None switches the epilogue off."""
+        if to_world is None:
+            self._check(self.lib.mocap_set_world_transform(self._h, None))
+        else:
+            W = np.ascontiguousarray(to_world, dtype=np.float64).reshape(16)
+            self._check(self.lib.mocap_set_world_transform(self._h, _p(W)))
+
+    def locate_objects(self, xyz, err, n_pts, O_max=8):
+        xyz = np.ascontiguousarray(xyz, dtype=np.float64)
+        F, K_max, _ = xyz.shape
+        err = np.ascontiguousarray(err, dtype=np.float64).reshape(F, K_max)
+        n_pts = np.ascontiguousarray(n_pts, dtype=np.int32).reshape(F)
+        out = {"pos": np.full((F, O_max, 3), np.nan), "heading": np.full((F, O_max), np.nan),
+               "error": np.full((F, O_max), np.nan), "droneIndex": np.full((F, O_max), -1, dtype=np.int32),
+               "lead": np.full((F, O_max), -1, dtype=np.int32), "n_obj": np.zeros(F, dtype=np.int32)}
+        self._check(self.lib.mocap_locate_objects(self._h, F, K_max, _p(xyz), _p(err), _p(n_pts), int(O_max),
+                                                  _p(out["pos"]), _p(out["heading"]), _p(out["error"]),
+                                                  _p(out["droneIndex"]), _p(out["lead"]), _p(out["n_obj"])))
+        return out
 
     # ------------------------------------------------------------------ device-pointer entry points
     def match_triangulate_dev(self, n_frames, M_max, d_blobs, d_counts, gate_px, K_max, G_cap, d_xyz, d_err,

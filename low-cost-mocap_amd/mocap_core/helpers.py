@@ -182,6 +182,28 @@ def find_point_correspondance_and_object_points_batch(blobs, counts, camera_pose
         return core.match_triangulate_auto(blobs, counts, gate_px=gate_px, K_max=K_max)
 
 
+# ----------------------------------------------------------------------------- after the path
+def set_to_world_coords_matrix(to_world_coords_matrix):
+    """Cameras.to_world_coords_matrix (helpers.py:40,100): with a matrix set, the frame path returns
+    world coordinates -- the loop at helpers.py:96-103 runs fused in the kernel's store.  None = off
+    (camera-0 coordinates, exactly what find_point_correspondance_and_object_points returns upstream)."""
+    with _state["lock"]:
+        get_core().set_world_transform(to_world_coords_matrix)
+
+
+def locate_objects(object_points, errors):
+    """helpers.py:424-480: list of {"pos", "heading", "error", "droneIndex"} for one frame."""
+    P = np.asarray(object_points, dtype=np.float64).reshape(-1, 3)
+    if P.shape[0] == 0:
+        return []
+    E = np.asarray(errors, dtype=np.float64).reshape(-1)
+    with _state["lock"]:
+        res = get_core().locate_objects(P[None], E[None], [P.shape[0]], O_max=max(1, P.shape[0]))
+    return [{"pos": res["pos"][0, j].copy(), "heading": float(res["heading"][0, j]),
+             "error": float(res["error"][0, j]), "droneIndex": int(res["droneIndex"][0, j])}
+            for j in range(int(res["n_obj"][0]))]
+
+
 # ----------------------------------------------------------------------------- bundle adjustment
 def _ba_x0(camera_poses):
     """helpers.py:278-285 (including its focal-length indexing: entry i+1 takes camera i's focal)."""

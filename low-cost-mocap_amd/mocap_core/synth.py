@@ -200,3 +200,44 @@ def obs_to_reference_array(obs, as_int=False):
                 out[n, c, 0] = int(obs[n, c, 0]) if as_int else float(obs[n, c, 0])
                 out[n, c, 1] = int(obs[n, c, 1]) if as_int else float(obs[n, c, 1])
     return out
+
+
+# Default to-world matrix of the reference UI (computer_code/src/App.tsx:45).  Numeric fixture only.
+APP_TSX_TO_WORLD = [[0.9941338485260931, 0.0986512964608827, -0.04433748889242502, 0.9938296704767513],
+                    [-0.0986512964608827, 0.659022672138982, -0.7456252673517598, 2.593331619023365],
+                    [0.04433748889242498, -0.7456252673517594, -0.6648888236128887, 2.9576262456228286],
+                    [0, 0, 0, 1]]
+
+
+def make_object_frames(n_frames, k_max, seed=0, jitter=0.004):
+    """World-coordinate point sets for the object locator (reference helpers.py:424-480): per frame
+    0-2 drone LED triangles (0.095 / 0.095 / 0.15 m, jittered, random pose) among random clutter.
+    Returns xyz f64 [F][k_max][3] (NaN padded), err f64 [F][k_max], n_pts i32 [F]."""
+    rng = np.random.default_rng(seed)
+    xyz = np.full((n_frames, k_max, 3), np.nan)
+    err = np.full((n_frames, k_max), np.nan)
+    n_pts = np.zeros(n_frames, dtype=np.int32)
+    h = np.sqrt(0.095 ** 2 - 0.075 ** 2)
+    for f in range(n_frames):
+        pts = []
+        for _ in range(int(rng.integers(0, 3))):
+            c = rng.uniform(-1, 1, 3)
+            ang = rng.uniform(0, 2 * np.pi)
+            tilt = rng.normal(0, 0.2)
+            u = np.array([np.cos(ang), np.sin(ang), tilt])
+            u /= np.linalg.norm(u)
+            w = np.cross(u, [0, 0, 1.0])
+            w /= np.linalg.norm(w)
+            side = 1.0 if rng.random() < 0.5 else -1.0
+            tri = [c + side * h * w, c + 0.075 * u, c - 0.075 * u]
+            pts += [p + rng.normal(0, jitter, 3) for p in tri]
+        n_clutter = int(rng.integers(0, max(1, k_max - len(pts) + 1)))
+        pts += [rng.uniform(-1, 1, 3) for _ in range(n_clutter)]
+        pts = np.array(pts[:k_max]).reshape(-1, 3)
+        order = rng.permutation(len(pts))
+        pts = pts[order]
+        n = len(pts)
+        n_pts[f] = n
+        xyz[f, :n] = pts
+        err[f, :n] = rng.uniform(0.05, 2.0, n)
+    return xyz, err, n_pts

@@ -205,6 +205,57 @@ def golden_ba(name, C, n_points, seed, run_solver):
     print(name, "points", n_points, "m", res32.shape[1])
 
 
+def reference_world_epilogue(object_points, to_world):
+    """Runs the reference's OWN lines computer_code/api/helpers.py:97-103 (inline in
+    Cameras._camera_read, not callable on their own): the loop is read from the file and exec'd."""
+    path = os.path.join(ref_harness.REFERENCE_API, "helpers.py")
+    with open(path) as fh:
+        lines = fh.read().split("\n")[96:103]
+    assert lines[0].strip() == "for i, object_point in enumerate(object_points):", lines[0]
+    assert "object_points[i] = new_object_point" in lines[-1], lines[-1]
+    import textwrap
+    import types
+    env = {"np": np, "object_points": np.array(object_points, dtype=np.float64).copy(),
+           "self": types.SimpleNamespace(to_world_coords_matrix=to_world)}
+    exec(textwrap.dedent("\n".join(lines)), env)
+    return env["object_points"]
+
+
+def golden_post(name, n_frames, k_max, seed):
+    """World-coordinate epilogue (helpers.py:96-103) and locate_objects (helpers.py:424-480)."""
+    H = ref_harness.load_reference(4)
+    W = synth.APP_TSX_TO_WORLD
+    Winv = np.linalg.inv(np.array(W))
+    xyz_w, err, n_pts = synth.make_object_frames(n_frames, k_max, seed=seed)
+    # camera-0 coordinates whose epilogue image is (about) xyz_w: undo swap, W and the sign flip
+    cam = np.full_like(xyz_w, np.nan)
+    ref_world = np.full_like(xyz_w, np.nan)
+    o_max = 8
+    ref_pos = np.full((n_frames, o_max, 3), np.nan)
+    ref_heading = np.full((n_frames, o_max), np.nan)
+    ref_error = np.full((n_frames, o_max), np.nan)
+    ref_drone = np.full((n_frames, o_max), -1, dtype=np.int32)
+    ref_nobj = np.zeros(n_frames, dtype=np.int32)
+    for f in range(n_frames):
+        n = int(n_pts[f])
+        q = xyz_w[f, :n][:, [0, 2, 1]]
+        h = np.c_[q, np.ones(n)] @ Winv.T
+        cam[f, :n] = (h[:, :3] / h[:, 3:4]) * np.array([-1, -1, 1.0])
+        if n:
+            ref_world[f, :n] = reference_world_epilogue(cam[f, :n], W)
+        objs = H.locate_objects(ref_world[f, :n].copy(), err[f, :n].copy())
+        ref_nobj[f] = len(objs)
+        for j, o in enumerate(objs[:o_max]):
+            ref_pos[f, j] = o["pos"]
+            ref_heading[f, j] = o["heading"]
+            ref_error[f, j] = o["error"]
+            ref_drone[f, j] = o["droneIndex"]
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), to_world=np.array(W, dtype=np.float64), cam_xyz=cam,
+                        err=err, n_pts=n_pts, ref_world=ref_world, ref_pos=ref_pos, ref_heading=ref_heading,
+                        ref_error=ref_error, ref_drone=ref_drone, ref_nobj=ref_nobj)
+    print(name, "frames", n_frames, "objects", int(ref_nobj.sum()))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     # BASELINE.json configs[0..2] shapes
@@ -229,6 +280,8 @@ def main():
     # bundle adjustment
     golden_ba("ba_c4_n40", 4, 40, seed=8, run_solver=False)
     golden_ba("ba_c3_n24", 3, 24, seed=9, run_solver=True)
+    # the rows right after the path: world-coordinate epilogue + object locator
+    golden_post("post_world_locate", 300, 24, seed=10)
 
 
 if __name__ == "__main__":

@@ -238,6 +238,64 @@ def find_point_correspondance_and_object_points(blobs, counts, Ks, R, t, gate_px
     }
 
 
+# ----------------------------------------------------------------------------- after the path
+def world_epilogue(object_points, to_world_coords_matrix):
+    """helpers.py:96-103 (inline in Cameras._camera_read): camera-0 coordinates -> world."""
+    out = np.array(object_points, dtype=np.float64).reshape(-1, 3).copy()
+    for i, object_point in enumerate(out):
+        new_object_point = np.array([[-1, 0, 0], [0, -1, 0], [0, 0, 1]]) @ object_point
+        new_object_point = np.concatenate((new_object_point, [1]))
+        new_object_point = np.array(to_world_coords_matrix) @ new_object_point
+        new_object_point = new_object_point[:3] / new_object_point[3]
+        new_object_point[1], new_object_point[2] = new_object_point[2], new_object_point[1]
+        out[i] = new_object_point
+    return out
+
+
+def locate_objects(object_points, errors):
+    """helpers.py:424-480 restated with explicit loops: 3-LED patterns (two points 0.095 m from a lead
+    point and 0.15 m from each other, +-0.025), first valid pair in row-major order wins
+    (cartesian_product, helpers.py:532-533); only the lead point is checked against
+    `already_matched_points` (helpers.py:437).  Returns a list of dicts like the reference plus "lead"."""
+    P = np.asarray(object_points, dtype=np.float64).reshape(-1, 3)
+    E = np.asarray(errors, dtype=np.float64).reshape(-1)
+    K = P.shape[0]
+    dist1, dist2 = 0.095, 0.15
+
+    def dist(i, j):
+        d = P[i] - P[j]
+        return np.sqrt((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2])
+
+    matched, objects = set(), []
+    for i in range(K):
+        if i in matched:
+            continue
+        matches = [j for j in range(K) if np.abs(dist(i, j) - dist1) < 0.025]
+        if len(matches) < 2:
+            continue
+        found = False
+        for a in matches:
+            for b in matches:
+                if np.abs(dist(a, b) - dist2) > 0.025:
+                    continue
+                matched.update((i, a, b))
+                location = (P[a] + P[b]) / 2
+                error = ((E[i] + E[a]) + E[b]) / 3
+                hv = P[a] - P[b]
+                hv = hv / np.sqrt((hv[0] * hv[0] + hv[1] * hv[1]) + hv[2] * hv[2])
+                heading = np.arctan2(hv[1], hv[0])
+                heading = heading - np.pi if heading > np.pi / 2 else heading
+                heading = heading + np.pi if heading < -np.pi / 2 else heading
+                drone_index = 0 if (P[i] - location)[1] > 0 else 1
+                objects.append({"pos": location, "heading": -heading, "error": error,
+                                "droneIndex": drone_index, "lead": i})
+                found = True
+                break
+            if found:
+                break
+    return objects
+
+
 # ----------------------------------------------------------------------------- bundle adjustment
 def rotvec_to_matrix(rv):
     """scipy.spatial.transform.Rotation.from_rotvec(rv).as_matrix() (helpers.py:258), restated:

@@ -1,0 +1,76 @@
+"""GPU parity of the rows right after the hot path: the world-coordinate
+epilogue fused into the frame kernel (reference helpers.py:96-103) and the object locator
+(helpers.py:424-480), against the reference's own outputs (tests/golden/post_world_locate.npz)
+and the oracle restatement on larger seeded sets."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def test_locate_objects_vs_reference_golden(core):
+    g = load_golden("post_world_locate")
+    res = core.locate_objects(g["ref_world"], g["err"], g["n_pts"], O_max=8)
+    assert np.array_equal(res["n_obj"], g["ref_nobj"])
+    have = np.arange(8)[None, :] < g["ref_nobj"][:, None]
+    assert np.array_equal(res["droneIndex"][have], g["ref_drone"][have])
+    np.testing.assert_allclose(res["pos"][have], g["ref_pos"][have], rtol=1e-14, atol=0)
+    np.testing.assert_allclose(res["error"][have], g["ref_error"][have], rtol=1e-14, atol=0)
+    np.testing.assert_allclose(res["heading"][have], g["ref_heading"][have], rtol=0, atol=1e-12)
+
+
+def test_locate_objects_vs_oracle_large(core):
+    from mocap_core import synth
+    from oracle import mocap_oracle as mo
+    xyz, err, n_pts = synth.make_object_frames(1500, 32, seed=77)
+    res = core.locate_objects(xyz, err, n_pts, O_max=10)
+    for f in range(xyz.shape[0]):
+        n = int(n_pts[f])
+        objs = mo.locate_objects(xyz[f, :n], err[f, :n])
+        assert res["n_obj"][f] == len(objs), f
+        for j, o in enumerate(objs):
+            assert res["lead"][f, j] == o["lead"] and res["droneIndex"][f, j] == o["droneIndex"]
+            np.testing.assert_allclose(res["pos"][f, j], o["pos"], rtol=1e-14, atol=0)
+            assert abs(res["heading"][f, j] - o["heading"]) < 1e-12
+    # the mirror of the reference function (one frame, list of dicts)
+    from mocap_core import helpers
+    helpers.set_core(core)
+    n = int(n_pts[3])
+    got = helpers.locate_objects(xyz[3, :n], err[3, :n])
+    want = mo.locate_objects(xyz[3, :n], err[3, :n])
+    assert len(got) == len(want)
+    for a, b in zip(got, want):
+        assert a["droneIndex"] == b["droneIndex"] and abs(a["heading"] - b["heading"]) < 1e-12
+
+
+def test_world_epilogue_fused_in_frame_kernel(core):
+    """With a to-world matrix set, the frame path's points are the reference loop helpers.py:96-103
+    applied to the points it returns without one (1e-12: the 4x4 product is a BLAS call upstream)."""
+    from mocap_core import synth
+    from oracle import mocap_oracle as mo
+    g = load_golden("post_world_locate")
+    rig = synth.ring_rig(8)
+    blobs, counts, _ = synth.make_blob_stream(rig, 400, 16, seed=71)
+    core.set_cameras(rig["K"], rig["R"], rig["t"])
+    base = core.match_triangulate(blobs, counts, K_max=48)
+    try:
+        core.set_world_transform(g["to_world"])
+        res = core.match_triangulate(blobs, counts, K_max=48)
+    finally:
+        core.set_world_transform(None)
+    assert np.array_equal(res["n_out"], base["n_out"]) and np.array_equal(res["err"], base["err"], equal_nan=True)
+    valid = np.arange(48)[None, :] < base["n_out"][:, None]
+    assert np.array_equal(res["corr"][valid], base["corr"][valid])
+    want = mo.world_epilogue(base["xyz"][valid], g["to_world"])
+    np.testing.assert_allclose(res["xyz"][valid], want, rtol=1e-12, atol=1e-12)
+    # and against the reference's own epilogue outputs
+    F = g["cam_xyz"].shape[0]
+    for f in range(0, F, 17):
+        n = int(g["n_pts"][f])
+        if n:
+            np.testing.assert_allclose(mo.world_epilogue(g["cam_xyz"][f, :n], g["to_world"]), g["ref_world"][f, :n],
+                                       rtol=0, atol=0)
+    again = core.match_triangulate(blobs, counts, K_max=48)      # switched off again: camera-0 coordinates
+    assert np.array_equal(again["xyz"][valid], base["xyz"][valid])

@@ -92,3 +92,20 @@ def test_f32_rounding_switch_changes_little():
     assert np.array_equal(a["n_out"], b["n_out"])
     m = np.isfinite(a["err"]) & np.isfinite(b["err"])
     np.testing.assert_allclose(a["err"][m], b["err"][m], rtol=1e-2, atol=1e-5)
+
+
+def test_post_rows_oracle_vs_reference_golden():
+    """World-coordinate epilogue (helpers.py:96-103, run verbatim from the reference file by
+    oracle/make_golden.py) and locate_objects (helpers.py:424-480) against the restatements."""
+    from oracle import mocap_oracle as mo
+    g = load_golden("post_world_locate")
+    for f in range(g["cam_xyz"].shape[0]):
+        n = int(g["n_pts"][f])
+        if n:
+            assert np.array_equal(mo.world_epilogue(g["cam_xyz"][f, :n], g["to_world"]), g["ref_world"][f, :n])
+        objs = mo.locate_objects(g["ref_world"][f, :n], g["err"][f, :n])
+        assert len(objs) == g["ref_nobj"][f]
+        for j, o in enumerate(objs):
+            assert np.array_equal(o["pos"], g["ref_pos"][f, j]) and o["droneIndex"] == g["ref_drone"][f, j]
+            assert abs(o["heading"] - g["ref_heading"][f, j]) < 1e-12
+            assert abs(o["error"] - g["ref_error"][f, j]) <= 1e-15
