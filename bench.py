@@ -132,7 +132,8 @@ def ba_bench(core, iters=200):
     core.set_cameras(rig["K"], init["R"], init["t"])
     helpers.set_camera_params([{"intrinsic_matrix": k.tolist()} for k in rig["K"]])
     x0 = helpers._ba_x0([{"R": init["R"][i], "t": init["t"][i]} for i in range(CAMS)])
-    core.ba_solve(x0, obs, ftol=0.0, xtol=0.0, gtol=0.0, max_iter=3)            # warm-up
+    core.ba_solve(x0, obs, ftol=0.0, xtol=0.0, gtol=0.0, max_iter=40)           # warm-up (a one-off ~60 ms
+    # runtime stall lands in the first few dozen launches of a process; measured with MOCAP_BA_PROFILE=1)
     # tolerances 0: the loop runs until its evaluation budget is spent.  One iteration = one
     # accepted-or-rejected trust-region step including its Jacobian (n+1 residual evaluations of all
     # points, robust scaling, the MFMA J^T J / J^T f, the n x n subproblem and the trial evaluation).

@@ -95,6 +95,8 @@ extern "C" void mocap_destroy(mocap_ctx* ctx) {
   for (auto& b : ctx->scratch) b.release();
   ctx->frame_ws.release();
   ctx->world.release();
+  if (ctx->ba_pin) (void)hipHostFree(ctx->ba_pin);
+  if (ctx->ba_event) (void)hipEventDestroy(ctx->ba_event);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
 }

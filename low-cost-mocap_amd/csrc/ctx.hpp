@@ -32,6 +32,11 @@ struct mocap_ctx {
   DevBuf tables;            // Pq | RT | K4 | F | K9
   const double* d_K9 = nullptr;
   mocap::CamView cv{};
+  // bundle adjustment: pinned host staging (async copies that really are async) and the event the
+  // LM loop spin-waits on (hipStreamSynchronize may sleep on an interrupt: +50..400 us per wait)
+  void* ba_pin = nullptr;
+  size_t ba_pin_cap = 0;
+  hipEvent_t ba_event = nullptr;
   DevBuf world;             // 16 doubles: the to-world matrix of the fused epilogue
   bool world_on = false;
   DevBuf frame_ws;          // wide-frame workspace: [workgroup][hit lists | group columns | ...]
