@@ -121,6 +121,26 @@ def frame_latency(core, blobs, counts, n=300):
                     "includes the Python/ctypes call overhead)"}
 
 
+def ba_bench_16k(core, iters=60):
+    """BASELINE.json configs[3]: 8 cams, 2000 frames x 8 markers = 16 000 calibration points."""
+    from mocap_core import helpers
+    rig = synth.ring_rig(CAMS)
+    rng = np.random.default_rng(9)
+    obs, _ = synth.make_ba_observations(rig, 16000, seed=9)
+    init = synth.perturb_rig(rig, rng)
+    core.set_cameras(rig["K"], init["R"], init["t"])
+    helpers.set_camera_params([{"intrinsic_matrix": k.tolist()} for k in rig["K"]])
+    x0 = helpers._ba_x0([{"R": init["R"][i], "t": init["t"][i]} for i in range(CAMS)])
+    core.ba_solve(x0, obs, ftol=0.0, xtol=0.0, gtol=0.0, max_iter=10)
+    t0 = time.perf_counter()
+    _, info = core.ba_solve(x0, obs, ftol=0.0, xtol=0.0, gtol=0.0, max_iter=iters)
+    dt = time.perf_counter() - t0
+    _, ref = core.ba_solve(x0, obs, ftol=1e-2)
+    return {"points": int(info["m"]), "value": info["iterations"] / dt, "ms_per_iter": 1e3 * dt / max(info["iterations"], 1),
+            "reference_rule_run": {"iterations": ref["iterations"], "status": ref["status"], "cost0": ref["cost0"],
+                                   "cost": ref["cost"], "elapsed_ms": ref["elapsed_ms"]}}
+
+
 def ba_bench(core, iters=200):
     """Secondary metric: LM iterations/sec, 8 cams x 1000 points, reference settings
     (cauchy loss, float32 residual cast, 2-point Jacobian incl. the dead focal columns)."""
@@ -132,17 +152,23 @@ def ba_bench(core, iters=200):
     core.set_cameras(rig["K"], init["R"], init["t"])
     helpers.set_camera_params([{"intrinsic_matrix": k.tolist()} for k in rig["K"]])
     x0 = helpers._ba_x0([{"R": init["R"][i], "t": init["t"][i]} for i in range(CAMS)])
-    core.ba_solve(x0, obs, ftol=0.0, xtol=0.0, gtol=0.0, max_iter=40)           # warm-up (a one-off ~60 ms
-    # runtime stall lands in the first few dozen launches of a process; measured with MOCAP_BA_PROFILE=1)
+    core.ba_solve(x0, obs, ftol=0.0, xtol=0.0, gtol=0.0, max_iter=40)           # warm-up
     # tolerances 0: the loop runs until its evaluation budget is spent.  One iteration = one
     # accepted-or-rejected trust-region step including its Jacobian (n+1 residual evaluations of all
     # points, robust scaling, the MFMA J^T J / J^T f, the n x n subproblem and the trial evaluation).
-    t0 = time.perf_counter()
-    _, info = core.ba_solve(x0, obs, ftol=0.0, xtol=0.0, gtol=0.0, max_iter=iters)
-    dt = time.perf_counter() - t0
+    # Median of 5 solves: a process sees a one-off 60-80 ms runtime stall at an unpredictable moment
+    # (found with MOCAP_BA_PROFILE=1: a single linearisation of ~190 taking 60 ms instead of 0.09).
+    runs = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        _, info = core.ba_solve(x0, obs, ftol=0.0, xtol=0.0, gtol=0.0, max_iter=iters)
+        runs.append((time.perf_counter() - t0, info))
+    runs.sort(key=lambda r: r[0])
+    dt, info = runs[len(runs) // 2]
     _, info_ref = core.ba_solve(x0, obs, ftol=1e-2)                             # reference stopping rule
     return {"metric": "BA iters/sec (8 cams, 1k pts)", "value": info["iterations"] / dt,
             "iterations": info["iterations"], "nfev": info["nfev"], "ms_per_iter": 1e3 * dt / max(info["iterations"], 1),
+            "runs_ms": [round(1e3 * r[0], 2) for r in runs], "statistic": "median of 5 solves",
             "params": int(x0.size), "points": int(info["m"]),
             "reference_rule_run": {"iterations": info_ref["iterations"], "status": info_ref["status"],
                                    "cost0": info_ref["cost0"], "cost": info_ref["cost"],
@@ -301,6 +327,7 @@ def main():
             if not args.no_ba and default_wl:
                 core.set_stream(0)
                 line["ba"] = ba_bench(core)
+                line["ba"]["calibration_16k_points"] = ba_bench_16k(core)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
