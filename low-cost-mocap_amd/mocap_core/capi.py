@@ -1,5 +1,9 @@
 """ctypes binding of the C ABI in include/mocap_core.h (lib/libmocap_core.so).
 
+Load order: PyTorch ships its own libamdhip64 under the same SONAME as the system one this library
+links to; the first one loaded serves the whole process.  When PyTorch is used alongside (device
+buffers, torch.distributed), import torch BEFORE the first MocapCore() so both share PyTorch's copy.
+
 This is the host side of the drop-in boundary.  There is NO CPU fallback: if the shared
 library is missing or no MI355X is visible, construction raises.  Marshalling only --
 every number comes from the HIP kernels.

@@ -99,3 +99,37 @@ def gather_records(rec, dst=0):
         return out.reshape(world * rec.shape[0], rec.shape[1])
     dist.gather(rec, gather_list=None, dst=dst)
     return None
+
+
+class PendingGather:
+    """Handle of a gather that is still in flight (gather_records_async).  result() completes it:
+    on `dst` the concatenated [world*F][rb] tensor, None elsewhere."""
+
+    def __init__(self, work, out, rec, is_dst):
+        self._work, self._out, self._rec, self._is_dst = work, out, rec, is_dst
+
+    def result(self):
+        if self._work is not None:
+            self._work.wait()      # RCCL: orders the current stream after the collective, no host block
+            self._work = None
+        if self._out is None:
+            return self._rec if self._is_dst else None
+        return self._out.reshape(self._out.shape[0] * self._out.shape[1], self._out.shape[2])
+
+
+def gather_records_async(rec, dst=0):
+    """gather_records without waiting: the collective is queued behind the work that produced `rec`
+    and runs on the process group's own stream, so the next batch's kernels can be enqueued (and run)
+    while the records travel.  One step's exchange then hides behind the next step's compute; only the
+    last one of a run is exposed.  Keep the returned handle and call .result()."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return PendingGather(None, None, rec, True)
+    world, rank = dist.get_world_size(), dist.get_rank()
+    if rank == dst:
+        out = torch.empty((world,) + tuple(rec.shape), dtype=rec.dtype, device=rec.device)
+        work = dist.gather(rec, gather_list=list(out.unbind(0)), dst=dst, async_op=True)
+        return PendingGather(work, out, rec, True)
+    work = dist.gather(rec, gather_list=None, dst=dst, async_op=True)
+    return PendingGather(work, None, rec, False)

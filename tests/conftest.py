@@ -37,5 +37,9 @@ def gpu_available():
 @pytest.fixture(scope="session")
 def core():
     """The HIP core through its C ABI; fails loudly (never falls back) when missing on a GPU box."""
+    # PyTorch bundles its own libamdhip64 with the same SONAME as /opt/rocm's: whichever is loaded first
+    # serves both.  A process that uses both must load torch first (bench.py does); tests that touch
+    # torch.cuda / RCCL later in the session would otherwise find torch bound to the other runtime.
+    import torch  # noqa: F401
     from mocap_core import capi
     return capi.MocapCore(device_id=0)

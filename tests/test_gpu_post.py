@@ -74,3 +74,42 @@ def test_world_epilogue_fused_in_frame_kernel(core):
                                        rtol=0, atol=0)
     again = core.match_triangulate(blobs, counts, K_max=48)      # switched off again: camera-0 coordinates
     assert np.array_equal(again["xyz"][valid], base["xyz"][valid])
+
+
+def test_rccl_gather_api_world1():
+    """The exchange step through the real RCCL backend (world size 1 is all a 1-GPU box offers):
+    init, async gather of packed device records, completion, unpack.  The N > 1 logic is covered by
+    the gloo world-2 test in test_host_cpu.py; this pins the calls RCCL itself accepts."""
+    import os
+    import socket
+    import torch
+    import torch.distributed as dist
+    from mocap_core import dist as mdist
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        F, K, C = 64, 16, 4
+        rng = np.random.default_rng(5)
+        n_out = torch.from_numpy(rng.integers(0, K, F).astype(np.int32)).to(dev)
+        xyz = torch.from_numpy(rng.normal(size=(F, K, 3))).to(dev)
+        err = torch.from_numpy(rng.random((F, K))).to(dev)
+        corr = torch.from_numpy(rng.integers(-1, 4, (F, K, C)).astype(np.int16)).to(dev)
+        rec = mdist.pack_records(n_out, xyz, err, corr)
+        # world == 1 short-circuits inside gather_records*, so call the collective itself too
+        out = torch.empty((1,) + tuple(rec.shape), dtype=rec.dtype, device=dev)
+        work = dist.gather(rec, gather_list=list(out.unbind(0)), dst=0, async_op=True)
+        work.wait()
+        torch.cuda.synchronize()
+        assert torch.equal(out[0], rec)
+        got = mdist.unpack_records(mdist.gather_records_async(rec).result(), C, K)
+        assert np.array_equal(got["n_out"], n_out.cpu().numpy()) and np.array_equal(got["xyz"], xyz.cpu().numpy())
+        assert np.array_equal(got["corr"], corr.cpu().numpy())
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()

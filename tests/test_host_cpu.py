@@ -128,11 +128,15 @@ def _worker(rank, world, port, out_path):
     rec = mdist.pack_records(torch.from_numpy(res["n_out"]), torch.from_numpy(res["xyz"]),
                              torch.from_numpy(res["err"]), torch.from_numpy(res["corr"]))
     allrec = mdist.gather_records(rec, dst=0)
+    # the pipelined form bench.py uses: several exchanges in flight, completed later, same bytes
+    handles = [mdist.gather_records_async(rec.clone(), dst=0) for _ in range(3)]
+    later = [h.result() for h in handles]
     if rank == 0:
         got = mdist.unpack_records(allrec, C, K)
         np.savez(out_path, **got)
+        assert all(torch.equal(x, allrec) for x in later)
     else:
-        assert allrec is None
+        assert allrec is None and all(x is None for x in later)
     dist.barrier()
     dist.destroy_process_group()
 
