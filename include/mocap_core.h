@@ -67,7 +67,7 @@ int mocap_set_stream(mocap_ctx* ctx, void* hip_stream);
 int mocap_synchronize(mocap_ctx* ctx);
 int mocap_set_options(mocap_ctx* ctx, uint32_t flags);
 /* scheduling knobs of the frame path; results are bit-identical for every setting (tested).
- *   frame_threads    workgroup size 64 | 128 | 256 (0 = keep)
+ *   frame_threads    workgroup size 64 | 128 | 256 (0 = automatic: 64 for tiny frames, else 256)
  *   heavy_threshold  candidate count above which a frame is cut into slices evaluated by several
  *                    workgroups (-1 = automatic, 0 = never split)
  *   slice_size       target candidates per slice (0 = automatic) */

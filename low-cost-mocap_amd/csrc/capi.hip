@@ -132,7 +132,7 @@ extern "C" int mocap_set_tuning(mocap_ctx* ctx, int frame_threads, int heavy_thr
   std::lock_guard<std::mutex> lk(ctx->mu);
   if (frame_threads != 0 && frame_threads != 64 && frame_threads != 128 && frame_threads != 256)
     return ctx->fail(MOCAP_E_ARG, "mocap_set_tuning: frame_threads must be 0, 64, 128 or 256");
-  if (frame_threads) ctx->frame_threads = frame_threads;
+  ctx->frame_threads = frame_threads;  // 0 = automatic
   ctx->heavy_threshold = heavy_threshold < 0 ? -1 : heavy_threshold;
   ctx->slice_size = slice_size < 0 ? 0 : slice_size;
   return MOCAP_OK;
@@ -367,7 +367,9 @@ static int match_dev_locked(mocap_ctx* ctx, int64_t n_frames, int M_max, const f
   a.status = d_status;
   a.n_cand = d_n_cand;
   a.world = ctx->world_on ? (const double*)ctx->world.ptr : nullptr;
-  int T = ctx->frame_threads;
+  // automatic workgroup size: tiny frames (4 x 4: a handful of candidates) are latency-bound, one wave
+  // per frame keeps 4x more frames in flight per CU; everything else wants 256 lanes per frame
+  int T = ctx->frame_threads ? ctx->frame_threads : (ctx->C * M_max <= 32 ? 64 : 256);
   const int hit_cap = ctx->hit_cap < 1 ? 1 : (ctx->hit_cap > M_max ? M_max : ctx->hit_cap);
   bool wide = ctx->force_wide != 0;
   size_t lds = 0;
@@ -394,7 +396,6 @@ static int match_dev_locked(mocap_ctx* ctx, int64_t n_frames, int M_max, const f
   int per_cu = (int)((160 * 1024) / lds);
   const int wave_cap = 16 / (T / 64) > 0 ? 16 / (T / 64) : 1;  // 128 VGPRs -> 16 waves per CU
   if (per_cu > wave_cap) per_cu = wave_cap;
-  if (per_cu > 8) per_cu = 8;
   if (per_cu < 1) per_cu = 1;
   const int64_t full_grid = (int64_t)ctx->num_cus * per_cu;
   int64_t grid = full_grid < n_frames ? full_grid : n_frames;
@@ -410,6 +411,13 @@ static int match_dev_locked(mocap_ctx* ctx, int64_t n_frames, int M_max, const f
   FrameQueues& q = a.q;
   q.heavy_threshold = ctx->heavy_threshold >= 0 ? (uint32_t)ctx->heavy_threshold : (batch ? 16384u : 2u * T);
   q.slice_size = ctx->slice_size > 0 ? (uint32_t)ctx->slice_size : (batch ? 8192u : 4u * T);
+  // small frames: amortise the queue atomic over a chunk (keeps >= 64 chunks per workgroup for balance);
+  // frames with real work keep the finest granularity, their candidate counts are heavy-tailed
+  q.frame_chunk = 1;
+  if (ctx->C * M_max <= 32) {
+    int64_t ch = n_frames / (full_grid * 64);
+    q.frame_chunk = (int)(ch < 1 ? 1 : (ch > 16 ? 16 : ch));
+  }
   int64_t H = n_frames / 8;
   if (H < 64) H = 64;
   if (H > n_frames) H = n_frames;

@@ -18,7 +18,7 @@ struct DevBuf {
 struct mocap_ctx {
   int device = 0;
   int num_cus = 256;
-  int frame_threads = 256;  // workgroup size of the frame kernel (MOCAP_FRAME_THREADS=64|128|256)
+  int frame_threads = 0;    // workgroup size of the frame kernel, 0 = automatic (MOCAP_FRAME_THREADS=64|128|256)
   int heavy_threshold = -1; // -1 = automatic; 0 = never split heavy frames (MOCAP_HEAVY_THRESHOLD)
   int slice_size = 0;       // 0 = automatic (MOCAP_SLICE_SIZE)
   int hit_cap = 16;         // wide frames: hits kept per (root, camera) (mocap_set_frame_limits)

@@ -672,12 +672,19 @@ __global__ __launch_bounds__(T, MOCAP_FRAME_WAVES_PER_EU) void frame_kernel(Fram
   const FrameQueues& q = p.q;
   const int R = p.K_max;
 
+  int chunk_next = 0, chunk_end = 0;  // lane 0 only: frames of the chunk it pulled last
   while (true) {
     // ------------------------------------------------------------ pull a work item
     if (tid == 0) {
       int item;
       if (MODE == MODE_MAIN) {
-        item = atomicAdd(&q.counters[QC_NEXT_FRAME], 1);
+        // frames are pulled `frame_chunk` at a time: one device-scope atomic per frame on a single
+        // address tops out near 90 M/s, which small frames (4 x 4: a few candidates each) exceed
+        if (chunk_next >= chunk_end) {
+          chunk_next = atomicAdd(&q.counters[QC_NEXT_FRAME], q.frame_chunk);
+          chunk_end = chunk_next + q.frame_chunk;
+        }
+        item = chunk_next++;
         if (item >= p.n_frames) item = -1;
       } else if (MODE == MODE_SLICE) {
         int n = q.counters[QC_N_SLICES];

@@ -25,6 +25,7 @@ struct FrameQueues {
   int H_cap, W_cap;
   uint32_t heavy_threshold;  // candidate count above which a frame is deferred (0 = never)
   uint32_t slice_size;       // target candidates per slice
+  int frame_chunk;           // frames a workgroup takes per pull of the frame queue (>= 1)
 };
 
 struct FrameArgs {

@@ -9,7 +9,8 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "low-cost-mocap_
 import torch
 from mocap_core import capi, synth
 
-C, M, F, K_MAX = 8, 16, int(os.environ.get("FRAMES", 100000)), 48
+C, M, K_MAX = (int(v) for v in os.environ.get("SHAPE", "8,16,48").split(","))
+F = int(os.environ.get("FRAMES", 100000))
 rig = synth.ring_rig(C)
 blobs, counts, _ = synth.make_blob_stream(rig, F, M, seed=1)
 dev = torch.device("cuda", 0)

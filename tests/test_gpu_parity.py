@@ -220,7 +220,7 @@ def test_scheduling_knobs_do_not_change_results(core):
         base = core.match_triangulate(blobs, counts, K_max=48)
         assert base["n_cand"].max() > 20000               # the batch does contain heavy frames
         valid = np.arange(48)[None, :] < base["n_out"][:, None]
-        for threads, thr, sl in [(256, 2048, 512), (128, 4096, 1024), (64, 1024, 256), (256, 300, 300), (256, -1, 0)]:
+        for threads, thr, sl in [(256, 2048, 512), (128, 4096, 1024), (64, 1024, 256), (256, 300, 300), (256, -1, 0), (0, -1, 0)]:
             core.set_tuning(threads, thr, sl)
             res = core.match_triangulate(blobs, counts, K_max=48)
             for key in ("n_out", "status", "n_cand"):
@@ -228,7 +228,7 @@ def test_scheduling_knobs_do_not_change_results(core):
             for key in ("xyz", "err", "corr"):
                 assert np.array_equal(res[key][valid], base[key][valid]), (threads, thr, sl, key)
     finally:
-        core.set_tuning(256, -1, 0)
+        core.set_tuning(0, -1, 0)
 
 
 def test_triangulate_vs_c_oracle_large(core):
