@@ -128,6 +128,47 @@ int mocap_match_triangulate_dev(mocap_ctx* ctx, int64_t n_frames, int M_max, con
                                 double* d_xyz, double* d_err, int16_t* d_corr, int32_t* d_n_out,
                                 int32_t* d_status, int32_t* d_n_cand);
 
+/* ---------------------------------------------------------------- before the path
+ * Blob extraction: replaces the per-camera preprocessing of Cameras._camera_read (helpers.py:68-82:
+ * np.rot90, make_square helpers.py:507-523, cv.undistort, cv.GaussianBlur (9,9), cv.filter2D with the 5x5
+ * sharpening kernel, cv.cvtColor RGB2BGR) and Cameras._find_dot (helpers.py:143-163: grey, threshold
+ * 255*0.2, cv.findContours RETR_TREE / CHAIN_APPROX_SIMPLE, cv.moments, int() centroid of every contour
+ * with m00 != 0, in findContours' order) for a batch of frame sets.
+ *
+ * mocap_set_image_params: frame geometry and lens model, once per camera set (natural call site:
+ * Cameras.__init__ / set_camera_params, helpers.py:20-22,195-201).  Builds the fixed-point undistortion
+ * map cv.undistort would rebuild per frame.
+ *   rows, cols   raw frame size (pseyepy RES_SMALL: 240 x 320); must be landscape with >= 8 rows of square
+ *                padding above and below -- outside that domain the reference's make_square raises
+ *   K [C][9]     intrinsic_matrix, dist [C][5] distortion_coef (k1 k2 p1 p2 k3)   (camera-params.json)
+ *   rotation [C] quarter turns of np.rot90 (may be NULL = 0); odd values are rejected like the reference */
+int mocap_set_image_params(mocap_ctx* ctx, int C, int rows, int cols, const double* K, const double* dist,
+                           const int32_t* rotation);
+/* read back camera `camera`'s packed map [S][S] (S = cols): fx | fy << 5 | (sx + 1) << 10 | (sy + 1) << 21,
+ * sx field 2047 = every tap outside the frame (tests / debugging) */
+int mocap_get_undistort_map(mocap_ctx* ctx, int camera, uint32_t* map);
+
+/* per-image status bits written by mocap_find_blobs* */
+enum {
+  MOCAP_BLOB_ST_POINT_OVERFLOW = 1, /* more centroids than M_max: the first M_max were kept            */
+  MOCAP_BLOB_ST_CAP_OVERFLOW = 2    /* more than 8192 border pairs / 1024 contours in one image (noise,
+                                       not blobs): count = 0                                            */
+};
+/* mocap_find_blobs
+ *   images    [F][C][rows][cols][3] uint8 RGB, what pseyepy's Camera.read() returns per camera
+ *   M_max     blob slots per camera
+ *   blobs     [F][C][M_max][2] float32 centroids (x, y): exactly the frame path's input layout, so the
+ *             _dev variant chains into mocap_match_triangulate_dev without leaving HBM
+ *   counts    [F][C] centroids per camera (0 = the reference's [[None, None]], helpers.py:158-159)
+ *   status    [F][C] MOCAP_BLOB_ST_* bits
+ *   processed [F][C][cols][cols][3] (may be NULL) the BGR frame the reference streams to the UI
+ *             (helpers.py:82,141; without the debug drawings of helpers.py:148,155-156)
+ *   n_contours [F][C] (may be NULL) contours found, including the zero-area ones the reference skips */
+int mocap_find_blobs(mocap_ctx* ctx, int64_t n_frames, const uint8_t* images, int M_max, float* blobs,
+                     int32_t* counts, int32_t* status, uint8_t* processed, int32_t* n_contours);
+int mocap_find_blobs_dev(mocap_ctx* ctx, int64_t n_frames, const uint8_t* d_images, int M_max, float* d_blobs,
+                         int32_t* d_counts, int32_t* d_status, uint8_t* d_processed);
+
 /* ---------------------------------------------------------------- after the path
  * World-coordinate epilogue of the frame loop (helpers.py:96-103), fused into the frame path's store:
  * with a matrix set, `xyz` of mocap_match_triangulate* leaves the kernel as

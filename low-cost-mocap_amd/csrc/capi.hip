@@ -94,6 +94,10 @@ extern "C" void mocap_destroy(mocap_ctx* ctx) {
   ctx->tables.release();
   for (auto& b : ctx->scratch) b.release();
   ctx->frame_ws.release();
+  ctx->img_map.release();
+  ctx->img_rot.release();
+  ctx->img_mask.release();
+  ctx->img_stage.release();
   ctx->world.release();
   if (ctx->ba_pin) (void)hipHostFree(ctx->ba_pin);
   if (ctx->ba_event) (void)hipEventDestroy(ctx->ba_event);

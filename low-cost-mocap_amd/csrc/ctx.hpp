@@ -39,6 +39,9 @@ struct mocap_ctx {
   hipEvent_t ba_event = nullptr;
   DevBuf world;             // 16 doubles: the to-world matrix of the fused epilogue
   bool world_on = false;
+  // blob extraction (mocap_set_image_params): frame geometry, undistortion maps, mask workspace
+  int img_C = 0, img_rows = 0, img_cols = 0, img_S = 0, img_ay = 0;
+  DevBuf img_map, img_rot, img_mask, img_stage;
   DevBuf frame_ws;          // wide-frame workspace: [workgroup][hit lists | group columns | ...]
   DevBuf scratch[4];        // [0] host-API staging, [1..3] bundle adjustment workspace
 

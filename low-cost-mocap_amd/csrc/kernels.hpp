@@ -73,6 +73,28 @@ struct LocateArgs {
 };
 hipError_t launch_locate_objects(const LocateArgs& a, hipStream_t stream);
 
+// blob extraction, the step before the frame path (reference helpers.py:68-82, 143-163), csrc/blob_kernels.hip
+constexpr int BLOB_ST_POINT_OVERFLOW_ = 1;  // more centroids than M_max: the first M_max are kept
+constexpr int BLOB_ST_CAP_OVERFLOW_ = 2;    // more border pairs / contours than the workgroup's tables hold
+struct BlobArgs {
+  int64_t n_images;        // F * C, camera = image % C
+  int C, rows, cols;       // raw frame size
+  int S, ay;               // squared frame edge (= cols), first frame row inside it
+  int M_max;
+  const uint8_t* raw;      // [n_images][rows][cols][3] RGB
+  const uint32_t* map;     // [C][S][S] undistortion map: fx | fy << 5 | (sx + 1) << 10 | (sy + 1) << 21
+  const int32_t* rot;      // [C] quarter turns (0 or 2)
+  unsigned long long* mask;  // [n_images][S][ceil(S / 64)] thresholded frame, 1 bit per pixel
+  uint8_t* processed;      // [n_images][S][S][3] BGR frame as the reference streams it, or null
+  float* blobs;            // [n_images][M_max][2]
+  int32_t* counts;         // [n_images]
+  int32_t* status;         // [n_images]
+  int32_t* n_contours;     // [n_images] or null
+};
+hipError_t launch_blob_mask(const BlobArgs& a, hipStream_t stream);
+hipError_t launch_blob_contours(const BlobArgs& a, int P_cap, int N_cap, int only_overflowed, hipStream_t stream);
+size_t blob_contour_lds_bytes(int S, int P_cap, int N_cap);
+
 // explicit-correspondence triangulation, optionally batched over P camera sets (bundle adjustment)
 struct TriArgs {
   CamView cv;             // tables of camera set 0; set p is offset by the strides below

@@ -22,6 +22,8 @@ MOCAP_E_NOCONV = -5
 ST_ROOT_OVERFLOW = 1
 ST_CAND_OVERFLOW = 2
 ST_HIT_OVERFLOW = 4
+BLOB_ST_POINT_OVERFLOW = 1
+BLOB_ST_CAP_OVERFLOW = 2
 OPT_F32_ROUNDING = 1
 
 _vp, _i32, _i64, _dbl, _u32 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_double, ctypes.c_uint32
@@ -44,6 +46,10 @@ SIGNATURES = {
     "mocap_triangulate_dev": (_i32, [_vp, _i64, _vp, _vp, _vp]),
     "mocap_match_triangulate": (_i32, [_vp, _i64, _i32, _vp, _vp, _dbl, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mocap_match_triangulate_dev": (_i32, [_vp, _i64, _i32, _vp, _vp, _dbl, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mocap_set_image_params": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "mocap_get_undistort_map": (_i32, [_vp, _i32, _vp]),
+    "mocap_find_blobs": (_i32, [_vp, _i64, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "mocap_find_blobs_dev": (_i32, [_vp, _i64, _vp, _i32, _vp, _vp, _vp, _vp]),
     "mocap_set_world_transform": (_i32, [_vp, _vp]),
     "mocap_locate_objects": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mocap_locate_objects_dev": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -205,6 +211,44 @@ class MocapCore:
                 for key in ("n_out", "status", "n_cand"):
                     res[key][f] = big[key][j]
         return res
+
+    # ------------------------------------------------------------------ before the path
+    def set_image_params(self, rows, cols, K, dist, rotation=None):
+        """Frame geometry + lens model of every camera (camera-params.json: intrinsic_matrix,
+        distortion_coef, rotation) -> the undistortion maps of the blob-extraction stage."""
+        K = np.ascontiguousarray(K, dtype=np.float64).reshape(-1, 9)
+        C = K.shape[0]
+        dist = np.ascontiguousarray(dist, dtype=np.float64).reshape(C, 5)
+        rot = None if rotation is None else np.ascontiguousarray(rotation, dtype=np.int32).reshape(C)
+        self._check(self.lib.mocap_set_image_params(self._h, C, int(rows), int(cols), _p(K), _p(dist), _p(rot)))
+        self.img_C, self.img_rows, self.img_cols = C, int(rows), int(cols)
+
+    def undistort_map(self, camera=0):
+        m = np.zeros((self.img_cols, self.img_cols), dtype=np.uint32)
+        self._check(self.lib.mocap_get_undistort_map(self._h, int(camera), _p(m)))
+        return m
+
+    def find_blobs(self, images, M_max=16, want_processed=False):
+        """images [F][C][rows][cols][3] uint8 RGB -> blobs f32 [F][C][M_max][2], counts, status
+        (the frame path's input layout), optionally the processed BGR frames."""
+        images = np.ascontiguousarray(images, dtype=np.uint8)
+        F, C = images.shape[:2]
+        assert images.shape == (F, C, self.img_rows, self.img_cols, 3) and C == self.img_C
+        blobs = np.zeros((F, C, M_max, 2), dtype=np.float32)
+        counts = np.zeros((F, C), dtype=np.int32)
+        status = np.zeros((F, C), dtype=np.int32)
+        ncont = np.zeros((F, C), dtype=np.int32)
+        proc = np.zeros((F, C, self.img_cols, self.img_cols, 3), dtype=np.uint8) if want_processed else None
+        self._check(self.lib.mocap_find_blobs(self._h, F, _p(images), int(M_max), _p(blobs), _p(counts), _p(status),
+                                              _p(proc), _p(ncont)))
+        out = {"blobs": blobs, "counts": counts, "status": status, "n_contours": ncont}
+        if want_processed:
+            out["processed"] = proc
+        return out
+
+    def find_blobs_dev(self, n_frames, d_images, M_max, d_blobs, d_counts, d_status, d_processed=0):
+        self._check(self.lib.mocap_find_blobs_dev(self._h, int(n_frames), _vp(d_images), int(M_max), _vp(d_blobs),
+                                                  _vp(d_counts), _vp(d_status), _vp(d_processed or 0)))
 
     # ------------------------------------------------------------------ after the path
     def set_world_transform(self, to_world):

@@ -183,6 +183,40 @@ def find_point_correspondance_and_object_points_batch(blobs, counts, camera_pose
 
 
 # ----------------------------------------------------------------------------- after the path
+# ----------------------------------------------------------------------------- before the path
+def camera_read_find_dots(raw_frames, M_max=64, want_frames=True):
+    """The per-camera body of Cameras._camera_read (helpers.py:71-82) + Cameras._find_dot
+    (helpers.py:143-163) for one set of raw frames (what pseyepy's Camera.read() returns):
+    returns (frames, image_points) with frames = the processed BGR frames the reference streams
+    (without its debug drawings) and image_points = per camera [[x, y], ...] or [[None, None]]
+    (helpers.py:158-159) -- ready for find_point_correspondance_and_object_points.
+    Lens model and rotation come from set_camera_params() (camera-params.json entries)."""
+    raw = np.ascontiguousarray(np.asarray(raw_frames, dtype=np.uint8))
+    C, rows, cols = raw.shape[0], raw.shape[1], raw.shape[2]
+    params = _state["camera_params"]
+    if params is None or len(params) < C:
+        raise RuntimeError("set_camera_params() has not been called with one entry per camera")
+    K = np.array([np.array(params[i]["intrinsic_matrix"], dtype=np.float64) for i in range(C)])
+    dist = np.array([np.array(params[i]["distortion_coef"], dtype=np.float64).ravel()[:5] for i in range(C)])
+    rot = np.array([int(params[i].get("rotation", 0)) for i in range(C)], dtype=np.int32)
+    with _state["lock"]:
+        core = get_core()
+        key = (rows, cols, K.tobytes(), dist.tobytes(), rot.tobytes())
+        if _state.get("img_key") != key:
+            core.set_image_params(rows, cols, K, dist, rot)
+            _state["img_key"] = key
+        res = core.find_blobs(raw[None], M_max=M_max, want_processed=want_frames)
+        if (res["status"] & capi.BLOB_ST_POINT_OVERFLOW).any():     # more dots than slots: ask again
+            res = core.find_blobs(raw[None], M_max=int(res["n_contours"].max()) + 1, want_processed=want_frames)
+    image_points = []
+    for c in range(C):
+        n = int(res["counts"][0, c])
+        pts = res["blobs"][0, c, :n].astype(np.int64).tolist()
+        image_points.append(pts if n else [[None, None]])
+    frames = [f for f in res["processed"][0]] if want_frames else [None] * C
+    return frames, image_points
+
+
 def set_to_world_coords_matrix(to_world_coords_matrix):
     """Cameras.to_world_coords_matrix (helpers.py:40,100): with a matrix set, the frame path returns
     world coordinates -- the loop at helpers.py:96-103 runs fused in the kernel's store.  None = off

@@ -241,3 +241,63 @@ def make_object_frames(n_frames, k_max, seed=0, jitter=0.004):
         xyz[f, :n] = pts
         err[f, :n] = rng.uniform(0.05, 2.0, n)
     return xyz, err, n_pts
+
+
+# ----------------------------------------------------------------------------- camera frames (blob extraction)
+REFERENCE_DISTORTION = (-1.26372388e-01, 2.62661497e-01, 1.21306197e-03, 2.24507008e-04, -2.48534118e-01)
+"""distortion_coef of every entry of the reference's api/camera-params.json (k1 k2 p1 p2 k3)."""
+
+
+def distort_pixels(u, v, K, dist):
+    """Ideal pinhole pixel -> where the lens puts it (the forward model cv.undistort inverts)."""
+    k1, k2, p1, p2, k3 = dist
+    x = (u - K[0, 2]) / K[0, 0]
+    y = (v - K[1, 2]) / K[1, 1]
+    r2 = x * x + y * y
+    kr = 1 + ((k3 * r2 + k2) * r2 + k1) * r2
+    xd = x * kr + 2 * p1 * x * y + p2 * (r2 + 2 * x * x)
+    yd = y * kr + p1 * (r2 + 2 * y * y) + 2 * p2 * x * y
+    return K[0, 0] * xd + K[0, 2], K[1, 1] * yd + K[1, 2]
+
+
+def render_camera_frames(rig, n_frames, n_markers, seed=0, rows=240, cols=320, dist=REFERENCE_DISTORTION,
+                         spot_sigma=(1.2, 2.2), noise_levels=3, dropout=0.05, half_extent=0.7, min_sep=0.12,
+                         peak=400.0):
+    """Synthetic PS3-Eye style IR frames: uint8 RGB [F][C][rows][cols][3], dark with sensor noise in
+    [0, noise_levels) and one saturated Gaussian spot per visible marker at the lens-distorted
+    projection.  K refers to the squared (cols x cols) frame the reference builds with make_square
+    (helpers.py:72,507-523), so raw row = squared row - (cols - rows) // 2.
+    Returns (frames, truth) with truth["uv"] [F][C][M][2] the ideal (undistorted) pixel, NaN = unseen."""
+    rng = np.random.default_rng(seed)
+    C = len(rig["R"])
+    F, M = int(n_frames), int(n_markers)
+    ay = (cols - rows) // 2
+    world = _sample_markers(rng, F, M, half_extent, min_sep)
+    X0 = world @ rig["R0"].T + rig["centre"]
+    frames = rng.integers(0, max(1, noise_levels), (F, C, rows, cols, 3), dtype=np.uint8)
+    uv = np.full((F, C, M, 2), np.nan)
+    R = 9
+    yy, xx = np.mgrid[-R:R + 1, -R:R + 1]
+    for c in range(C):
+        Xc = X0 @ rig["R"][c].T + rig["t"][c]
+        K = rig["K"][c]
+        u = K[0, 0] * Xc[..., 0] / Xc[..., 2] + K[0, 2]
+        v = K[1, 1] * Xc[..., 1] / Xc[..., 2] + K[1, 2]
+        ud, vd = distort_pixels(u, v, K, dist)
+        vd = vd - ay
+        seen = (rng.random((F, M)) >= dropout) & (Xc[..., 2] > 0)
+        seen &= (ud >= 4) & (ud < cols - 4) & (vd >= 4) & (vd < rows - 4)
+        sig = rng.uniform(spot_sigma[0], spot_sigma[1], (F, M))
+        for f in range(F):
+            img = frames[f, c].astype(np.float32)
+            for m in np.flatnonzero(seen[f]):
+                cx, cy = ud[f, m], vd[f, m]
+                ix, iy = int(round(cx)), int(round(cy))
+                x0, x1, y0, y1 = max(ix - R, 0), min(ix + R + 1, cols), max(iy - R, 0), min(iy + R + 1, rows)
+                gx = xx[0, x0 - ix + R:x1 - ix + R] + ix - cx
+                gy = yy[y0 - iy + R:y1 - iy + R, 0] + iy - cy
+                spot = peak * np.exp(-(gy[:, None] ** 2 + gx[None, :] ** 2) / (2 * sig[f, m] ** 2))
+                img[y0:y1, x0:x1] += spot[:, :, None]
+                uv[f, c, m] = (u[f, m], v[f, m])
+            frames[f, c] = np.clip(img, 0, 255).astype(np.uint8)
+    return frames, {"uv": uv, "points_cam0": X0}

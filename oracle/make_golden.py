@@ -256,8 +256,46 @@ def golden_post(name, n_frames, k_max, seed):
     print(name, "frames", n_frames, "objects", int(ref_nobj.sum()))
 
 
+def golden_blobs(name, C, n_frames, n_markers, seed, Ks=None, dists=None, rotation=None, noisy=False):
+    """Blob extraction: the reference's own Cameras._camera_read preprocessing and
+    Cameras._find_dot (helpers.py:68-82, 143-163) on synthetic raw frames.  rot90 / make_square / the
+    centroid rule are the reference's code; its OpenCV calls are oracle/cv_image_restate.py."""
+    rig = synth.ring_rig(C)
+    Ks = [synth.DEFAULT_K] * C if Ks is None else Ks
+    rig["K"] = np.array(Ks, dtype=np.float64)
+    dists = [synth.REFERENCE_DISTORTION] * C if dists is None else dists
+    rotation = [0] * C if rotation is None else rotation
+    images, _ = synth.render_camera_frames(rig, n_frames, n_markers, seed=seed, noise_levels=2,
+                                           spot_sigma=(1.0, 6.0) if noisy else (1.2, 2.2))
+    if noisy:
+        rng = np.random.default_rng(seed)
+        images[0, 0] = np.maximum(images[0, 0], rng.integers(0, 90, images[0, 0].shape, dtype=np.uint8))
+    H = ref_harness.load_reference(C, intrinsics=[np.asarray(k).tolist() for k in Ks])
+    ref_frames, ref_pts = [], []
+    for f in range(n_frames):
+        fr, pts = ref_harness.reference_find_dots(H, list(images[f]), distortion=dists, rotation=rotation)
+        ref_frames.append(np.array(fr))
+        ref_pts.append(pts)
+    mmax = max(1, max(len(p) for fp in ref_pts for p in fp))
+    ref_points = np.zeros((n_frames, C, mmax, 2), dtype=np.int32)
+    ref_counts = np.zeros((n_frames, C), dtype=np.int32)
+    for f in range(n_frames):
+        for c in range(C):
+            p = ref_pts[f][c]
+            if p != [[None, None]]:
+                ref_counts[f, c] = len(p)
+                ref_points[f, c, :len(p)] = p
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), images=images, K=rig["K"], dist=np.array(dists, dtype=np.float64),
+                        rotation=np.array(rotation, dtype=np.int32), ref_frames=np.array(ref_frames),
+                        ref_points=ref_points, ref_counts=ref_counts)
+    print(name, "frame sets", n_frames, "points", int(ref_counts.sum()))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if "--blobs-only" in sys.argv:
+        return main_blobs()
+    main_blobs()
     # BASELINE.json configs[0..2] shapes
     golden_frames("frames_c2_m1", synth.ring_rig(2), 8, 1, seed=0)
     golden_frames("frames_c4_m4", synth.ring_rig(4), 40, 4, seed=0)
@@ -282,6 +320,15 @@ def main():
     golden_ba("ba_c3_n24", 3, 24, seed=9, run_solver=True)
     # the rows right after the path: world-coordinate epilogue + object locator
     golden_post("post_world_locate", 300, 24, seed=10)
+
+
+def main_blobs():
+    # the step before the path: raw camera frames -> image points
+    golden_blobs("blobs_c2_ref_params", 2, 1, 8, seed=11)
+    golden_blobs("blobs_c3_calib_rot", 3, 1, 6, seed=12, Ks=CALIBRATED_K,
+                 dists=[[-0.2, 0.1, 0.002, -0.001, 0.05], list(synth.REFERENCE_DISTORTION), [0, 0, 0, 0, 0]],
+                 rotation=[0, 2, 2])
+    golden_blobs("blobs_c1_noisy", 1, 1, 10, seed=13, noisy=True)
 
 
 if __name__ == "__main__":

@@ -24,7 +24,7 @@ import types
 
 import numpy as np
 
-from . import cv_restate
+from . import cv_image_restate, cv_restate
 
 REFERENCE_API = "/root/reference/computer_code/api"
 
@@ -46,6 +46,7 @@ def _install_stubs(num_cameras):
     cv2.projectPoints = cv_restate.project_points
     cv2.line = lambda img, *a, **k: img
     cv2.KalmanFilter = _FakeKalman
+    cv_image_restate.install(cv2)      # blob-extraction stage (helpers.py:68-88, 143-163), SURVEY 8f row 3
     sys.modules["cv2"] = cv2
 
     pseyepy = types.ModuleType("pseyepy")
@@ -95,6 +96,29 @@ def load_reference(num_cameras, intrinsics=None):
         })
     cams.camera_params = params
     return _helpers
+
+
+def reference_find_dots(H, raw_frames, distortion=None, rotation=None):
+    """The reference's own Cameras._camera_read preprocessing (helpers.py:68-82) followed by its
+    Cameras._find_dot (helpers.py:143-163) on one set of raw camera frames (list of HxWx3 uint8, what
+    pseyepy's Camera.read() hands over).  Returns (processed frames, image_points per camera) exactly as
+    the reference produces them ([[None, None]] for an empty camera)."""
+    cams = H.Cameras.instance()
+    assert len(raw_frames) == cams.num_cameras
+    for i in range(cams.num_cameras):
+        if distortion is not None:
+            cams.camera_params[i]["distortion_coef"] = list(distortion[i])
+        if rotation is not None:
+            cams.camera_params[i]["rotation"] = int(rotation[i])
+    cams.cameras.read = lambda: ([np.array(f, dtype=np.uint8) for f in raw_frames], None)
+    cams.is_capturing_points = False
+    frames = cams._camera_read()
+    out_frames, out_points = [], []
+    for f in frames:
+        img, pts = cams._find_dot(f)
+        out_frames.append(img)
+        out_points.append(pts)
+    return out_frames, out_points
 
 
 class NullSocket:

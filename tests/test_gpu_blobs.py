@@ -1,0 +1,154 @@
+"""GPU parity of the blob-extraction stage (Cameras._camera_read preprocessing +
+Cameras._find_dot, reference helpers.py:68-82, 143-163) against the oracle and the reference-pinned
+golden set.  Everything in this stage is integer arithmetic: the bar is BIT-EXACT (processed frames,
+centroids, their order, counts)."""
+import numpy as np
+import pytest
+
+from conftest import golden_names, load_golden
+from mocap_core import capi, synth
+from oracle import blob_oracle as bo
+
+pytestmark = pytest.mark.gpu
+
+REF_K = np.array([[320.0, 0, 160], [0, 320, 160], [0, 0, 1]])
+
+
+def _oracle_points(frames_set, Ks, dists, rots=None):
+    frames, pts = bo.find_dots(frames_set, Ks, dists, rots)
+    return np.array(frames), pts
+
+
+def _check_against_oracle(core, images, Ks, dists, rots=None, M_max=64, check_frames=True):
+    F, C = images.shape[:2]
+    core.set_image_params(images.shape[2], images.shape[3], Ks, dists, rots)
+    res = core.find_blobs(images, M_max=M_max, want_processed=check_frames)
+    for f in range(F):
+        frames, pts = _oracle_points(images[f], Ks, dists, rots)
+        if check_frames:
+            assert np.array_equal(res["processed"][f], frames), f"processed frame differs (frame set {f})"
+        for c in range(C):
+            n = len(pts[c])
+            assert res["counts"][f, c] == min(n, M_max), (f, c, res["counts"][f, c], n)
+            k = min(n, M_max)
+            got = res["blobs"][f, c, :k].astype(np.int64).tolist()
+            assert got == pts[c][:k], (f, c)
+            assert bool(res["status"][f, c] & capi.BLOB_ST_POINT_OVERFLOW) == (n > M_max)
+    return res
+
+
+def test_undistort_map_matches_oracle(core):
+    from oracle import cv_image_restate as ci
+    core.set_image_params(240, 320, [REF_K], [synth.REFERENCE_DISTORTION])
+    m = core.undistort_map(0)
+    sx, sy, fx, fy = ci.undistort_map(REF_K, synth.REFERENCE_DISTORTION, 320, 320)
+    outside = (sx >= 320) | (sx + 1 < 0) | (sy >= 320) | (sy + 1 < 0)
+    want = np.where(outside, 2047 << 10, fx | (fy << 5) | ((sx + 1) << 10) | ((sy + 1) << 21)).astype(np.uint32)
+    assert np.array_equal(m, want)
+
+
+@pytest.mark.parametrize("name", golden_names("blobs_"))
+def test_blobs_match_reference_golden(core, name):
+    """Golden = the reference's own _camera_read + _find_dot run through the stub harness."""
+    g = load_golden(name)
+    images = g["images"]
+    F, C = images.shape[:2]
+    core.set_image_params(images.shape[2], images.shape[3], g["K"], g["dist"], g["rotation"])
+    res = core.find_blobs(images, M_max=g["ref_points"].shape[2], want_processed=True)
+    assert np.array_equal(res["counts"], g["ref_counts"])
+    assert np.array_equal(res["processed"], g["ref_frames"])
+    for f in range(F):
+        for c in range(C):
+            n = g["ref_counts"][f, c]
+            assert np.array_equal(res["blobs"][f, c, :n], g["ref_points"][f, c, :n].astype(np.float32))
+
+
+def test_synthetic_rig_frames(core):
+    rig = synth.ring_rig(4)
+    images, truth = synth.render_camera_frames(rig, 3, 8, seed=11)
+    dists = [synth.REFERENCE_DISTORTION] * 4
+    res = _check_against_oracle(core, images, rig["K"], dists)
+    # and the centroids are the markers: visible markers have a blob within 1.5 px of their ideal pixel
+    # (spots that overlap in a view merge into one blob, as they do for the reference)
+    near = total = 0
+    for f in range(3):
+        for c in range(4):
+            uv = truth["uv"][f, c]
+            uv = uv[~np.isnan(uv[:, 0])]
+            b = res["blobs"][f, c, :res["counts"][f, c]]
+            for p in uv:
+                total += 1
+                near += np.min(np.abs(b - p).max(axis=1)) < 1.5
+    assert near >= 0.85 * total, (near, total)
+
+
+def test_rotation_and_distinct_intrinsics(core):
+    rng = np.random.default_rng(5)
+    rig = synth.ring_rig(3)
+    images, _ = synth.render_camera_frames(rig, 2, 6, seed=12)
+    Ks = np.array([[[268.66976067, 0, 123.58679484], [0, 268.57495496, 167.56126939], [0, 0, 1]],
+                   [[269.95158059, 0, 139.37072352], [0, 270.09608831, 160.36482761], [0, 0, 1]],
+                   REF_K])
+    dists = np.array([synth.REFERENCE_DISTORTION, [-0.2, 0.1, 0.002, -0.001, 0.05], [0, 0, 0, 0, 0]])
+    _check_against_oracle(core, images, Ks, dists, rots=[2, 0, 2])
+    del rng
+
+
+def test_noisy_frames_holes_nesting_and_caps(core):
+    """Bright noise makes hundreds of contours with holes and nesting: exercises the parent/ordering rules,
+    the zero-area filter, the large-table re-run and the point-overflow flag."""
+    rng = np.random.default_rng(6)
+    rig = synth.ring_rig(2)
+    images, _ = synth.render_camera_frames(rig, 2, 10, seed=13, spot_sigma=(2.0, 9.0), peak=600.0)
+    images[0, 1] = np.maximum(images[0, 1], rng.integers(0, 110, images[0, 1].shape, dtype=np.uint8))
+    images[1, 0] = np.maximum(images[1, 0], rng.integers(0, 70, images[1, 0].shape, dtype=np.uint8))
+    dists = [synth.REFERENCE_DISTORTION] * 2
+    res = _check_against_oracle(core, images, rig["K"], dists, M_max=1024)
+    assert res["n_contours"].max() > 256          # the small tables overflowed and the re-run produced the result
+    _check_against_oracle(core, images, rig["K"], dists, M_max=8, check_frames=False)
+
+
+def test_blank_and_saturated_frames(core):
+    images = np.zeros((1, 2, 240, 320, 3), dtype=np.uint8)
+    images[0, 1] = 255                             # one huge blob touching every border of the frame area
+    res = _check_against_oracle(core, images, [REF_K, REF_K], [synth.REFERENCE_DISTORTION] * 2)
+    assert res["counts"][0, 0] == 0
+
+
+def test_images_chain_into_frame_path_on_device(core):
+    """find_blobs_dev writes the frame path's input layout: images -> blobs -> 3-D points without
+    leaving HBM, and the points are the markers."""
+    import torch
+    rig = synth.ring_rig(4)
+    F, M = 6, 6
+    images, truth = synth.render_camera_frames(rig, F, M, seed=21, dropout=0.0)
+    core.set_cameras(rig["K"], rig["R"], rig["t"])
+    core.set_image_params(240, 320, rig["K"], [synth.REFERENCE_DISTORTION] * 4)
+    dev = torch.device("cuda", 0)
+    K_max, M_max = 32, 16
+    d_img = torch.from_numpy(images).to(dev)
+    d_blobs = torch.zeros((F, 4, M_max, 2), dtype=torch.float32, device=dev)
+    d_counts = torch.zeros((F, 4), dtype=torch.int32, device=dev)
+    d_bst = torch.zeros((F, 4), dtype=torch.int32, device=dev)
+    d_xyz = torch.zeros((F, K_max, 3), dtype=torch.float64, device=dev)
+    d_err = torch.zeros((F, K_max), dtype=torch.float64, device=dev)
+    d_corr = torch.zeros((F, K_max, 4), dtype=torch.int16, device=dev)
+    d_n = torch.zeros(F, dtype=torch.int32, device=dev)
+    d_st = torch.zeros(F, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    core.find_blobs_dev(F, d_img.data_ptr(), M_max, d_blobs.data_ptr(), d_counts.data_ptr(), d_bst.data_ptr())
+    core.match_triangulate_dev(F, M_max, d_blobs.data_ptr(), d_counts.data_ptr(), 5.0, K_max, 1 << 20,
+                               d_xyz.data_ptr(), d_err.data_ptr(), d_corr.data_ptr(), d_n.data_ptr(), d_st.data_ptr())
+    core.synchronize()
+    host = core.find_blobs(images, M_max=M_max)
+    assert np.array_equal(d_counts.cpu().numpy(), host["counts"])
+    assert np.array_equal(d_blobs.cpu().numpy(), host["blobs"])
+    n = d_n.cpu().numpy()
+    xyz = d_xyz.cpu().numpy()
+    assert not d_st.cpu().numpy().any()
+    hit = 0
+    for f in range(F):
+        pts = xyz[f, :n[f]]
+        for X in truth["points_cam0"][f]:
+            hit += np.linalg.norm(pts - X, axis=1).min() < 0.03      # int() centroids: ~1 px at 3 m
+    assert hit >= 0.8 * F * M, hit                                    # merged spots lose a marker

@@ -109,3 +109,62 @@ def test_post_rows_oracle_vs_reference_golden():
             assert np.array_equal(o["pos"], g["ref_pos"][f, j]) and o["droneIndex"] == g["ref_drone"][f, j]
             assert abs(o["heading"] - g["ref_heading"][f, j]) < 1e-12
             assert abs(o["error"] - g["ref_error"][f, j]) <= 1e-15
+
+
+# ----------------------------------------------------------------------------- blob extraction
+BLOB_SETS = golden_names("blobs_")
+
+
+@pytest.mark.parametrize("name", BLOB_SETS)
+def test_blob_oracle_matches_reference_golden(name):
+    """oracle/blob_oracle.py (restated rot90 / make_square / _find_dot) against the reference's own
+    _camera_read + _find_dot run through the harness: bit-exact frames, points and order."""
+    from oracle import blob_oracle as bo
+    g = load_golden(name)
+    for f in range(g["images"].shape[0]):
+        frames, pts = bo.find_dots(g["images"][f], g["K"], g["dist"], g["rotation"])
+        assert np.array_equal(np.array(frames), g["ref_frames"][f])
+        for c, p in enumerate(pts):
+            n = int(g["ref_counts"][f, c])
+            assert len(p) == n
+            assert np.array_equal(np.array(p, dtype=np.int32).reshape(n, 2), g["ref_points"][f, c, :n])
+
+
+def test_find_contours_structure_against_scipy_labelling():
+    """The restated findContours against an independent definition: one outer border per 8-connected
+    foreground component, one hole border per enclosed 4-connected background component, parents =
+    geometric containment, RETR_TREE order = pre-order with siblings in reverse raster order."""
+    from scipy import ndimage
+    from oracle import cv_image_restate as ci
+    rng = np.random.default_rng(0)
+    for trial in range(6):
+        m = (rng.random((40, 48)) < (0.35 + 0.08 * trial)).astype(np.uint8) * 255
+        contours, hier = ci.find_contours(m, ci.RETR_TREE, ci.CHAIN_APPROX_SIMPLE)
+        fg, n_fg = ndimage.label(m > 0, structure=np.ones((3, 3)))
+        pad = np.pad(m == 0, 1, constant_values=True)
+        bg, n_bg = ndimage.label(pad)                       # 4-connected; label of the outside = bg[0, 0]
+        holes = set(range(1, n_bg + 1)) - {bg[0, 0]}
+        is_hole = []
+        for i, c in enumerate(contours):
+            depth, p = 0, hier[0, i, 3]
+            while p >= 0:
+                depth, p = depth + 1, hier[0, p, 3]
+            is_hole.append(depth % 2 == 1)
+        assert sum(1 for h in is_hole if not h) == n_fg
+        assert sum(1 for h in is_hole if h) == len(holes)
+        for i, c in enumerate(contours):
+            x, y = c[0, 0]
+            comp = fg[y, x]
+            assert comp > 0                                 # contour vertices are foreground pixels
+            assert all(fg[py, px] == comp for px, py in c[:, 0])
+            par = hier[0, i, 3]
+            if is_hole[i]:
+                assert par >= 0 and fg[contours[par][0, 0][1], contours[par][0, 0][0]] == comp
+            elif par >= 0:
+                # an outer border inside a hole: the hole's border belongs to the enclosing component
+                assert is_hole[par]
+        # siblings at the top level come in reverse raster order of their first (start) vertex
+        top = [i for i in range(len(contours)) if hier[0, i, 3] < 0]
+        starts = [(contours[i][:, 0, 1].min(), ) for i in top]
+        assert starts == sorted(starts, reverse=True) or len(top) < 2 or all(
+            starts[k] >= starts[k + 1] for k in range(len(starts) - 1))
