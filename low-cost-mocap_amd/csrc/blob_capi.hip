@@ -90,26 +90,58 @@ int find_blobs_dev_locked(mocap_ctx* ctx, int64_t n_frames, const uint8_t* d_ima
   if (n_frames < 0 || M_max < 1) return ctx->fail(MOCAP_E_ARG, "mocap_find_blobs: bad size argument");
   if (n_frames == 0) return MOCAP_OK;
   if (!d_images || !d_blobs || !d_counts || !d_status) return ctx->fail(MOCAP_E_ARG, "mocap_find_blobs: null buffer");
+  // frame sets are processed in chunks: the squared-frame workspace of one chunk (~340 KB per image) stays
+  // in the 256 MB Infinity Cache between the pre-pass that writes it and the mask kernel that reads it
+  const int C = ctx->img_C, S = ctx->img_S;
+  const int64_t chunk_frames = (2048 / C) > 0 ? 2048 / C : 1;
+  const int64_t chunk_images = chunk_frames * C;
+  const size_t sq_img = (size_t)(S + 2) * (S + 2 * kSquarePad) * 3;
+  const int64_t want = n_frames * C < chunk_images ? n_frames * C : chunk_images;
+  if (ctx->img_sq_images < want) {
+    if (ctx->img_sq.reserve(sq_img * want)) return ctx->fail(MOCAP_E_HIP, "hipMalloc(squared frames, %zu B) failed", sq_img * want);
+    HIP_TRY(ctx, hipMemsetAsync(ctx->img_sq.ptr, 0, ctx->img_sq.cap, ctx->stream));  // the zero frame, once
+    ctx->img_sq_images = (int64_t)(ctx->img_sq.cap / sq_img);
+  }
+  const size_t words = (size_t)(S + 63) / 64;
+  if (ctx->img_mask.reserve((size_t)n_frames * C * S * words * 8)) return ctx->fail(MOCAP_E_HIP, "hipMalloc(mask) failed");
+  for (int64_t f0 = 0; f0 < n_frames; f0 += chunk_frames) {
+    const int64_t nf = n_frames - f0 < chunk_frames ? n_frames - f0 : chunk_frames;
+    const size_t i0 = (size_t)f0 * C;
+    BlobArgs a;
+    a.n_images = nf * C;
+    a.img_base = (int64_t)i0;
+    a.C = C;
+    a.rows = ctx->img_rows;
+    a.cols = ctx->img_cols;
+    a.S = S;
+    a.ay = ctx->img_ay;
+    a.M_max = M_max;
+    a.raw = d_images + i0 * ctx->img_rows * ctx->img_cols * 3;
+    a.rot = (const int32_t*)ctx->img_rot.ptr;
+    a.squared = (uint8_t*)ctx->img_sq.ptr;
+    a.gather = (const uint32_t*)ctx->img_tiles.ptr;
+    a.cam_lens = (const int32_t*)ctx->img_lens.ptr;
+    a.mask = (unsigned long long*)ctx->img_mask.ptr + i0 * S * words;
+    a.processed = d_processed ? d_processed + i0 * S * S * 3 : nullptr;
+    a.blobs = d_blobs + i0 * M_max * 2;
+    a.counts = d_counts + i0;
+    a.status = d_status + i0;
+    a.n_contours = d_n_contours ? d_n_contours + i0 : nullptr;
+    HIP_TRY(ctx, launch_blob_square(a, ctx->stream));
+    HIP_TRY(ctx, launch_blob_mask(a, ctx->stream));
+  }
+  // contours of the whole batch at once (one workgroup per image, reads only the 1-bit masks)
   BlobArgs a;
-  a.n_images = n_frames * ctx->img_C;
-  a.C = ctx->img_C;
-  a.rows = ctx->img_rows;
-  a.cols = ctx->img_cols;
-  a.S = ctx->img_S;
-  a.ay = ctx->img_ay;
+  memset(&a, 0, sizeof a);
+  a.n_images = n_frames * C;
+  a.C = C;
+  a.S = S;
   a.M_max = M_max;
-  a.raw = d_images;
-  a.map = (const uint32_t*)ctx->img_map.ptr;
-  a.rot = (const int32_t*)ctx->img_rot.ptr;
-  const size_t mask_bytes = (size_t)a.n_images * a.S * ((a.S + 63) / 64) * 8;
-  if (ctx->img_mask.reserve(mask_bytes)) return ctx->fail(MOCAP_E_HIP, "hipMalloc(mask, %zu B) failed", mask_bytes);
   a.mask = (unsigned long long*)ctx->img_mask.ptr;
-  a.processed = d_processed;
   a.blobs = d_blobs;
   a.counts = d_counts;
   a.status = d_status;
   a.n_contours = d_n_contours;
-  HIP_TRY(ctx, launch_blob_mask(a, ctx->stream));
   HIP_TRY(ctx, launch_blob_contours(a, kPCapSmall, kNCapSmall, 0, ctx->stream));
   // images whose border tables overflowed run again with the largest tables LDS holds; the launch is
   // a no-op (one status read per workgroup) for every other image
@@ -132,6 +164,7 @@ extern "C" int mocap_set_image_params(mocap_ctx* ctx, int C, int rows, int cols,
   if (cols != S || ay < 8 || S - ay - rows < 8)
     return ctx->fail(MOCAP_E_ARG, "frames must be landscape with >= 8 rows of square padding (reference make_square)");
   if (S > 1024) return ctx->fail(MOCAP_E_LIMIT, "frame edge %d exceeds 1024", S);
+  if (cols % 16) return ctx->fail(MOCAP_E_ARG, "frame width must be a multiple of 16");
   std::vector<int32_t> rot(C, 0);
   for (int c = 0; c < C; c++) {
     const int r = rotation ? ((rotation[c] % 4) + 4) % 4 : 0;
@@ -152,11 +185,54 @@ extern "C" int mocap_set_image_params(mocap_ctx* ctx, int C, int rows, int cols,
     else
       build_undistort_map(K + 9 * c, dist + 5 * c, S, map.data() + (size_t)c * S * S);
   }
-  if (ctx->img_map.reserve(map.size() * sizeof(uint32_t)) || ctx->img_rot.reserve(C * sizeof(int32_t)))
+  // gather tables of the mask kernel: per distinct lens and 64 x 64 tile, for each pixel of the tile's
+  // 76 x 76 region (reflect-101 of cv::GaussianBlur / cv::filter2D applied here, once) the byte offset of
+  // the top-left bilinear tap inside a zero-framed squared frame, and the 1/32-px fractions
+  const int tiles = (S + kBlobTile - 1) / kBlobTile;
+  const int WP = S + 2 * kSquarePad, RW = kBlobTile + 2 * kBlobHalo;
+  std::vector<int32_t> lens(C, 0);
+  std::vector<int> lens_cam;  // first camera of each distinct lens
+  for (int c = 0; c < C; c++) {
+    int same = -1;
+    for (size_t l = 0; l < lens_cam.size() && same < 0; l++)
+      if (!memcmp(map.data() + (size_t)lens_cam[l] * S * S, map.data() + (size_t)c * S * S, sizeof(uint32_t) * S * S)) same = (int)l;
+    if (same < 0) {
+      same = (int)lens_cam.size();
+      lens_cam.push_back(c);
+    }
+    lens[c] = same;
+  }
+  std::vector<uint32_t> gather(lens_cam.size() * tiles * tiles * (size_t)kBlobGather, 0u);
+  auto refl = [S](int i) {
+    i = i < 0 ? -i : i;
+    i = i >= S ? 2 * (S - 1) - i : i;
+    return i < 0 ? 0 : (i >= S ? S - 1 : i);
+  };
+  for (size_t l = 0; l < lens_cam.size(); l++)
+    for (int t = 0; t < tiles * tiles; t++) {
+      const int ty0 = (t / tiles) * kBlobTile, tx0 = (t % tiles) * kBlobTile;
+      uint32_t* g = gather.data() + (l * tiles * tiles + t) * (size_t)kBlobGather;
+      for (int vy = 0; vy < RW; vy++)
+        for (int vx = 0; vx < RW; vx++) {
+          const uint32_t m = map[((size_t)lens_cam[l] * S + refl(ty0 - kBlobHalo + vy)) * S + refl(tx0 - kBlobHalo + vx)];
+          const int sxp = (m >> 10) & 2047;
+          uint32_t e = 0;  // every tap outside: offset 0 = the zero frame, fractions 0
+          if (sxp != 2047) {
+            const int sx = sxp - 1, sy = (int)(m >> 21) - 1;  // -1 .. S-1: row/column -1 and S are the zero frame
+            e = (uint32_t)(((sy + 1) * WP + sx + kSquarePad) * 3) | (m & 31u) << 22 | ((m >> 5) & 31u) << 27;
+          }
+          g[vy * RW + vx] = e;
+        }
+    }
+  if (ctx->img_map.reserve(map.size() * sizeof(uint32_t)) || ctx->img_rot.reserve(C * sizeof(int32_t)) ||
+      ctx->img_tiles.reserve(gather.size() * sizeof(uint32_t)) || ctx->img_lens.reserve(C * sizeof(int32_t)))
     return ctx->fail(MOCAP_E_HIP, "hipMalloc(undistortion maps) failed");
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->img_tiles.ptr, gather.data(), gather.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->img_lens.ptr, lens.data(), C * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(ctx->img_map.ptr, map.data(), map.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(ctx->img_rot.ptr, rot.data(), C * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->img_S != S) ctx->img_sq_images = 0;  // the zero frame of the squared workspace has another shape
   ctx->img_C = C;
   ctx->img_rows = rows;
   ctx->img_cols = cols;

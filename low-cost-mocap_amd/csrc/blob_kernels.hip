@@ -8,7 +8,7 @@
 //                                          cv.moments per contour, int() centroid if m00 != 0
 //
 // Every OpenCV stage on 8-bit images is integer / fixed-point arithmetic; it is restated here exactly
-// (oracle/cv_image_restate.py documents each formula and its OpenCV source):
+// (DESIGN.md section 3.5 lists each formula with its OpenCV source file):
 //   undistort  = gather through a frame-invariant fixed-point map (built once per camera on the host,
 //                blob_capi.hip) with 1/32-px bilinear weights:  (sum w*p + 512) >> 10
 //   Gaussian   = separable [4 13 30 51 60 51 30 13 4] / 256, (sum + 32768) >> 16, reflect-101 borders
@@ -28,20 +28,23 @@
 //                         contour and accumulates the Green's-theorem sums (exact integers).  Parents come
 //                         from the pair met by walking left on the start row (Suzuki's LNBD rule, stated
 //                         geometrically), output order = pre-order with siblings in reverse discovery order
-//                         (cvInsertNodeIntoTree).  The C oracle (oracle/c) uses the sequential algorithm, so
-//                         two independent algorithms cross-check each other in the parity tests.
+//                         (cvInsertNodeIntoTree).  The parity tests check it against the sequential
+//                         raster-scan algorithm: two independent algorithms cross-check each other.
 #include "kernels.hpp"
 
 namespace mocap {
 
 namespace {
 
-constexpr int BT = 64;              // output tile edge
+constexpr int BT = kBlobTile;        // output tile edge
 constexpr int HG = 4, HF = 2;       // halos of the 9x9 Gaussian and the 5x5 filter
+static_assert(HG + HF == kBlobHalo, "halo");
 constexpr int UW = BT + 2 * (HG + HF);  // 76: undistorted region edge
-constexpr int UP = 80;              // its padded row stride (bytes)
+static_assert(UW * UW == kBlobRegion, "region");
+constexpr int UP = UW;              // its row stride: region index = LDS offset (the row pass over-reads <= 4 bytes)
 constexpr int BW = BT + 2 * HF;     // 68: blurred region edge
 constexpr int BP = 72;              // its padded row stride (bytes)
+constexpr int VT = 78;              // stride (u16) of the column-major row-pass result: 76 rows + pad
 constexpr int kBlobThreads = 256;
 
 __device__ __forceinline__ int reflect101(int i, int n) {
@@ -49,119 +52,220 @@ __device__ __forceinline__ int reflect101(int i, int n) {
   return i >= n ? 2 * (n - 1) - i : i;
 }
 
-// one pixel of the squared frame (helpers.py:507-523) read straight from the raw frame:
-// rows [ay, ay+rows) are the frame, 8 feathered rows above/below are edge rows * (7-i)/8, the rest is 0
-__device__ __forceinline__ void squared_px(const uint8_t* __restrict__ raw, int rows, int cols, int ay, int rot,
-                                           int Y, int X, int& r, int& g, int& b) {
-  r = g = b = 0;
-  if ((unsigned)X >= (unsigned)cols || (unsigned)Y >= (unsigned)cols) return;
-  int rr = Y - ay, scale = 8;
-  if (rr < 0) {
-    scale = 8 + rr;  // rr = -1 -> 7/8 ... rr = -8 -> 0
-    rr = 0;
-  } else if (rr >= rows) {
-    scale = 7 - (rr - rows);
-    rr = rows - 1;
-  }
-  if (scale <= 0) return;
-  int cc = X;
-  if (rot == 2) {
-    rr = rows - 1 - rr;
-    cc = cols - 1 - cc;
-  }
-  const uint8_t* p = raw + ((size_t)rr * cols + cc) * 3;
-  r = (p[0] * scale) >> 3;
-  g = (p[1] * scale) >> 3;
-  b = (p[2] * scale) >> 3;
-}
-
 }  // namespace
 
+// packed tap weights (byte 0 = first tap)
+constexpr uint32_t pk4(int a, int b, int c, int d) {
+  return (uint32_t)(a & 0xff) | (uint32_t)(b & 0xff) << 8 | (uint32_t)(c & 0xff) << 16 | (uint32_t)(d & 0xff) << 24;
+}
+typedef unsigned short v2u16 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t udot2(uint32_t a, uint32_t b, uint32_t c) {
+  return __builtin_amdgcn_udot2(__builtin_bit_cast(v2u16, a), __builtin_bit_cast(v2u16, b), c, false);
+}
+
+// ---- pre-pass: np.rot90 (k = 0 or 2) + make_square (helpers.py:507-523) into the zero-framed layout the
+// gather tables address.  One workgroup per image; only the frame rows and the 2 x 8 feathered rows are
+// written (edge row * (7 - i) / 8, truncated), the zero frame and the empty rows are set once at allocation.
+constexpr int kSquareRows = 16;  // squared rows per workgroup (4 per wave)
+__global__ __launch_bounds__(kBlobThreads) void blob_square_kernel(BlobArgs a) {
+  const int first = a.ay - 8, n_rows = a.rows + 16;  // squared rows [first, first + n_rows)
+  const int groups = (n_rows + kSquareRows - 1) / kSquareRows;
+  const int64_t img = blockIdx.x / groups;
+  const int grp = blockIdx.x % groups;
+  const int cam = (int)((a.img_base + img) % a.C);
+  const int rot = a.rot[cam];
+  const int S = a.S, WP = S + 2 * kSquarePad;
+  const uint8_t* raw = a.raw + (size_t)img * a.rows * a.cols * 3;
+  uint8_t* sq = a.squared + (size_t)img * (S + 2) * WP * 3;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int row_bytes = a.cols * 3;
+#pragma unroll
+  for (int k = 0; k < kSquareRows / 4; k++) {
+    const int Y = first + grp * kSquareRows + wave * (kSquareRows / 4) + k;
+    if (Y >= first + n_rows) break;
+    int r = Y - a.ay, scale = 8;
+    if (r < 0) {
+      scale = 8 + r;  // r = -1 -> 7/8 ... r = -8 -> 0
+      r = 0;
+    } else if (r >= a.rows) {
+      scale = 7 - (r - a.rows);
+      r = a.rows - 1;
+    }
+    uint8_t* dst = sq + ((size_t)(Y + 1) * WP + kSquarePad) * 3;
+    if (rot == 0) {
+      // 16 bytes per lane: rows start 16-byte aligned in both layouts (cols % 16 == 0 checked by the host)
+      const uint8_t* src = raw + (size_t)r * row_bytes;
+      for (int i = lane * 16; i < row_bytes; i += 64 * 16) {
+        uint4 v = *(const uint4*)(src + i);
+        if (scale != 8) {
+          uint32_t* w = (uint32_t*)&v;
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const uint32_t e = ((w[q] & 0x00ff00ffu) * (uint32_t)scale) >> 3 & 0x00ff00ffu;
+            const uint32_t o = (((w[q] >> 8) & 0x00ff00ffu) * (uint32_t)scale) >> 3 & 0x00ff00ffu;
+            w[q] = e | o << 8;
+          }
+        }
+        *(uint4*)(dst + i) = v;
+      }
+    } else {  // rot90 k = 2: rows and columns reversed
+      const uint8_t* src = raw + (size_t)(a.rows - 1 - r) * row_bytes;
+      for (int x = lane; x < a.cols; x += 64) {
+        const uint8_t* p = src + (size_t)(a.cols - 1 - x) * 3;
+        dst[3 * x] = (uint8_t)((p[0] * scale) >> 3);
+        dst[3 * x + 1] = (uint8_t)((p[1] * scale) >> 3);
+        dst[3 * x + 2] = (uint8_t)((p[2] * scale) >> 3);
+      }
+    }
+  }
+}
+
+hipError_t launch_blob_square(const BlobArgs& a, hipStream_t stream) {
+  if (a.n_images <= 0) return hipSuccess;
+  const int groups = (a.rows + 16 + kSquareRows - 1) / kSquareRows;
+  hipLaunchKernelGGL(blob_square_kernel, dim3((unsigned)(a.n_images * groups)), dim3(kBlobThreads), 0, stream, a);
+  return hipGetLastError();
+}
+
 __global__ __launch_bounds__(kBlobThreads) void blob_mask_kernel(BlobArgs a) {
-  __shared__ uint8_t U[3][UW * UP];
-  __shared__ uint16_t Hh[UW * BW];
-  __shared__ uint8_t Bl[BW * BP];
+  __shared__ __attribute__((aligned(16))) uint8_t U[3][UW * UP + 4];  // undistorted region, row-major (+4: over-read of the last row)
+  __shared__ __attribute__((aligned(16))) uint16_t Vt[BW * VT];   // row-pass result, COLUMN-major (8.8 fixed point)
+  __shared__ __attribute__((aligned(16))) uint8_t Bl[BW * BP];    // blurred region, row-major, stored as value - 128
   const int tid = threadIdx.x;
   const int S = a.S;
   const int tiles = (S + BT - 1) / BT;
   const int64_t img = blockIdx.x / (tiles * tiles);
   const int tile = blockIdx.x % (tiles * tiles);
   const int ty0 = (tile / tiles) * BT, tx0 = (tile % tiles) * BT;
-  const int cam = (int)(img % a.C);
-  const uint8_t* raw = a.raw + (size_t)img * a.rows * a.cols * 3;
-  const uint32_t* map = a.map + (size_t)cam * S * S;
-  const int rot = a.rot[cam];
+  const int cam = (int)((a.img_base + img) % a.C);
+  const int WP = S + 2 * kSquarePad;
+  const uint8_t* sq = a.squared + (size_t)img * (S + 2) * WP * 3;
+  const uint32_t* tab = a.gather + ((size_t)a.cam_lens[cam] * tiles * tiles + tile) * kBlobGather;
+  const uint32_t row_bytes = (uint32_t)WP * 3;
 
-  // ---- A: undistorted region, reflect-101 applied while filling so later stages are plain windows
-  for (int idx = tid; idx < UW * UW; idx += kBlobThreads) {
-    const int vy = idx / UW, vx = idx - vy * UW;
-    int Y = reflect101(ty0 - (HG + HF) + vy, S), X = reflect101(tx0 - (HG + HF) + vx, S);
-    Y = Y < 0 ? 0 : (Y >= S ? S - 1 : Y);  // partial tiles: positions nobody reads
-    X = X < 0 ? 0 : (X >= S ? S - 1 : X);
-    const uint32_t m = map[(size_t)Y * S + X];
-    int o0 = 0, o1 = 0, o2 = 0;
-    const int sxp = (m >> 10) & 2047;
-    if (sxp != 2047) {
-      const int fx = m & 31, fy = (m >> 5) & 31, sx = sxp - 1, sy = (int)(m >> 21) - 1;
-      const int w00 = (32 - fx) * (32 - fy), w01 = fx * (32 - fy), w10 = (32 - fx) * fy, w11 = fx * fy;
-      int r0, g0, b0, r1, g1, b1, r2, g2, b2, r3, g3, b3;
-      squared_px(raw, a.rows, a.cols, a.ay, rot, sy, sx, r0, g0, b0);
-      squared_px(raw, a.rows, a.cols, a.ay, rot, sy, sx + 1, r1, g1, b1);
-      squared_px(raw, a.rows, a.cols, a.ay, rot, sy + 1, sx, r2, g2, b2);
-      squared_px(raw, a.rows, a.cols, a.ay, rot, sy + 1, sx + 1, r3, g3, b3);
-      o0 = (w00 * r0 + w01 * r1 + w10 * r2 + w11 * r3 + 512) >> 10;
-      o1 = (w00 * g0 + w01 * g1 + w10 * g2 + w11 * g3 + 512) >> 10;
-      o2 = (w00 * b0 + w01 * b1 + w10 * b2 + w11 * b3 + 512) >> 10;
-    }
-    U[0][vy * UP + vx] = (uint8_t)o0;
-    U[1][vy * UP + vx] = (uint8_t)o1;
-    U[2][vy * UP + vx] = (uint8_t)o2;
+  // ---- A: undistorted region = table-driven bilinear gather from the squared frame.  The table already
+  // holds the reflect-101 of the region, the tap address and the 1/32-px fractions; the zero frame of the
+  // squared layout is cv::remap's BORDER_CONSTANT.  Software-pipelined: all table words of a chunk, then
+  // all pixel loads (two unaligned 8-byte loads = 2 x 2 RGB pixels), then the arithmetic.
+  constexpr int CH = 8;
+#pragma unroll
+  for (int base = 0; base < kBlobGather; base += CH * kBlobThreads) {
+    constexpr int kIters = kBlobGather / kBlobThreads;
+    uint32_t mm[CH];
+    unsigned long long tt[CH], bb[CH];
+#pragma unroll
+    for (int k = 0; k < CH; k++)
+      if (base / kBlobThreads + k < kIters) mm[k] = tab[base + k * kBlobThreads + tid];
+#pragma unroll
+    for (int k = 0; k < CH; k++)
+      if (base / kBlobThreads + k < kIters) {
+        const uint8_t* p = sq + (mm[k] & 0x3fffffu);
+        __builtin_memcpy(&tt[k], p, 8);
+        __builtin_memcpy(&bb[k], p + row_bytes, 8);
+      }
+#pragma unroll
+    for (int k = 0; k < CH; k++)
+      if (base / kBlobThreads + k < kIters) {
+        const int idx = base + k * kBlobThreads + tid;
+        // (32-fy) [(32-fx) p00 + fx p01] + fy [(32-fx) p10 + fx p11] = the four-weight sum of cv::remap's
+        // BilinearTab_i (weights (32-fx)(32-fy)*32 ... summing to 32768), then (sum*32 + 16384) >> 15.
+        // R and B ride in one register as two 16-bit fields (each partial sum < 2^13).
+        const uint32_t fx = (mm[k] >> 22) & 31u, fy = mm[k] >> 27, gx = 32u - fx, gy = 32u - fy;
+        const uint32_t tl = (uint32_t)tt[k], th = (uint32_t)(tt[k] >> 32), bl = (uint32_t)bb[k], bh = (uint32_t)(bb[k] >> 32);
+        const uint32_t t_rb = gx * (tl & 0x00ff00ffu) + fx * __builtin_amdgcn_perm(th, tl, 0x0c050c03u);
+        const uint32_t t_g = gx * ((tl >> 8) & 0xffu) + fx * (th & 0xffu);
+        const uint32_t b_rb = gx * (bl & 0x00ff00ffu) + fx * __builtin_amdgcn_perm(bh, bl, 0x0c050c03u);
+        const uint32_t b_g = gx * ((bl >> 8) & 0xffu) + fx * (bh & 0xffu);
+        const uint32_t o_r = (gy * (t_rb & 0xffffu) + fy * (b_rb & 0xffffu) + 512u) >> 10;
+        const uint32_t o_g = (gy * t_g + fy * b_g + 512u) >> 10;
+        const uint32_t o_b = (gy * (t_rb >> 16) + fy * (b_rb >> 16) + 512u) >> 10;
+        if (idx < kBlobRegion) {
+          U[0][idx] = (uint8_t)o_r;
+          U[1][idx] = (uint8_t)o_g;
+          U[2][idx] = (uint8_t)o_b;
+        }
+      }
   }
   __syncthreads();
 
-  // lane -> output pixels: x = lane % 64, rows (lane / 64) + 4 j: one wave covers one tile row at a time
-  const int px = tid & 63, py0 = tid >> 6;
-  int grey[BT / 4];
+  // lane -> output pixels: x = lane % 64, rows 16 (lane / 64) + j: one wave covers one tile row at a time
+  const int px = tid & 63, wv = tid >> 6;
+  int grey[16];
 #pragma unroll
-  for (int j = 0; j < BT / 4; j++) grey[j] = 0;
+  for (int j = 0; j < 16; j++) grey[j] = 0;
   uint8_t* proc = a.processed ? a.processed + (size_t)img * S * S * 3 : nullptr;
+
+  constexpr uint32_t G0 = pk4(4, 13, 30, 51), G1 = pk4(60, 51, 30, 13), G2 = pk4(4, 0, 0, 0);  // Gaussian taps 0..8
+  constexpr uint32_t P0 = 4u | 13u << 16, P1 = 30u | 51u << 16, P2 = 60u | 51u << 16, P3 = 30u | 13u << 16, P4 = 4u;
+  // rows of the 5x5 sharpening kernel (helpers.py:76-80): rows 0/4, rows 1/3, row 2
+  constexpr uint32_t KA0 = pk4(-2, -1, -1, -1), KA1 = pk4(-2, 0, 0, 0);
+  constexpr uint32_t KB0 = pk4(-1, 1, 3, 1), KB1 = pk4(-1, 0, 0, 0);
+  constexpr uint32_t KC0 = pk4(-1, 3, 4, 3), KC1 = pk4(-1, 0, 0, 0);
 
   for (int ch = 0; ch < 3; ch++) {
     const uint8_t* Uc = U[ch];
-    // ---- B1: row pass (ufixedpoint16, exact: <= 255 * 256)
-    for (int idx = tid; idx < UW * BW; idx += kBlobThreads) {
-      const int r = idx / BW, c = idx - r * BW;
-      const uint8_t* u = Uc + r * UP + c;
-      const int h = 60 * u[4] + 51 * (u[3] + u[5]) + 30 * (u[2] + u[6]) + 13 * (u[1] + u[7]) + 4 * (u[0] + u[8]);
-      Hh[idx] = (uint16_t)h;
+    // ---- B1: row pass, 4 outputs per lane from 16 bytes (v_dot4_u32_u8); exact in 16 bits (<= 255 * 256)
+    for (int it = tid; it < UW * (BW / 4); it += kBlobThreads) {
+      const int r = it / (BW / 4), c = 4 * (it - r * (BW / 4));
+      const uint32_t* u = (const uint32_t*)(Uc + r * UP + c);
+      const uint32_t d0 = u[0], d1 = u[1], d2 = u[2], d3 = u[3];
+      uint16_t* out = Vt + c * VT + r;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const uint32_t w0 = j ? __builtin_amdgcn_alignbyte(d1, d0, j) : d0;
+        const uint32_t w1 = j ? __builtin_amdgcn_alignbyte(d2, d1, j) : d1;
+        const uint32_t w2 = j ? __builtin_amdgcn_alignbyte(d3, d2, j) : d2;
+        const uint32_t h = __builtin_amdgcn_udot4(w0, G0, __builtin_amdgcn_udot4(w1, G1, __builtin_amdgcn_udot4(w2, G2, 0u, false), false), false);
+        out[j * VT] = (uint16_t)h;
+      }
     }
     __syncthreads();
-    // ---- B2: column pass (ufixedpoint32), rounding shift
-    for (int idx = tid; idx < BW * BW; idx += kBlobThreads) {
-      const int r = idx / BW, c = idx - r * BW;
-      const uint16_t* h = Hh + r * BW + c;
-      const int v = 60 * h[4 * BW] + 51 * (h[3 * BW] + h[5 * BW]) + 30 * (h[2 * BW] + h[6 * BW]) +
-                    13 * (h[1 * BW] + h[7 * BW]) + 4 * (h[0] + h[8 * BW]);
-      Bl[r * BP + c] = (uint8_t)((v + 32768) >> 16);
+    // ---- B2: column pass, 4 outputs per lane from 14 values (v_dot2_u32_u16).  The accumulator starts at
+    // 32768 + (128 << 16): rounding of (sum + 32768) >> 16 and the "- 128" of the signed store in one
+    for (int it = tid; it < BW * (BW / 4); it += kBlobThreads) {
+      const int m = it / BW, x = it - m * BW;
+      const uint32_t* v = (const uint32_t*)(Vt + x * VT + 4 * m);
+      uint32_t e[7];
+#pragma unroll
+      for (int i = 0; i < 7; i++) e[i] = v[i];
+      uint32_t q[6];
+#pragma unroll
+      for (int i = 0; i < 6; i++) q[i] = __builtin_amdgcn_alignbyte(e[i + 1], e[i], 2);
+      constexpr uint32_t R0 = 32768u + (128u << 16);
+      const uint32_t s0 = udot2(e[0], P0, udot2(e[1], P1, udot2(e[2], P2, udot2(e[3], P3, udot2(e[4], P4, R0)))));
+      const uint32_t s1 = udot2(q[0], P0, udot2(q[1], P1, udot2(q[2], P2, udot2(q[3], P3, udot2(q[4], P4, R0)))));
+      const uint32_t s2 = udot2(e[1], P0, udot2(e[2], P1, udot2(e[3], P2, udot2(e[4], P3, udot2(e[5], P4, R0)))));
+      const uint32_t s3 = udot2(q[1], P0, udot2(q[2], P1, udot2(q[3], P2, udot2(q[4], P3, udot2(q[5], P4, R0)))));
+      uint8_t* o = Bl + (4 * m) * BP + x;
+      o[0] = (uint8_t)(s0 >> 16);  // value - 128 (mod 256): the 5x5 kernel sums to 0, so the offset cancels
+      o[BP] = (uint8_t)(s1 >> 16);
+      o[2 * BP] = (uint8_t)(s2 >> 16);
+      o[3 * BP] = (uint8_t)(s3 >> 16);
     }
     __syncthreads();
-    // ---- B3: 5x5 sharpening kernel (helpers.py:76-80) = -(sum of the 25) - corners + 2 d + 4 e + 5 centre
+    // ---- B3: 5x5 kernel as three 5-tap row filters per blurred row (v_dot4c_i32_i8), accumulated straight
+    // into the output rows they belong to
+    int acc[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) acc[j] = 0;
+    const int sh = px & 3;
+#pragma unroll
+    for (int t = 0; t < 20; t++) {
+      const uint32_t* b = (const uint32_t*)(Bl + (16 * wv + t) * BP + (px & ~3));
+      const uint32_t lo = b[0], hi = b[1];
+      const int w0 = (int)__builtin_amdgcn_alignbyte(hi, lo, sh), w1 = (int)(hi >> (8 * sh));
+      if (t < 16) acc[t] = __builtin_amdgcn_sdot4(w0, (int)KA0, __builtin_amdgcn_sdot4(w1, (int)KA1, acc[t], false), false);
+      if (t >= 1 && t - 1 < 16) acc[t - 1] = __builtin_amdgcn_sdot4(w0, (int)KB0, __builtin_amdgcn_sdot4(w1, (int)KB1, acc[t - 1], false), false);
+      if (t >= 2 && t - 2 < 16) acc[t - 2] = __builtin_amdgcn_sdot4(w0, (int)KC0, __builtin_amdgcn_sdot4(w1, (int)KC1, acc[t - 2], false), false);
+      if (t >= 3 && t - 3 < 16) acc[t - 3] = __builtin_amdgcn_sdot4(w0, (int)KB0, __builtin_amdgcn_sdot4(w1, (int)KB1, acc[t - 3], false), false);
+      if (t >= 4) acc[t - 4] = __builtin_amdgcn_sdot4(w0, (int)KA0, __builtin_amdgcn_sdot4(w1, (int)KA1, acc[t - 4], false), false);
+    }
     const int coef = ch == 0 ? 3735 : (ch == 1 ? 19235 : 9798);  // raw R ends up where RGB2GRAY reads "B"
 #pragma unroll
-    for (int j = 0; j < BT / 4; j++) {
-      const int y = py0 + 4 * j;
-      const uint8_t* b = Bl + y * BP + px;
-      int s = 0;
-#pragma unroll
-      for (int i = 0; i < 5; i++)
-#pragma unroll
-        for (int k = 0; k < 5; k++) s += b[i * BP + k];
-      const int corners = b[0] + b[4] + b[4 * BP] + b[4 * BP + 4];
-      const int diag = b[BP + 1] + b[BP + 3] + b[3 * BP + 1] + b[3 * BP + 3];
-      const int edge = b[BP + 2] + b[2 * BP + 1] + b[2 * BP + 3] + b[3 * BP + 2];
-      int f = -s - corners + 2 * diag + 4 * edge + 5 * b[2 * BP + 2];
-      f = f < 0 ? 0 : (f > 255 ? 255 : f);
+    for (int j = 0; j < 16; j++) {
+      const int f = acc[j] < 0 ? 0 : (acc[j] > 255 ? 255 : acc[j]);
       grey[j] += coef * f;
+      const int y = 16 * wv + j;
       if (proc && ty0 + y < S && tx0 + px < S)
         proc[((size_t)(ty0 + y) * S + tx0 + px) * 3 + (2 - ch)] = (uint8_t)f;  // RGB2BGR (helpers.py:82)
     }
@@ -172,8 +276,8 @@ __global__ __launch_bounds__(kBlobThreads) void blob_mask_kernel(BlobArgs a) {
   const int words = (S + 63) / 64;
   unsigned long long* mask = a.mask + (size_t)img * S * words;
 #pragma unroll
-  for (int j = 0; j < BT / 4; j++) {
-    const int y = py0 + 4 * j;
+  for (int j = 0; j < 16; j++) {
+    const int y = 16 * wv + j;
     const bool on = ((grey[j] + 16384) >> 15) > 51 && tx0 + px < S;
     const unsigned long long w = __ballot(on);
     if (px == 0 && ty0 + y < S) mask[(size_t)(ty0 + y) * words + tx0 / 64] = w;

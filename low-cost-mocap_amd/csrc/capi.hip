@@ -98,6 +98,9 @@ extern "C" void mocap_destroy(mocap_ctx* ctx) {
   ctx->img_rot.release();
   ctx->img_mask.release();
   ctx->img_stage.release();
+  ctx->img_tiles.release();
+  ctx->img_lens.release();
+  ctx->img_sq.release();
   ctx->world.release();
   if (ctx->ba_pin) (void)hipHostFree(ctx->ba_pin);
   if (ctx->ba_event) (void)hipEventDestroy(ctx->ba_event);

@@ -76,14 +76,26 @@ hipError_t launch_locate_objects(const LocateArgs& a, hipStream_t stream);
 // blob extraction, the step before the frame path (reference helpers.py:68-82, 143-163), csrc/blob_kernels.hip
 constexpr int BLOB_ST_POINT_OVERFLOW_ = 1;  // more centroids than M_max: the first M_max are kept
 constexpr int BLOB_ST_CAP_OVERFLOW_ = 2;    // more border pairs / contours than the workgroup's tables hold
+constexpr int kBlobTile = 64;  // output tile edge of blob_mask_kernel
+constexpr int kBlobHalo = 6;   // 4 (9x9 Gaussian) + 2 (5x5 filter)
+constexpr int kBlobRegion = (kBlobTile + 2 * kBlobHalo) * (kBlobTile + 2 * kBlobHalo);  // 5776 region pixels per tile
+constexpr int kBlobGather = ((kBlobRegion + 255) / 256) * 256;  // gather-table entries per tile (padded to 256)
+constexpr int kSquarePad = 16;  // zero pixels left and right of a squared-frame row (keeps rows 16-byte aligned)
 struct BlobArgs {
-  int64_t n_images;        // F * C, camera = image % C
+  int64_t n_images;        // images of this launch; camera = (img_base + image) % C
+  int64_t img_base;        // index of the launch's first image in the caller's batch
   int C, rows, cols;       // raw frame size
   int S, ay;               // squared frame edge (= cols), first frame row inside it
   int M_max;
   const uint8_t* raw;      // [n_images][rows][cols][3] RGB
-  const uint32_t* map;     // [C][S][S] undistortion map: fx | fy << 5 | (sx + 1) << 10 | (sy + 1) << 21
   const int32_t* rot;      // [C] quarter turns (0 or 2)
+  // squared frames (helpers.py:507-523) with a zero frame around them: [n_images][S + 2][S + 2 * kSquarePad][3];
+  // only the frame and feather rows are rewritten per image, everything else stays zero
+  uint8_t* squared;
+  // per (distinct lens, tile): for each pixel of the tile's 76 x 76 region (reflect-101 already applied)
+  // byte offset of the top-left tap in a squared frame | fx << 22 | fy << 27
+  const uint32_t* gather;
+  const int32_t* cam_lens;   // [C] index of the camera's lens table
   unsigned long long* mask;  // [n_images][S][ceil(S / 64)] thresholded frame, 1 bit per pixel
   uint8_t* processed;      // [n_images][S][S][3] BGR frame as the reference streams it, or null
   float* blobs;            // [n_images][M_max][2]
@@ -91,6 +103,7 @@ struct BlobArgs {
   int32_t* status;         // [n_images]
   int32_t* n_contours;     // [n_images] or null
 };
+hipError_t launch_blob_square(const BlobArgs& a, hipStream_t stream);
 hipError_t launch_blob_mask(const BlobArgs& a, hipStream_t stream);
 hipError_t launch_blob_contours(const BlobArgs& a, int P_cap, int N_cap, int only_overflowed, hipStream_t stream);
 size_t blob_contour_lds_bytes(int S, int P_cap, int N_cap);
