@@ -121,6 +121,86 @@ def frame_latency(core, blobs, counts, n=300):
                     "includes the Python/ctypes call overhead)"}
 
 
+def blob_stage_bench(core, dev, stream, steps=5, frames=1024, distinct=16):
+    """The row before the path: raw 8-camera PS3-Eye frame sets (240 x 320 RGB, resident in
+    HBM) -> blob centroids (mocap_find_blobs_dev), and the chain images -> blobs -> 3-D markers without
+    leaving HBM.  Secondary figures; the headline metric starts from blobs."""
+    import torch
+    from oracle import c_oracle
+    C, M, M_max, K_MAX = CAMS, MARKERS, 32, 48
+    rig = synth.ring_rig(C)
+    images, _ = synth.render_camera_frames(rig, distinct, M, seed=1)
+    dists = [synth.REFERENCE_DISTORTION] * C
+    core.set_cameras(rig["K"], rig["R"], rig["t"])
+    core.set_image_params(240, 320, rig["K"], dists)
+    core.set_stream(stream.cuda_stream)
+    F = frames
+    d_img = torch.from_numpy(images).to(dev).repeat((F + distinct - 1) // distinct, 1, 1, 1, 1)[:F].contiguous()
+    d_blobs = torch.zeros((F, C, M_max, 2), dtype=torch.float32, device=dev)
+    d_counts = torch.zeros((F, C), dtype=torch.int32, device=dev)
+    d_bst = torch.zeros((F, C), dtype=torch.int32, device=dev)
+    d_xyz = torch.empty((F, K_MAX, 3), dtype=torch.float64, device=dev)
+    d_err = torch.empty((F, K_MAX), dtype=torch.float64, device=dev)
+    d_corr = torch.empty((F, K_MAX, C), dtype=torch.int16, device=dev)
+    d_nout = torch.zeros(F, dtype=torch.int32, device=dev)
+    d_st = torch.zeros(F, dtype=torch.int32, device=dev)
+
+    def blobs_only():
+        core.find_blobs_dev(F, d_img.data_ptr(), M_max, d_blobs.data_ptr(), d_counts.data_ptr(), d_bst.data_ptr())
+
+    def chain():
+        blobs_only()
+        core.match_triangulate_dev(F, M_max, d_blobs.data_ptr(), d_counts.data_ptr(), 5.0, K_MAX, G_CAP,
+                                   d_xyz.data_ptr(), d_err.data_ptr(), d_corr.data_ptr(), d_nout.data_ptr(),
+                                   d_st.data_ptr())
+
+    def timed(fn):
+        fn()
+        torch.cuda.synchronize(dev)
+        ts = []
+        for _ in range(steps):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(stream)
+            fn()
+            b.record(stream)
+            torch.cuda.synchronize(dev)
+            ts.append(a.elapsed_time(b))
+        return float(np.median(ts))
+
+    ms_b = timed(blobs_only)
+    ms_c = timed(chain)
+    n_img = F * C
+    in_bytes = n_img * 240 * 320 * 3
+    out_bytes = int(d_counts.sum().item()) * 8 + n_img * 8
+    # parity gate: the first frame sets against the C oracle (sequential contours)
+    nchk = 2
+    ref = c_oracle.BlobOracle(240, 320, rig["K"], dists).find_blobs(images[:nchk], M_max=M_max)
+    got_c, got_b = d_counts[:nchk].cpu().numpy(), d_blobs[:nchk].cpu().numpy()
+    t0 = time.perf_counter()
+    ncpu = 0
+    bo = c_oracle.BlobOracle(240, 320, rig["K"], dists)
+    while time.perf_counter() - t0 < 4.0 and ncpu < distinct:
+        bo.find_blobs(images[ncpu:ncpu + 1], M_max=M_max)
+        ncpu += 1
+    cpu_rate = ncpu * C / (time.perf_counter() - t0)
+    return {"metric": "camera images/s, raw RGB frames -> blob centroids (helpers.py:68-82,143-163)",
+            "value": n_img / ms_b * 1e3, "frame_sets_per_s": F / ms_b * 1e3, "ms_per_batch": ms_b,
+            "images_per_batch": n_img, "markers_per_frame_set": MARKERS,
+            "roofline": {"bound": "hbm", "achieved": (in_bytes + out_bytes) / ms_b / 1e6, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": (in_bytes + out_bytes) / ms_b / 1e6 / HBM_PEAK_GBS,
+                         "algorithmic_bytes_per_image": 240 * 320 * 3 + 8,
+                         "note": "integer-VALU bound (9x9 + 5x5 filters on 3 channels: ~180 ops/pixel); "
+                                 "profiles/r01_blob_*"},
+            "chain_images_to_markers": {"markers_per_s": float(d_nout.sum().item()) / ms_c * 1e3,
+                                        "frame_sets_per_s": F / ms_c * 1e3, "ms_per_batch": ms_c,
+                                        "overflow_frames": int((d_st != 0).sum().item())},
+            "parity": {"frame_sets_checked": nchk, "counts_equal": bool(np.array_equal(got_c, ref["counts"])),
+                       "centroids_bit_exact": bool(np.array_equal(got_b, ref["blobs"]))},
+            "cpu_baseline": {"value": cpu_rate, "unit": "images/s", "cores": 1, "kind": "port",
+                             "sample": f"{ncpu} frame sets of {C} images, scalar C restatement (oracle/c/blob_oracle.c); "
+                                       "OpenCV's own SIMD paths would be faster than this port"}}
+
+
 def ba_bench_16k(core, iters=60):
     """BASELINE.json configs[3]: 8 cams, 2000 frames x 8 markers = 16 000 calibration points."""
     from mocap_core import helpers
@@ -184,6 +264,7 @@ def main():
     ap.add_argument("--frames", type=int, default=0, help="frames per GPU per step (0 = the workload's default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ba", action="store_true")
+    ap.add_argument("--no-blobs", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -335,6 +416,8 @@ def main():
             if default_wl:
                 core.set_stream(0)
                 line["latency"] = frame_latency(core, blobs, counts)
+            if not args.no_blobs and default_wl:
+                line["blob_stage"] = blob_stage_bench(core, dev, stream)
             if not args.no_ba and default_wl:
                 core.set_stream(0)
                 line["ba"] = ba_bench(core)

@@ -14,8 +14,8 @@ _lib = None
 
 
 def build(force=False):
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(
-            os.path.join(_HERE, "c", "mocap_oracle.c")):
+    srcs = [os.path.join(_HERE, "c", f) for f in ("mocap_oracle.c", "blob_oracle.c")]
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", os.path.join(_HERE, "c"), "-B", "libmocap_oracle.so"],
                               stdout=subprocess.DEVNULL)
     return _SO
@@ -34,6 +34,11 @@ def _load():
         L.mo_triangulate.argtypes = [vp, i64, vp, vp, vp]
         L.mo_match_triangulate.argtypes = [vp, i64, i32, vp, vp, dbl, i32, i64, vp, vp, vp, vp, vp, vp]
         L.mo_ba_residuals.argtypes = [vp, i32, vp, i64, vp, vp]
+        L.bo_cam_create.restype = vp
+        L.bo_cam_create.argtypes = [i32, i32, vp, vp, i32]
+        L.bo_cam_destroy.argtypes = [vp]
+        L.bo_find_dots.restype = i32
+        L.bo_find_dots.argtypes = [vp, vp, i32, vp, vp, vp]
         _lib = L
     return _lib
 
@@ -93,3 +98,43 @@ class COracle:
         r = np.empty((P, N))
         _load().mo_ba_residuals(self._h, P, _p(params), N, _p(obs), _p(r))
         return r
+
+
+class BlobOracle:
+    """Blob-extraction stage (helpers.py:68-82, 143-163) in plain C, sequential Suzuki-Abe contours
+    (oracle/c/blob_oracle.c).  One instance per camera set."""
+
+    def __init__(self, rows, cols, K, dist, rotation=None):
+        L = _load()
+        K = np.ascontiguousarray(K, dtype=np.float64).reshape(-1, 9)
+        self.C = K.shape[0]
+        dist = np.ascontiguousarray(dist, dtype=np.float64).reshape(self.C, 5)
+        rot = [0] * self.C if rotation is None else list(rotation)
+        self.rows, self.cols = int(rows), int(cols)
+        self._cams = [L.bo_cam_create(self.rows, self.cols, _p(K[c]), _p(dist[c]), int(rot[c])) for c in range(self.C)]
+
+    def __del__(self):
+        for h in getattr(self, "_cams", []):
+            _load().bo_cam_destroy(h)
+        self._cams = []
+
+    def find_blobs(self, images, M_max=64, want_processed=False):
+        """images [F][C][rows][cols][3] -> same dict layout as MocapCore.find_blobs (counts are NOT clipped)."""
+        L = _load()
+        images = np.ascontiguousarray(images, dtype=np.uint8)
+        F, C = images.shape[:2]
+        assert C == self.C
+        blobs = np.zeros((F, C, M_max, 2), dtype=np.float32)
+        counts = np.zeros((F, C), dtype=np.int32)
+        ncont = np.zeros((F, C), dtype=np.int32)
+        proc = np.zeros((F, C, self.cols, self.cols, 3), dtype=np.uint8) if want_processed else None
+        nc = ctypes.c_int()
+        for f in range(F):
+            for c in range(C):
+                counts[f, c] = L.bo_find_dots(self._cams[c], _p(images[f, c]), M_max, _p(blobs[f, c]),
+                                              _p(proc[f, c]) if want_processed else None, ctypes.byref(nc))
+                ncont[f, c] = nc.value
+        out = {"blobs": blobs, "counts": counts, "n_contours": ncont}
+        if want_processed:
+            out["processed"] = proc
+        return out

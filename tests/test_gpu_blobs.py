@@ -108,6 +108,31 @@ def test_noisy_frames_holes_nesting_and_caps(core):
     _check_against_oracle(core, images, rig["K"], dists, M_max=8, check_frames=False)
 
 
+def test_batch_against_c_oracle_sequential_contours(core):
+    """A batch that spans several internal chunks (camera phase, workspace reuse) with frames from clean to
+    heavily noisy, against the C oracle: the kernel follows border cycles in parallel, the oracle runs the
+    sequential Suzuki-Abe raster scan with marks -- two algorithms, identical output required."""
+    from oracle import c_oracle
+    rng = np.random.default_rng(31)
+    C, F = 3, 24
+    rig = synth.ring_rig(C)
+    images, _ = synth.render_camera_frames(rig, F, 12, seed=32, spot_sigma=(0.8, 5.0), peak=500.0)
+    for f in range(0, F, 3):
+        amp = int(rng.integers(20, 140))
+        images[f, f % C] = np.maximum(images[f, f % C], rng.integers(0, amp, images[f, 0].shape, dtype=np.uint8))
+    dists = [synth.REFERENCE_DISTORTION, [-0.2, 0.1, 0.002, -0.001, 0.05], synth.REFERENCE_DISTORTION]
+    rots = [0, 2, 0]
+    core.set_image_params(240, 320, rig["K"], dists, rots)
+    M_max = 128
+    res = core.find_blobs(images, M_max=M_max, want_processed=True)
+    ref = c_oracle.BlobOracle(240, 320, rig["K"], dists, rots).find_blobs(images, M_max=M_max, want_processed=True)
+    assert np.array_equal(res["processed"], ref["processed"])
+    assert np.array_equal(res["n_contours"], ref["n_contours"])
+    assert np.array_equal(res["counts"], np.minimum(ref["counts"], M_max))
+    assert np.array_equal(res["blobs"], ref["blobs"])
+    assert ref["n_contours"].max() > 300 and (ref["counts"] > M_max).any()   # the stress frames are in
+
+
 def test_blank_and_saturated_frames(core):
     images = np.zeros((1, 2, 240, 320, 3), dtype=np.uint8)
     images[0, 1] = 255                             # one huge blob touching every border of the frame area

@@ -168,3 +168,17 @@ def test_find_contours_structure_against_scipy_labelling():
         starts = [(contours[i][:, 0, 1].min(), ) for i in top]
         assert starts == sorted(starts, reverse=True) or len(top) < 2 or all(
             starts[k] >= starts[k + 1] for k in range(len(starts) - 1))
+
+
+@pytest.mark.parametrize("name", BLOB_SETS)
+def test_c_blob_oracle_matches_reference_golden(name):
+    """oracle/c/blob_oracle.c (sequential Suzuki-Abe with border marks) against the same goldens."""
+    g = load_golden(name)
+    bo = c_oracle.BlobOracle(g["images"].shape[2], g["images"].shape[3], g["K"], g["dist"], g["rotation"])
+    r = bo.find_blobs(g["images"], M_max=g["ref_points"].shape[2], want_processed=True)
+    assert np.array_equal(r["counts"], g["ref_counts"])
+    assert np.array_equal(r["processed"], g["ref_frames"])
+    for f in range(g["images"].shape[0]):
+        for c in range(g["images"].shape[1]):
+            n = int(g["ref_counts"][f, c])
+            assert np.array_equal(r["blobs"][f, c, :n], g["ref_points"][f, c, :n].astype(np.float32))
