@@ -192,6 +192,29 @@ int mocap_locate_objects_dev(mocap_ctx* ctx, int64_t n_frames, int K_max, const 
                              double* d_heading, double* d_oerr, int32_t* d_drone, int32_t* d_lead,
                              int32_t* d_n_obj);
 
+/* ---------------------------------------------------------------- initial poses
+ * The pose-chaining loop of the `calculate-camera-pose` handler (index.py:229-270), i.e. the caller of
+ * bundle_adjustment: per neighbouring camera pair cv.findFundamentalMat(FM_RANSAC, threshold, confidence)
+ * on the points both cameras saw (index.py:241-246), cv.sfm.essentialFromFundamental with the intrinsics of
+ * cameras 0 and 1 (index.py:247), cv.sfm.motionFromEssential (index.py:248), the cheirality vote over the four
+ * candidates through triangulate_points (index.py:250-262), R = R_c R_prev, t = t_prev + R_prev t_c (:264-265).
+ *   obs [N][C][2]   calibration points, NaN = unseen (the handler's `cameraPoints` payload, index.py:232)
+ *   K [C][9]        intrinsics; like the reference only those of cameras 0 and 1 are read
+ *   threshold, confidence, max_iters   cv.findFundamentalMat arguments (reference: 1, 0.99999, default 1000)
+ *   R [C][9], t [C][3]   poses, camera 0 = (I, 0); t has the unit scale of motionFromEssential per pair
+ *   info [C-1][4]   (may be NULL) per pair: correspondences, RANSAC inliers, RANSAC iterations, candidate index
+ * RANSAC draws its subsets from cv::RNG((uint64)-1) exactly like cv::RANSACPointSetRegistrator and replays its
+ * bookkeeping over per-model inlier counts computed on the GPU.  Fewer than 15 common points: MOCAP_E_ARG
+ * (OpenCV would silently switch to LMedS). */
+int mocap_initial_poses(mocap_ctx* ctx, int C, int64_t N, const double* obs, const double* K, double threshold,
+                        double confidence, int max_iters, double* R, double* t, int32_t* info);
+/* cv.findFundamentalMat(p1, p2, FM_RANSAC, threshold, confidence, max_iters): p1, p2 [n][2] float32 (host),
+ * F [9] row-major with F[8] = 1, mask [n] (may be NULL) 1 = inlier, info [3] (may be NULL) = inliers,
+ * iterations run, iteration that produced F.  The result is the best minimal 7-point model (OpenCV does not
+ * refit on the inliers). */
+int mocap_find_fundamental(mocap_ctx* ctx, int64_t n, const float* p1, const float* p2, double threshold,
+                           double confidence, int max_iters, double* F, uint8_t* mask, int32_t* info);
+
 /* ---------------------------------------------------------------- bundle adjustment
  * Parameter vector as the reference (helpers.py:278-285):
  *   x = [f0, (f_i, rotvec_i[3], t_i[3]) for i = 1..C-1],  n = 1 + 7 (C-1); camera 0 = (I, 0).

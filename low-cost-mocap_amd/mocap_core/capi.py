@@ -53,6 +53,8 @@ SIGNATURES = {
     "mocap_set_world_transform": (_i32, [_vp, _vp]),
     "mocap_locate_objects": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mocap_locate_objects_dev": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mocap_initial_poses": (_i32, [_vp, _i32, _i64, _vp, _vp, _dbl, _dbl, _i32, _vp, _vp, _vp]),
+    "mocap_find_fundamental": (_i32, [_vp, _i64, _vp, _vp, _dbl, _dbl, _i32, _vp, _vp, _vp]),
     "mocap_ba_residuals": (_i32, [_vp, _i32, _vp, _i64, _vp, _vp]),
     "mocap_ba_normal_eq": (_i32, [_vp, _vp, _i64, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "mocap_ba_solve": (_i32, [_vp, _vp, _i64, _vp, _dbl, _dbl, _dbl, _i32, _i32, _i32, _vp]),
@@ -283,6 +285,30 @@ class MocapCore:
 
     def triangulate_dev(self, N, d_obs, d_xyz, d_err):
         self._check(self.lib.mocap_triangulate_dev(self._h, int(N), _vp(d_obs), _vp(d_xyz), _vp(d_err or 0)))
+
+    # ------------------------------------------------------------------ initial poses
+    def find_fundamental(self, p1, p2, threshold=1.0, confidence=0.99999, max_iters=1000):
+        p1 = np.ascontiguousarray(p1, dtype=np.float32).reshape(-1, 2)
+        p2 = np.ascontiguousarray(p2, dtype=np.float32).reshape(-1, 2)
+        n = p1.shape[0]
+        F = np.zeros(9)
+        mask = np.zeros(n, dtype=np.uint8)
+        info = np.zeros(3, dtype=np.int32)
+        self._check(self.lib.mocap_find_fundamental(self._h, n, _p(p1), _p(p2), float(threshold), float(confidence),
+                                                    int(max_iters), _p(F), _p(mask), _p(info)))
+        return F.reshape(3, 3), mask, {"inliers": int(info[0]), "iterations": int(info[1]), "best_iteration": int(info[2])}
+
+    def initial_poses(self, obs, K, threshold=1.0, confidence=0.99999, max_iters=1000):
+        """obs (N, C, 2) NaN = unseen, K [C][3][3] -> (R [C][3][3], t [C][3], info [C-1][4])."""
+        obs = np.ascontiguousarray(obs, dtype=np.float64)
+        N, C, _ = obs.shape
+        K = np.ascontiguousarray(K, dtype=np.float64).reshape(C, 9)
+        R = np.zeros((C, 3, 3))
+        t = np.zeros((C, 3))
+        info = np.zeros((max(C - 1, 1), 4), dtype=np.int32)
+        self._check(self.lib.mocap_initial_poses(self._h, C, N, _p(obs), _p(K), float(threshold), float(confidence),
+                                                 int(max_iters), _p(R), _p(t), _p(info)))
+        return R, t, info
 
     # ------------------------------------------------------------------ bundle adjustment
     def n_params(self):

@@ -238,6 +238,31 @@ def locate_objects(object_points, errors):
             for j in range(int(res["n_obj"][0]))]
 
 
+# ----------------------------------------------------------------------------- initial poses (caller of BA)
+def initial_camera_poses(image_points):
+    """The pose-chaining loop of the `calculate-camera-pose` handler (index.py:234-270): `image_points` is
+    the handler's np.array(data["cameraPoints"]) -- (N, C, 2) with None for unseen -- and the result the
+    list of {"R": 3x3, "t": (3, 1)} it hands to bundle_adjustment (camera 0 = identity)."""
+    arr = np.asarray(image_points, dtype=object)
+    C = arr.shape[1]
+    obs = _obs_array(arr, C)
+    K = _intrinsics(C)
+    with _state["lock"]:
+        R, t, _ = get_core().initial_poses(obs, K)
+    return [{"R": R[i], "t": t[i].reshape(3, 1)} for i in range(C)]
+
+
+def calculate_camera_pose(data, socketio):
+    """index.py:229-281 end to end: initial poses, bundle_adjustment, final error, the `camera-pose` event."""
+    image_points = np.array(data["cameraPoints"], dtype=object)
+    camera_poses = initial_camera_poses(image_points)
+    camera_poses = bundle_adjustment(image_points, camera_poses, socketio)
+    object_points = triangulate_points(image_points, camera_poses)
+    error = float(np.mean(calculate_reprojection_errors(image_points, object_points, camera_poses)))
+    socketio.emit("camera-pose", {"camera_poses": camera_pose_to_serializable(camera_poses)})
+    return camera_poses, error
+
+
 # ----------------------------------------------------------------------------- bundle adjustment
 def _ba_x0(camera_poses):
     """helpers.py:278-285 (including its focal-length indexing: entry i+1 takes camera i's focal)."""

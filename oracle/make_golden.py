@@ -295,7 +295,10 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     if "--blobs-only" in sys.argv:
         return main_blobs()
+    if "--pose-only" in sys.argv:
+        return main_pose()
     main_blobs()
+    main_pose()
     # BASELINE.json configs[0..2] shapes
     golden_frames("frames_c2_m1", synth.ring_rig(2), 8, 1, seed=0)
     golden_frames("frames_c4_m4", synth.ring_rig(4), 40, 4, seed=0)
@@ -320,6 +323,29 @@ def main():
     golden_ba("ba_c3_n24", 3, 24, seed=9, run_solver=True)
     # the rows right after the path: world-coordinate epilogue + object locator
     golden_post("post_world_locate", 300, 24, seed=10)
+
+
+def golden_pose(name, C, n_points, seed, Ks=None, dropout=0.05, noise_px=0.3):
+    """Initial pose estimation: the reference's own calculate_camera_pose handler
+    (index.py:229-270, extracted by AST) up to the poses it hands to bundle_adjustment."""
+    rig = synth.ring_rig(C)
+    if Ks is not None:
+        rig["K"] = np.array(Ks, dtype=np.float64)
+    obs, _ = synth.make_ba_observations(rig, n_points, seed=seed, dropout=dropout, noise_px=noise_px)
+    obs = np.trunc(obs)                                  # _find_dot yields int() centroids (helpers.py:153-154)
+    H = ref_harness.load_reference(C, intrinsics=[np.asarray(k).tolist() for k in rig["K"]])
+    poses = ref_harness.reference_initial_poses(H, synth.obs_to_reference_array(obs, as_int=True).tolist())
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), K=rig["K"], obs=obs,
+                        ref_R=np.array([p["R"] for p in poses]),
+                        ref_t=np.array([np.asarray(p["t"], dtype=np.float64).reshape(3) for p in poses]),
+                        true_R=rig["R"], true_t=rig["t"])
+    print(name, "points", n_points, "cameras", C)
+
+
+def main_pose():
+    golden_pose("pose_c4_n120", 4, 120, seed=3)
+    golden_pose("pose_c8_n400", 8, 400, seed=14, dropout=0.2)
+    golden_pose("pose_c3_calibK", 3, 200, seed=15, Ks=CALIBRATED_K)
 
 
 def main_blobs():

@@ -24,7 +24,7 @@ import types
 
 import numpy as np
 
-from . import cv_image_restate, cv_restate
+from . import cv_image_restate, cv_pose_restate, cv_restate
 
 REFERENCE_API = "/root/reference/computer_code/api"
 
@@ -47,6 +47,7 @@ def _install_stubs(num_cameras):
     cv2.line = lambda img, *a, **k: img
     cv2.KalmanFilter = _FakeKalman
     cv_image_restate.install(cv2)      # blob-extraction stage (helpers.py:68-88, 143-163), SURVEY 8f row 3
+    cv_pose_restate.install(cv2)       # initial pose estimation (index.py:229-270), SURVEY 8f row 4
     sys.modules["cv2"] = cv2
 
     pseyepy = types.ModuleType("pseyepy")
@@ -119,6 +120,31 @@ def reference_find_dots(H, raw_frames, distortion=None, rotation=None):
         out_frames.append(img)
         out_points.append(pts)
     return out_frames, out_points
+
+
+def reference_initial_poses(H, camera_points):
+    """Runs the reference's own `calculate_camera_pose` handler (computer_code/api/index.py:229-281),
+    extracted from index.py by its AST (index.py itself imports flask, serial, ruckig: absent here), with
+    `bundle_adjustment` replaced by a probe that records the poses the handler hands to it.
+    camera_points: the `cameraPoints` payload, (N, C, 2) nested lists with None for unseen.
+    Returns the list of {"R", "t"} initial poses (index.py:234-270)."""
+    import ast
+    src = open(os.path.join(REFERENCE_API, "index.py")).read()
+    fn = next(n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "calculate_camera_pose")
+    fn.decorator_list = []
+    captured = {}
+
+    def probe(image_points, camera_poses, socketio):
+        captured["poses"] = [{"R": np.array(p["R"], dtype=np.float64), "t": np.array(p["t"], dtype=np.float64)}
+                             for p in camera_poses]
+        return camera_poses
+
+    ns = {"np": np, "cv": sys.modules["cv2"], "Cameras": H.Cameras, "triangulate_points": H.triangulate_points,
+          "calculate_reprojection_errors": H.calculate_reprojection_errors, "bundle_adjustment": probe,
+          "camera_pose_to_serializable": H.camera_pose_to_serializable, "socketio": NullSocket()}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), "index.py:calculate_camera_pose", "exec"), ns)
+    ns["calculate_camera_pose"]({"cameraPoints": camera_points})
+    return captured["poses"]
 
 
 class NullSocket:

@@ -182,3 +182,54 @@ def test_c_blob_oracle_matches_reference_golden(name):
         for c in range(g["images"].shape[1]):
             n = int(g["ref_counts"][f, c])
             assert np.array_equal(r["blobs"][f, c, :n], g["ref_points"][f, c, :n].astype(np.float32))
+
+
+# ----------------------------------------------------------------------------- initial poses
+@pytest.mark.parametrize("name", golden_names("pose_"))
+def test_pose_oracle_matches_reference_golden(name):
+    """oracle/pose_oracle.py against the reference's own calculate_camera_pose handler (index.py:229-270)
+    run through the harness: same arithmetic -> bit-exact."""
+    from oracle import pose_oracle
+    g = load_golden(name)
+    R, t = pose_oracle.initial_poses(g["obs"], [k for k in g["K"]])
+    assert np.array_equal(R, g["ref_R"])
+    assert np.array_equal(t, g["ref_t"])
+
+
+def test_cv_rng_and_subset_known_answers():
+    """cv::RNG is a documented multiply-with-carry generator: its first outputs from the RANSAC seed are
+    fixed numbers (computed by hand from state = 2^64 - 1, coefficient 4164903690)."""
+    from oracle import cv_pose_restate as cp
+    r = cp.RNG()
+    s = 0xFFFFFFFFFFFFFFFF
+    for _ in range(5):
+        s = ((s & 0xFFFFFFFF) * 4164903690 + (s >> 32)) & 0xFFFFFFFFFFFFFFFF
+        assert r.next() == (s & 0xFFFFFFFF)
+    r = cp.RNG()
+    assert [r.uniform(0, 100) for _ in range(4)] == [(v % 100) for v in _mwc(4)]
+
+
+def _mwc(n):
+    s, out = 0xFFFFFFFFFFFFFFFF, []
+    for _ in range(n):
+        s = ((s & 0xFFFFFFFF) * 4164903690 + (s >> 32)) & 0xFFFFFFFFFFFFFFFF
+        out.append(s & 0xFFFFFFFF)
+    return out
+
+
+def test_seven_point_models_satisfy_their_sample():
+    """Every matrix run_7point returns is singular and satisfies x2^T F x1 = 0 on its 7 correspondences."""
+    from mocap_core import synth
+    from oracle import cv_pose_restate as cp
+    rng = np.random.default_rng(0)
+    rig = synth.ring_rig(2)
+    obs, _ = synth.make_ba_observations(rig, 7, seed=1, dropout=0.0)
+    p1, p2 = obs[:, 0], obs[:, 1]
+    Fs = cp.run_7point(p1, p2)
+    assert 1 <= len(Fs) <= 3
+    for F in Fs:
+        assert abs(np.linalg.det(F / np.linalg.norm(F))) < 1e-10
+        h1 = np.c_[p1, np.ones(7)]
+        h2 = np.c_[p2, np.ones(7)]
+        assert np.abs(np.einsum("ni,ij,nj->n", h2, F, h1)).max() < 1e-6 * np.abs(F).max() * 320 * 320
+    del rng
