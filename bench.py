@@ -169,6 +169,9 @@ def blob_stage_bench(core, dev, stream, steps=5, frames=1024, distinct=16):
 
     ms_b = timed(blobs_only)
     ms_c = timed(chain)
+    core.set_blob_options(skip_dark_tiles=False)       # every tile filtered: the dense-work figure
+    ms_dense = timed(blobs_only)
+    core.set_blob_options(skip_dark_tiles=True)
     n_img = F * C
     in_bytes = n_img * 240 * 320 * 3
     out_bytes = int(d_counts.sum().item()) * 8 + n_img * 8
@@ -186,6 +189,9 @@ def blob_stage_bench(core, dev, stream, steps=5, frames=1024, distinct=16):
     return {"metric": "camera images/s, raw RGB frames -> blob centroids (helpers.py:68-82,143-163)",
             "value": n_img / ms_b * 1e3, "frame_sets_per_s": F / ms_b * 1e3, "ms_per_batch": ms_b,
             "images_per_batch": n_img, "markers_per_frame_set": MARKERS,
+            "all_tiles_filtered": {"value": n_img / ms_dense * 1e3, "ms_per_batch": ms_dense,
+                                   "note": "mocap_set_blob_options(0): without the exact dark-tile early-out "
+                                           "(background noise here is uniform in [0, 3): range 2, the bound of the proof)"},
             "roofline": {"bound": "hbm", "achieved": (in_bytes + out_bytes) / ms_b / 1e6, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": (in_bytes + out_bytes) / ms_b / 1e6 / HBM_PEAK_GBS,
                          "algorithmic_bytes_per_image": 240 * 320 * 3 + 8,

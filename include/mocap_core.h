@@ -148,6 +148,12 @@ int mocap_set_image_params(mocap_ctx* ctx, int C, int rows, int cols, const doub
  * sx field 2047 = every tap outside the frame (tests / debugging) */
 int mocap_get_undistort_map(mocap_ctx* ctx, int camera, uint32_t* map);
 
+/* scheduling knob of the blob stage; results are bit-identical for either setting (tested).
+ *   skip_dark_tiles  default 1: a 64 x 64 tile whose source bytes span a value range <= 2 (activity map of
+ *                    the pre-pass) provably yields no mask bit and is not filtered (exact early-out; IR
+ *                    frames are black but for the dots).  0 = filter every tile. */
+int mocap_set_blob_options(mocap_ctx* ctx, int skip_dark_tiles);
+
 /* per-image status bits written by mocap_find_blobs* */
 enum {
   MOCAP_BLOB_ST_POINT_OVERFLOW = 1, /* more centroids than M_max: the first M_max were kept            */

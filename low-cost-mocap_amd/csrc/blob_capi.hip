@@ -102,6 +102,8 @@ int find_blobs_dev_locked(mocap_ctx* ctx, int64_t n_frames, const uint8_t* d_ima
     HIP_TRY(ctx, hipMemsetAsync(ctx->img_sq.ptr, 0, ctx->img_sq.cap, ctx->stream));  // the zero frame, once
     ctx->img_sq_images = (int64_t)(ctx->img_sq.cap / sq_img);
   }
+  const int bands = (ctx->img_rows + 16 + kSquareRows - 1) / kSquareRows, segs = ctx->img_cols * 3 / 16;
+  if (ctx->img_act.reserve((size_t)want * bands * segs * 2)) return ctx->fail(MOCAP_E_HIP, "hipMalloc(activity map) failed");
   const size_t words = (size_t)(S + 63) / 64;
   if (ctx->img_mask.reserve((size_t)n_frames * C * S * words * 8)) return ctx->fail(MOCAP_E_HIP, "hipMalloc(mask) failed");
   for (int64_t f0 = 0; f0 < n_frames; f0 += chunk_frames) {
@@ -121,6 +123,10 @@ int find_blobs_dev_locked(mocap_ctx* ctx, int64_t n_frames, const uint8_t* d_ima
     a.squared = (uint8_t*)ctx->img_sq.ptr;
     a.gather = (const uint32_t*)ctx->img_tiles.ptr;
     a.cam_lens = (const int32_t*)ctx->img_lens.ptr;
+    a.activity = (uint8_t*)ctx->img_act.ptr;
+    a.tile_box = (const int16_t*)ctx->img_box.ptr;
+    a.tile_zero = (const uint8_t*)ctx->img_zero.ptr;
+    a.skip_dark = ctx->blob_skip_dark;
     a.mask = (unsigned long long*)ctx->img_mask.ptr + i0 * S * words;
     a.processed = d_processed ? d_processed + i0 * S * S * 3 : nullptr;
     a.blobs = d_blobs + i0 * M_max * 2;
@@ -224,9 +230,46 @@ extern "C" int mocap_set_image_params(mocap_ctx* ctx, int C, int rows, int cols,
           g[vy * RW + vx] = e;
         }
     }
+  // source bounding box of every tile in units of the pre-pass's activity map (16-row bands x 16-byte segments)
+  std::vector<int16_t> box(lens_cam.size() * tiles * tiles * 4);
+  std::vector<uint8_t> zero(lens_cam.size() * tiles * tiles, 0);
+  for (size_t l = 0; l < lens_cam.size(); l++)
+    for (int t = 0; t < tiles * tiles; t++) {
+      const uint32_t* g = gather.data() + (l * tiles * tiles + t) * (size_t)kBlobGather;
+      int b0 = 1 << 20, b1 = -1, s0 = 1 << 20, s1 = -1;
+      bool z = false;
+      for (int i = 0; i < RW * RW; i++) {
+        const int off = (int)(g[i] & 0x3fffffu) / 3;   // pixel index inside the zero-framed layout
+        const int Y0 = off / WP - 1, X0 = off % WP - kSquarePad;
+        for (int tap = 0; tap < 4; tap++) {
+          const int Y = Y0 + (tap >> 1), X = X0 + (tap & 1);
+          if (Y < ay - 8 || Y >= ay + rows + 8 || X < 0 || X >= S) {
+            z = true;
+            continue;
+          }
+          const int b = (Y - (ay - 8)) / kSquareRows, sa = 3 * X / 16, sb = (3 * X + 2) / 16;
+          b0 = b < b0 ? b : b0;
+          b1 = b > b1 ? b : b1;
+          s0 = sa < s0 ? sa : s0;
+          s1 = sb > s1 ? sb : s1;
+        }
+      }
+      int16_t* o = box.data() + (l * tiles * tiles + t) * 4;
+      if (b1 < 0) {  // every tap in the zero area: one (any) activity cell, the zero flag decides
+        b0 = b1 = s0 = s1 = 0;
+      }
+      o[0] = (int16_t)b0;
+      o[1] = (int16_t)b1;
+      o[2] = (int16_t)s0;
+      o[3] = (int16_t)s1;
+      zero[l * tiles * tiles + t] = z ? 1 : 0;
+    }
   if (ctx->img_map.reserve(map.size() * sizeof(uint32_t)) || ctx->img_rot.reserve(C * sizeof(int32_t)) ||
-      ctx->img_tiles.reserve(gather.size() * sizeof(uint32_t)) || ctx->img_lens.reserve(C * sizeof(int32_t)))
+      ctx->img_tiles.reserve(gather.size() * sizeof(uint32_t)) || ctx->img_lens.reserve(C * sizeof(int32_t)) ||
+      ctx->img_box.reserve(box.size() * sizeof(int16_t)) || ctx->img_zero.reserve(zero.size()))
     return ctx->fail(MOCAP_E_HIP, "hipMalloc(undistortion maps) failed");
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->img_box.ptr, box.data(), box.size() * sizeof(int16_t), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->img_zero.ptr, zero.data(), zero.size(), hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(ctx->img_tiles.ptr, gather.data(), gather.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(ctx->img_lens.ptr, lens.data(), C * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(ctx->img_map.ptr, map.data(), map.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
@@ -238,6 +281,13 @@ extern "C" int mocap_set_image_params(mocap_ctx* ctx, int C, int rows, int cols,
   ctx->img_cols = cols;
   ctx->img_S = S;
   ctx->img_ay = ay;
+  return MOCAP_OK;
+}
+
+extern "C" int mocap_set_blob_options(mocap_ctx* ctx, int skip_dark_tiles) {
+  if (!ctx) return MOCAP_E_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  ctx->blob_skip_dark = skip_dark_tiles ? 1 : 0;
   return MOCAP_OK;
 }
 

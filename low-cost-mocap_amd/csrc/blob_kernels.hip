@@ -66,7 +66,6 @@ __device__ __forceinline__ uint32_t udot2(uint32_t a, uint32_t b, uint32_t c) {
 // ---- pre-pass: np.rot90 (k = 0 or 2) + make_square (helpers.py:507-523) into the zero-framed layout the
 // gather tables address.  One workgroup per image; only the frame rows and the 2 x 8 feathered rows are
 // written (edge row * (7 - i) / 8, truncated), the zero frame and the empty rows are set once at allocation.
-constexpr int kSquareRows = 16;  // squared rows per workgroup (4 per wave)
 __global__ __launch_bounds__(kBlobThreads) void blob_square_kernel(BlobArgs a) {
   const int first = a.ay - 8, n_rows = a.rows + 16;  // squared rows [first, first + n_rows)
   const int groups = (n_rows + kSquareRows - 1) / kSquareRows;
@@ -79,6 +78,10 @@ __global__ __launch_bounds__(kBlobThreads) void blob_square_kernel(BlobArgs a) {
   uint8_t* sq = a.squared + (size_t)img * (S + 2) * WP * 3;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int row_bytes = a.cols * 3;
+  // activity of this band: per 16-byte segment the min / max byte over the band's rows (what the frame rows
+  // hold AFTER feather scaling, i.e. exactly the bytes the mask kernel will gather)
+  __shared__ uint32_t act[4][64];
+  uint32_t mn = 0x00ff00ffu, mx = 0u;  // two 16-bit fields, min / max over even and odd bytes alike
 #pragma unroll
   for (int k = 0; k < kSquareRows / 4; k++) {
     const int Y = first + grp * kSquareRows + wave * (kSquareRows / 4) + k;
@@ -107,6 +110,15 @@ __global__ __launch_bounds__(kBlobThreads) void blob_square_kernel(BlobArgs a) {
           }
         }
         *(uint4*)(dst + i) = v;
+        {
+          const uint32_t* w = (const uint32_t*)&v;
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const uint32_t e = w[q] & 0x00ff00ffu, o = (w[q] >> 8) & 0x00ff00ffu;
+            mn = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(v2u16, mn), __builtin_elementwise_min(__builtin_bit_cast(v2u16, e), __builtin_bit_cast(v2u16, o))));
+            mx = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(v2u16, mx), __builtin_elementwise_max(__builtin_bit_cast(v2u16, e), __builtin_bit_cast(v2u16, o))));
+          }
+        }
       }
     } else {  // rot90 k = 2: rows and columns reversed
       const uint8_t* src = raw + (size_t)(a.rows - 1 - r) * row_bytes;
@@ -116,6 +128,24 @@ __global__ __launch_bounds__(kBlobThreads) void blob_square_kernel(BlobArgs a) {
         dst[3 * x + 1] = (uint8_t)((p[1] * scale) >> 3);
         dst[3 * x + 2] = (uint8_t)((p[2] * scale) >> 3);
       }
+      mn = 0u;  // rotated cameras: no activity summary -> "full range", their tiles are never skipped
+      mx = 0x00ff00ffu;
+    }
+  }
+  if (a.activity) {
+    const uint32_t lo = min(mn & 0xffffu, mn >> 16), hi = max(mx & 0xffffu, mx >> 16);
+    act[wave][lane] = lo | hi << 8;
+    __syncthreads();
+    const int segs = row_bytes / 16;
+    if (wave == 0 && lane < segs) {
+      uint32_t l = 255u, h = 0u;
+      for (int w2 = 0; w2 < 4; w2++) {
+        l = min(l, act[w2][lane] & 0xffu);
+        h = max(h, act[w2][lane] >> 8);
+      }
+      uint8_t* o = a.activity + (((size_t)img * groups + grp) * segs + lane) * 2;
+      o[0] = (uint8_t)l;
+      o[1] = (uint8_t)h;
     }
   }
 }
@@ -142,6 +172,48 @@ __global__ __launch_bounds__(kBlobThreads) void blob_mask_kernel(BlobArgs a) {
   const uint8_t* sq = a.squared + (size_t)img * (S + 2) * WP * 3;
   const uint32_t* tab = a.gather + ((size_t)a.cam_lens[cam] * tiles * tiles + tile) * kBlobGather;
   const uint32_t row_bytes = (uint32_t)WP * 3;
+  const int words = (S + 63) / 64;
+  unsigned long long* mask = a.mask + (size_t)img * S * words;
+
+  // ---- dark-tile early-out (exact).  All bytes this tile can gather lie in [m, M] (activity map of the
+  // pre-pass; the zero frame counts as 0).  Bilinear interpolation and the Gaussian are convex combinations
+  // with round-to-nearest, so every blurred value stays in [m, M]; the 5x5 kernel sums to 0 with positive
+  // weights summing to 20, so its output is at most 20 (M - m); grey is a convex combination of the three
+  // channels.  M - m <= 2  =>  grey <= 40 < 52: no mask bit can be set.
+  if (a.skip_dark && !a.processed) {
+    const int16_t* box = a.tile_box + ((size_t)a.cam_lens[cam] * tiles * tiles + tile) * 4;
+    const int b0 = box[0], b1 = box[1], s0 = box[2], s1 = box[3];
+    if (b0 >= 0) {
+      const int segs = a.cols * 3 / 16, bands = (a.rows + 16 + kSquareRows - 1) / kSquareRows;
+      const uint8_t* act = a.activity + (size_t)img * bands * segs * 2;
+      const int nb = b1 - b0 + 1, ns = s1 - s0 + 1;
+      uint32_t lo = 255u, hi = 0u;
+      for (int i = tid; i < nb * ns; i += kBlobThreads) {
+        const int bi = b0 + i / ns, si = s0 + i % ns;
+        const uint8_t* e = act + ((size_t)bi * segs + si) * 2;
+        lo = min(lo, (uint32_t)e[0]);
+        hi = max(hi, (uint32_t)e[1]);
+      }
+      __shared__ uint32_t red[2][kBlobThreads / 64];
+      for (int o = 32; o > 0; o >>= 1) {
+        lo = min(lo, (uint32_t)__shfl_xor((int)lo, o));
+        hi = max(hi, (uint32_t)__shfl_xor((int)hi, o));
+      }
+      if ((tid & 63) == 0) {
+        red[0][tid >> 6] = lo;
+        red[1][tid >> 6] = hi;
+      }
+      __syncthreads();
+      lo = min(min(red[0][0], red[0][1]), min(red[0][2], red[0][3]));
+      hi = max(max(red[1][0], red[1][1]), max(red[1][2], red[1][3]));
+      // a box that reaches into the zero rows / zero frame of the squared layout (host flag) also sees 0
+      if (hi <= (a.tile_zero[(size_t)a.cam_lens[cam] * tiles * tiles + tile] ? 0u : lo) + 2u) {
+        for (int y = tid; y < BT; y += kBlobThreads)
+          if (ty0 + y < S) mask[(size_t)(ty0 + y) * words + tx0 / 64] = 0ull;
+        return;
+      }
+    }
+  }
 
   // ---- A: undistorted region = table-driven bilinear gather from the squared frame.  The table already
   // holds the reflect-101 of the region, the tap address and the 1/32-px fractions; the zero frame of the
@@ -273,8 +345,6 @@ __global__ __launch_bounds__(kBlobThreads) void blob_mask_kernel(BlobArgs a) {
   }
 
   // ---- C: grey, threshold (helpers.py:145-146), one 64-bit word per tile row
-  const int words = (S + 63) / 64;
-  unsigned long long* mask = a.mask + (size_t)img * S * words;
 #pragma unroll
   for (int j = 0; j < 16; j++) {
     const int y = 16 * wv + j;

@@ -101,6 +101,9 @@ extern "C" void mocap_destroy(mocap_ctx* ctx) {
   ctx->img_tiles.release();
   ctx->img_lens.release();
   ctx->img_sq.release();
+  ctx->img_act.release();
+  ctx->img_box.release();
+  ctx->img_zero.release();
   ctx->world.release();
   if (ctx->ba_pin) (void)hipHostFree(ctx->ba_pin);
   if (ctx->ba_event) (void)hipEventDestroy(ctx->ba_event);

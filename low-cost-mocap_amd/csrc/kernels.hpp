@@ -80,6 +80,7 @@ constexpr int kBlobTile = 64;  // output tile edge of blob_mask_kernel
 constexpr int kBlobHalo = 6;   // 4 (9x9 Gaussian) + 2 (5x5 filter)
 constexpr int kBlobRegion = (kBlobTile + 2 * kBlobHalo) * (kBlobTile + 2 * kBlobHalo);  // 5776 region pixels per tile
 constexpr int kBlobGather = ((kBlobRegion + 255) / 256) * 256;  // gather-table entries per tile (padded to 256)
+constexpr int kSquareRows = 16;  // squared rows per workgroup of the pre-pass = one band of the activity map
 constexpr int kSquarePad = 16;  // zero pixels left and right of a squared-frame row (keeps rows 16-byte aligned)
 struct BlobArgs {
   int64_t n_images;        // images of this launch; camera = (img_base + image) % C
@@ -96,6 +97,12 @@ struct BlobArgs {
   // byte offset of the top-left tap in a squared frame | fx << 22 | fy << 27
   const uint32_t* gather;
   const int32_t* cam_lens;   // [C] index of the camera's lens table
+  // dark-tile early-out (exact): the pre-pass records min / max of the raw bytes per (16-row band, 16-byte
+  // segment); a tile whose source bounding box spans a value range <= 2 cannot produce a set mask bit
+  uint8_t* activity;         // [n_images][bands][segs][2] (min, max); bands = ceil((rows + 16) / 16), segs = cols * 3 / 16
+  const int16_t* tile_box;   // [lens][tiles^2][4]: first band, last band, first segment, last segment; band < 0 = never skip
+  const uint8_t* tile_zero;  // [lens][tiles^2] 1 = the tile's taps reach zero rows / the zero frame (value 0 takes part)
+  int skip_dark;
   unsigned long long* mask;  // [n_images][S][ceil(S / 64)] thresholded frame, 1 bit per pixel
   uint8_t* processed;      // [n_images][S][S][3] BGR frame as the reference streams it, or null
   float* blobs;            // [n_images][M_max][2]

@@ -47,6 +47,7 @@ SIGNATURES = {
     "mocap_match_triangulate": (_i32, [_vp, _i64, _i32, _vp, _vp, _dbl, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mocap_match_triangulate_dev": (_i32, [_vp, _i64, _i32, _vp, _vp, _dbl, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mocap_set_image_params": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "mocap_set_blob_options": (_i32, [_vp, _i32]),
     "mocap_get_undistort_map": (_i32, [_vp, _i32, _vp]),
     "mocap_find_blobs": (_i32, [_vp, _i64, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
     "mocap_find_blobs_dev": (_i32, [_vp, _i64, _vp, _i32, _vp, _vp, _vp, _vp]),
@@ -224,6 +225,9 @@ class MocapCore:
         rot = None if rotation is None else np.ascontiguousarray(rotation, dtype=np.int32).reshape(C)
         self._check(self.lib.mocap_set_image_params(self._h, C, int(rows), int(cols), _p(K), _p(dist), _p(rot)))
         self.img_C, self.img_rows, self.img_cols = C, int(rows), int(cols)
+
+    def set_blob_options(self, skip_dark_tiles=True):
+        self._check(self.lib.mocap_set_blob_options(self._h, int(bool(skip_dark_tiles))))
 
     def undistort_map(self, camera=0):
         m = np.zeros((self.img_cols, self.img_cols), dtype=np.uint32)

@@ -24,13 +24,16 @@ def main():
     ap.add_argument("--cams", type=int, default=8)
     ap.add_argument("--markers", type=int, default=16)
     ap.add_argument("--processed", action="store_true")
+    ap.add_argument("--no-skip", action="store_true", help="filter every tile (no dark-tile early-out)")
+    ap.add_argument("--noise", type=int, default=3, help="background noise levels: uniform in [0, noise)")
     args = ap.parse_args()
     C, M_max = args.cams, 32
     rig = synth.ring_rig(C)
-    images, _ = synth.render_camera_frames(rig, args.distinct, args.markers, seed=1)
+    images, _ = synth.render_camera_frames(rig, args.distinct, args.markers, seed=1, noise_levels=args.noise)
     dev = torch.device("cuda", 0)
     core = capi.MocapCore(0)
     core.set_image_params(240, 320, rig["K"], [synth.REFERENCE_DISTORTION] * C)
+    core.set_blob_options(skip_dark_tiles=not args.no_skip)
     stream = torch.cuda.current_stream(dev)
     core.set_stream(stream.cuda_stream)
     F = args.frames
@@ -60,7 +63,7 @@ def main():
     print(json.dumps({"images": n_img, "ms": ms, "runs_ms": ts, "images_per_s": n_img / ms * 1e3,
                       "frame_sets_per_s": F / ms * 1e3, "GBps_algorithmic": (in_bytes + out_bytes) / ms / 1e6,
                       "frac_of_8TBps": (in_bytes + out_bytes) / ms / 1e6 / 8000, "points": int(d_counts.sum().item()),
-                      "status_nonzero": int((d_st != 0).sum().item()), "processed": args.processed}))
+                      "status_nonzero": int((d_st != 0).sum().item()), "processed": args.processed, "skip_dark_tiles": not args.no_skip, "noise_levels": args.noise}))
 
 
 if __name__ == "__main__":

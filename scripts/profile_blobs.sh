@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_blob_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $R/scripts/bench_blobs.py --frames 1024 --steps 3"
+CMD="python $R/scripts/bench_blobs.py --frames 1024 --steps 3 ${BLOB_ARGS:---no-skip}"
 run() {  # name, extra rocprof args
   local n=$1; shift
   timeout 300 rocprofv3 --kernel-trace "$@" -d $OUT/$n -o p -- $CMD > $OUT/$n.log 2>&1

@@ -133,6 +133,34 @@ def test_batch_against_c_oracle_sequential_contours(core):
     assert ref["n_contours"].max() > 300 and (ref["counts"] > M_max).any()   # the stress frames are in
 
 
+def test_dark_tile_early_out_does_not_change_results(core):
+    """mocap_set_blob_options(skip_dark_tiles): an exact early-out, so masks / centroids must be bit-identical
+    with it on and off -- clean frames (most tiles skipped), noise of range 2 / 3 / 4 around the bound of the
+    proof, a bright offset (range small but values high), dots on tile borders."""
+    rng = np.random.default_rng(41)
+    rig = synth.ring_rig(2)
+    images, _ = synth.render_camera_frames(rig, 6, 10, seed=42, noise_levels=1)
+    images[1] = np.maximum(images[1], rng.integers(0, 3, images[1].shape, dtype=np.uint8))     # range 2
+    images[2] = np.maximum(images[2], rng.integers(0, 4, images[2].shape, dtype=np.uint8))     # range 3
+    images[3] = np.maximum(images[3], rng.integers(0, 5, images[3].shape, dtype=np.uint8))     # range 4
+    images[4] = np.clip(images[4].astype(np.int32) + 200, 0, 255).astype(np.uint8)            # bright, flat
+    images[5, 0, 100:104, 62:66] = 255                                                         # dot across a tile border
+    images[5, 1, 76:80, 126:130] = 255
+    dists = [synth.REFERENCE_DISTORTION] * 2
+    core.set_image_params(240, 320, rig["K"], dists, [0, 2])
+    try:
+        core.set_blob_options(skip_dark_tiles=True)
+        on = core.find_blobs(images, M_max=64)
+        core.set_blob_options(skip_dark_tiles=False)
+        off = core.find_blobs(images, M_max=64)
+    finally:
+        core.set_blob_options(skip_dark_tiles=True)
+    for k in ("blobs", "counts", "status", "n_contours"):
+        assert np.array_equal(on[k], off[k]), k
+    assert on["counts"].sum() > 0
+    _check_against_oracle(core, images[[0, 4, 5]], rig["K"], dists, [0, 2])
+
+
 def test_blank_and_saturated_frames(core):
     images = np.zeros((1, 2, 240, 320, 3), dtype=np.uint8)
     images[0, 1] = 255                             # one huge blob touching every border of the frame area
