@@ -43,7 +43,7 @@ constexpr int UW = BT + 2 * (HG + HF);  // 76: undistorted region edge
 static_assert(UW * UW == kBlobRegion, "region");
 constexpr int UP = UW;              // its row stride: region index = LDS offset (the row pass over-reads <= 4 bytes)
 constexpr int BW = BT + 2 * HF;     // 68: blurred region edge
-constexpr int BP = 72;              // its padded row stride (bytes)
+constexpr int BP = 68;              // its row stride (bytes): the 5x5 stage reads at most column 67
 constexpr int VT = 78;              // stride (u16) of the column-major row-pass result: 76 rows + pad
 constexpr int kBlobThreads = 256;
 
