@@ -148,10 +148,23 @@ int find_blobs_dev_locked(mocap_ctx* ctx, int64_t n_frames, const uint8_t* d_ima
   a.counts = d_counts;
   a.status = d_status;
   a.n_contours = d_n_contours;
-  HIP_TRY(ctx, launch_blob_contours(a, kPCapSmall, kNCapSmall, 0, ctx->stream));
+  // table sizes that fit LDS next to the padded mask of this frame size (the mask grows with S^2 / 8)
+  int p_small = kPCapSmall, n_small = kNCapSmall, p_large = kPCapLarge, n_large = kNCapLarge;
+  const size_t lds_cap = 160 * 1024;
+  while (blob_contour_lds_bytes(S, p_large, n_large) > lds_cap && p_large > 512) {
+    p_large /= 2;
+    n_large /= 2;
+  }
+  while (blob_contour_lds_bytes(S, p_small, n_small) > lds_cap / 2 && p_small > 256) {
+    p_small /= 2;
+    n_small /= 2;
+  }
+  if (blob_contour_lds_bytes(S, p_large, n_large) > lds_cap)
+    return ctx->fail(MOCAP_E_LIMIT, "frame edge %d: the contour tables do not fit LDS", S);
+  HIP_TRY(ctx, launch_blob_contours(a, p_small, n_small, 0, ctx->stream));
   // images whose border tables overflowed run again with the largest tables LDS holds; the launch is
   // a no-op (one status read per workgroup) for every other image
-  HIP_TRY(ctx, launch_blob_contours(a, kPCapLarge, kNCapLarge, 1, ctx->stream));
+  HIP_TRY(ctx, launch_blob_contours(a, p_large, n_large, 1, ctx->stream));
   return MOCAP_OK;
 }
 
@@ -169,7 +182,7 @@ extern "C" int mocap_set_image_params(mocap_ctx* ctx, int C, int rows, int cols,
   const int ay = (S - rows) / 2;
   if (cols != S || ay < 8 || S - ay - rows < 8)
     return ctx->fail(MOCAP_E_ARG, "frames must be landscape with >= 8 rows of square padding (reference make_square)");
-  if (S > 1024) return ctx->fail(MOCAP_E_LIMIT, "frame edge %d exceeds 1024", S);
+  if (S > 832) return ctx->fail(MOCAP_E_LIMIT, "frame edge %d exceeds 832 (contour tables + padded mask must fit 160 KB of LDS)", S);
   if (cols % 16) return ctx->fail(MOCAP_E_ARG, "frame width must be a multiple of 16");
   std::vector<int32_t> rot(C, 0);
   for (int c = 0; c < C; c++) {

@@ -531,6 +531,7 @@ __global__ __launch_bounds__(kBlobThreads) void blob_contour_kernel(BlobArgs a, 
     if (tid == 0) {
       a.status[img] = BLOB_ST_CAP_OVERFLOW_;
       a.counts[img] = 0;
+      if (a.n_contours) a.n_contours[img] = -1;
     }
     return;
   }
@@ -571,6 +572,7 @@ __global__ __launch_bounds__(kBlobThreads) void blob_contour_kernel(BlobArgs a, 
     if (tid == 0) {
       a.status[img] = BLOB_ST_CAP_OVERFLOW_;
       a.counts[img] = 0;
+      if (a.n_contours) a.n_contours[img] = -1;
     }
     return;
   }

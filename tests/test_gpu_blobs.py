@@ -161,6 +161,39 @@ def test_dark_tile_early_out_does_not_change_results(core):
     _check_against_oracle(core, images[[0, 4, 5]], rig["K"], dists, [0, 2])
 
 
+@pytest.mark.parametrize("rows,cols", [(200, 352), (480, 640)])
+def test_other_frame_geometries(core, rows, cols):
+    """Frame edges that are not a multiple of the 64-px tile (352) and VGA: partial tiles, other mask
+    strides, LDS table sizes chosen per geometry."""
+    from oracle import c_oracle
+    rng = np.random.default_rng(rows)
+    C, F = 2, 2
+    K = np.array([[cols * 1.0, 0, cols / 2], [0, cols * 1.0, cols / 2], [0, 0, 1]])
+    images = rng.integers(0, 3, (F, C, rows, cols, 3), dtype=np.uint8)
+    yy, xx = np.mgrid[0:rows, 0:cols]
+    for f in range(F):
+        for c in range(C):
+            img = images[f, c].astype(np.float32)
+            for _ in range(12):
+                cx, cy, sg = rng.uniform(0, cols), rng.uniform(0, rows), rng.uniform(1.0, 4.0)
+                img += (400 * np.exp(-((xx - cx) ** 2 + (yy - cy) ** 2) / (2 * sg * sg)))[..., None]
+            images[f, c] = np.clip(img, 0, 255).astype(np.uint8)
+    images[1, 1] = np.maximum(images[1, 1], rng.integers(0, 100, images[1, 1].shape, dtype=np.uint8))
+    dists = [synth.REFERENCE_DISTORTION, [-0.2, 0.1, 0.002, -0.001, 0.05]]
+    core.set_image_params(rows, cols, [K, K], dists, [0, 2])
+    res = core.find_blobs(images, M_max=256, want_processed=True)
+    ref = c_oracle.BlobOracle(rows, cols, [K, K], dists, [0, 2]).find_blobs(images, M_max=256, want_processed=True)
+    assert np.array_equal(res["processed"], ref["processed"])
+    over = (res["status"] & capi.BLOB_ST_CAP_OVERFLOW) != 0
+    # more borders than the LDS tables of this geometry hold (noise, not blobs): flagged, never silently wrong
+    assert (ref["n_contours"][over] > 512).all() and (res["counts"][over] == 0).all() and (res["n_contours"][over] == -1).all()
+    ok = ~over
+    assert ok.sum() >= 3
+    assert np.array_equal(res["n_contours"][ok], ref["n_contours"][ok])
+    assert np.array_equal(res["counts"][ok], np.minimum(ref["counts"][ok], 256))
+    assert np.array_equal(res["blobs"][ok], ref["blobs"][ok])
+
+
 def test_blank_and_saturated_frames(core):
     images = np.zeros((1, 2, 240, 320, 3), dtype=np.uint8)
     images[0, 1] = 255                             # one huge blob touching every border of the frame area
