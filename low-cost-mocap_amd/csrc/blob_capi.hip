@@ -81,7 +81,7 @@ void build_undistort_map(const double* K, const double* dist, int S, uint32_t* o
   }
 }
 
-constexpr int kPCapSmall = 2048, kNCapSmall = 256;   // LDS tables of the common case: 3 workgroups per CU
+constexpr int kPCapSmall = 1024, kNCapSmall = 128;   // LDS tables of the common case (29 KB at 320 px): 5 workgroups per CU
 constexpr int kPCapLarge = 8192, kNCapLarge = 1024;  // re-run of images that overflowed them
 
 int find_blobs_dev_locked(mocap_ctx* ctx, int64_t n_frames, const uint8_t* d_images, int M_max, float* d_blobs,
