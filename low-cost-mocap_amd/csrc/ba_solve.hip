@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <limits>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -341,13 +342,13 @@ int ba_wait(mocap_ctx* ctx) {
 }
 
 // residuals for P parameter vectors already in w.d_params -> w.d_r [P][N]
-int ba_eval_device(mocap_ctx* ctx, BaWork& w, int P) {
+int ba_eval_device(mocap_ctx* ctx, BaWork& w, int P, const double* params = nullptr) {
   BaCamArgs ca;
   ca.C = w.C;
   ca.n = w.n;
   ca.P = P;
   ca.uniformK = w.uniformK;
-  ca.params = w.d_params;
+  ca.params = params ? params : w.d_params;
   ca.K = ctx->d_K9;
   ca.Pq = w.d_Pq;
   ca.RT = w.d_RT;
@@ -371,13 +372,13 @@ int ba_eval_device(mocap_ctx* ctx, BaWork& w, int P) {
 
 // cost at x (host) -> cost, finite
 int ba_cost_at(mocap_ctx* ctx, BaWork& w, const double* x, int f32, int cauchy, double& cost, bool& finite) {
+  // zero-copy: the kernels read the parameter vector from, and write (cost, finite) to, pinned host memory
+  // (device-visible, coherent) -- a copy-engine round trip costs more than the 2 us of work it would move
   memcpy(w.h_x, x, sizeof(double) * w.n);
-  HIP_TRY(ctx, hipMemcpyAsync(w.d_params, w.h_x, sizeof(double) * w.n, hipMemcpyHostToDevice, ctx->stream));
-  int rc = ba_eval_device(ctx, w, 1);
+  int rc = ba_eval_device(ctx, w, 1, w.h_x);
   if (rc) return rc;
-  HIP_TRY(ctx, launch_ba_cost(w.d_r, w.d_valid, w.m, f32, cauchy, w.d_cost, ctx->stream));
   double* out = w.h_G + (w.d_cost - w.d_G);
-  HIP_TRY(ctx, hipMemcpyAsync(out, w.d_cost, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, launch_ba_cost(w.d_r, w.d_valid, w.m, f32, cauchy, out, ctx->stream));
   rc = ba_wait(ctx);
   if (rc) return rc;
   cost = out[0];
@@ -388,11 +389,10 @@ int ba_cost_at(mocap_ctx* ctx, BaWork& w, const double* x, int f32, int cauchy, 
 // linearise at x: G = [J|f]^T [J|f] (host copy, NP x NP), cost
 int ba_linearize(mocap_ctx* ctx, BaWork& w, const double* x, int f32, int cauchy, std::vector<double>& G,
                  double& cost) {
-  memcpy(w.h_x, x, sizeof(double) * w.n);
-  HIP_TRY(ctx, hipMemcpyAsync(w.d_x, w.h_x, sizeof(double) * w.n, hipMemcpyHostToDevice, ctx->stream));
+  memcpy(w.h_x, x, sizeof(double) * w.n);  // pinned, read by the kernel directly (zero-copy)
   // scipy _numdiff: rel_step = sqrt(eps of the residual dtype) for the 2-point scheme
   const double rel_step = f32 ? std::sqrt((double)1.1920928955078125e-07) : std::sqrt(kEps);
-  HIP_TRY(ctx, launch_ba_perturb(w.d_x, w.n, rel_step, w.d_params, w.d_hvec, ctx->stream));
+  HIP_TRY(ctx, launch_ba_perturb(w.h_x, w.n, rel_step, w.d_params, w.d_hvec, ctx->stream));
   int rc = ba_eval_device(ctx, w, w.n + 1);
   if (rc) return rc;
   BaJacArgs ja;
@@ -408,11 +408,10 @@ int ba_linearize(mocap_ctx* ctx, BaWork& w, const double* x, int f32, int cauchy
   ja.Jaug = w.d_Jaug;
   ja.rho0 = nullptr;
   HIP_TRY(ctx, launch_ba_jacobian(ja, ctx->stream));
-  HIP_TRY(ctx, launch_ba_gram(w.d_Jaug, w.m_pad, w.NP, w.d_partial, w.ksplit, w.d_G, ctx->stream));
-  HIP_TRY(ctx, launch_ba_cost(w.d_r, w.d_valid, w.m, f32, cauchy, w.d_cost, ctx->stream));
-  // one download: G and the (cost, finite) pair sit back to back in the workspace
+  // G and the (cost, finite) pair are written straight into pinned host memory by the reduce / cost kernels
   const size_t nG = (size_t)w.NP * w.NP, span = (size_t)(w.d_cost - w.d_G) + 2;
-  HIP_TRY(ctx, hipMemcpyAsync(w.h_G, w.d_G, sizeof(double) * span, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, launch_ba_gram(w.d_Jaug, w.m_pad, w.NP, w.d_partial, w.ksplit, w.h_G, ctx->stream));
+  HIP_TRY(ctx, launch_ba_cost(w.d_r, w.d_valid, w.m, f32, cauchy, w.h_G + span - 2, ctx->stream));
   rc = ba_wait(ctx);
   if (rc) return rc;
   G.assign(w.h_G, w.h_G + nG);
@@ -469,6 +468,99 @@ extern "C" int mocap_ba_normal_eq(mocap_ctx* ctx, const double* x, int64_t N, co
   return MOCAP_OK;
 }
 
+// The same trust-region subproblem without an eigen-decomposition, for the case the reference always is in:
+// J has exactly-zero columns (the dead focal parameters, helpers.py:267-270), so `full_rank` of
+// solve_lsq_trust_region is False, no Gauss-Newton step is tried and alpha_lower = 0; all the secular
+// iteration needs is  |p(a)|  and  d|p|/da  for  p(a) = -(B + a I)^{-1} g  on the live block B = J^T J:
+//     phi(a) = |p| - Delta ,   phi'(a) = -(p^T (B + a I)^{-1} p) / |p|
+// (identical to scipy's sums over singular values: suf_k^2 / (s_k^2 + a)^3 etc.).  One Cholesky and two
+// solves per alpha (~15 k flops at 42 live parameters) instead of a 4 n^3 eigen-solve per linearisation.
+struct CholTR {
+  int na = 0;
+  std::vector<double> L, q, wv;
+  // L L^T = B + a I (row-major lower).  false = a pivot fell below 1e-10 of its diagonal entry: the block is
+  // numerically singular at this shift (e.g. the scale gauge of the rig near convergence) and the caller
+  // falls back to the eigen-decomposition, which handles vanishing singular values like scipy's SVD
+  bool factor(const std::vector<double>& B, double a) {
+    L = B;
+    for (int j = 0; j < na; j++) {
+      const double d0 = L[(size_t)j * na + j] + a;
+      double d = d0;
+      for (int k = 0; k < j; k++) d -= L[(size_t)j * na + k] * L[(size_t)j * na + k];
+      if (!(d > 1e-10 * d0)) return false;
+      d = std::sqrt(d);
+      L[(size_t)j * na + j] = d;
+      const double id = 1.0 / d;
+      for (int i = j + 1; i < na; i++) {
+        double v = L[(size_t)i * na + j];
+        const double* li = &L[(size_t)i * na];
+        const double* lj = &L[(size_t)j * na];
+        for (int k = 0; k < j; k++) v -= li[k] * lj[k];
+        L[(size_t)i * na + j] = v * id;
+      }
+    }
+    return true;
+  }
+  void solve(std::vector<double>& b) const {  // (L L^T) x = b in place
+    for (int i = 0; i < na; i++) {
+      double v = b[i];
+      for (int k = 0; k < i; k++) v -= L[(size_t)i * na + k] * b[k];
+      b[i] = v / L[(size_t)i * na + i];
+    }
+    for (int i = na - 1; i >= 0; i--) {
+      double v = b[i];
+      for (int k = i + 1; k < na; k++) v -= L[(size_t)k * na + i] * b[k];
+      b[i] = v / L[(size_t)i * na + i];
+    }
+  }
+};
+
+// solve_lsq_trust_region for a rank-deficient J (see CholTR); B, gl = live block of J^T J and of J^T f
+bool solve_tr_chol(CholTR& ch, const std::vector<double>& B, const std::vector<double>& gl, double Delta,
+                   double& alpha_io, std::vector<double>& pl) {
+  const int na = ch.na;
+  double alpha = alpha_io;
+  bool ok = true;
+  auto phi_and_derivative = [&](double a, double& phi, double& phi_prime) {
+    if (!ch.factor(B, a)) {
+      ok = false;
+      phi = phi_prime = 0;
+      return;
+    }
+    ch.q = gl;
+    ch.solve(ch.q);  // q = (B + a I)^{-1} g = -p
+    const double p_norm = norm2(ch.q);
+    ch.wv = ch.q;
+    ch.solve(ch.wv);
+    double pw = 0;
+    for (int i = 0; i < na; i++) pw += ch.q[i] * ch.wv[i];
+    phi = p_norm - Delta;
+    phi_prime = -pw / p_norm;
+  };
+  double alpha_upper = norm2(gl) / Delta;  // |suf| = |V^T g| = |g|
+  double alpha_lower = 0.0;
+  if (alpha == 0.0) alpha = std::max(0.001 * alpha_upper, std::sqrt(alpha_lower * alpha_upper));
+  for (int it = 0; it < 10; it++) {
+    if (alpha < alpha_lower || alpha > alpha_upper)
+      alpha = std::max(0.001 * alpha_upper, std::sqrt(alpha_lower * alpha_upper));
+    double phi, phi_prime;
+    phi_and_derivative(alpha, phi, phi_prime);
+    if (!ok) return false;
+    if (phi < 0) alpha_upper = alpha;
+    const double ratio = phi / phi_prime;
+    alpha_lower = std::max(alpha_lower, alpha - ratio);
+    alpha -= (phi + Delta) * ratio / Delta;
+    if (std::fabs(phi) < 0.01 * Delta) break;
+  }
+  pl = gl;
+  if (!ch.factor(B, alpha)) return false;
+  ch.solve(pl);
+  double pn = norm2(pl);
+  for (double& v : pl) v = pn > 0 ? -v * (Delta / pn) : -v;
+  alpha_io = alpha;
+  return true;
+}
+
 extern "C" int mocap_ba_solve(mocap_ctx* ctx, double* x, int64_t N, const double* obs, double ftol, double xtol,
                               double gtol, int max_iter, int f32_residuals, int use_cauchy, double* info) {
   if (!ctx) return MOCAP_E_ARG;
@@ -501,7 +593,9 @@ extern "C" int mocap_ba_solve(mocap_ctx* ctx, double* x, int64_t N, const double
   double alpha = 0.0, g_norm = 0.0;
   bool need_factor = true;
   std::vector<int> order(n), alive;
-  std::vector<double> Va, lama, eig_ms, lin_ms;
+  std::vector<double> Va, lama, eig_ms, lin_ms, Blive, glive, plive;
+  CholTR chol;
+  bool use_chol = false, eig_ready = false;
 
   while (true) {
     if (need_factor) {
@@ -530,6 +624,23 @@ extern "C" int mocap_ba_solve(mocap_ctx* ctx, double* x, int64_t N, const double
       A.assign((size_t)na * na, 0.0);
       for (int a = 0; a < na; a++)
         for (int b = 0; b < na; b++) A[(size_t)a * na + b] = JtJ[(size_t)alive[a] * n + alive[b]];
+      // exactly-zero columns of J <=> rank-deficient for scipy: the secular iteration needs no spectrum
+      use_chol = na < n && na > 0 && !getenv("MOCAP_BA_EIGEN");
+      eig_ready = false;
+      if (use_chol) {
+        chol.na = na;
+        Blive = A;
+        glive.resize(na);
+        for (int a = 0; a < na; a++) glive[a] = g[alive[a]];
+        t_eig += ms(te0, now());
+      }
+      need_factor = false;
+    }
+    auto ensure_eigen = [&]() {
+      if (eig_ready) return;
+      eig_ready = true;
+      const auto te0 = now();
+      const int na = (int)alive.size();
       sym_eig(na, A, Va, lama);
       V.assign((size_t)n * n, 0.0);
       lam.assign(n, 0.0);
@@ -556,12 +667,19 @@ extern "C" int mocap_ba_solve(mocap_ctx* ctx, double* x, int64_t N, const double
         }
         suf[k] = acc;  // s * U^T f = V^T J^T f
       }
-      need_factor = false;
-    }
+    };
+    if (!use_chol) ensure_eigen();
     double actual_reduction = -1, step_norm = 0, cost_new = cost;
     while (actual_reduction <= 0 && nfev < max_nfev) {
       const auto tt0 = now();
-      solve_tr(n, w.m, suf, s, Vs, Delta, alpha, step);
+      if (use_chol && !solve_tr_chol(chol, Blive, glive, Delta, alpha, plive)) use_chol = false;  // ill-conditioned
+      if (use_chol) {
+        step.assign(n, 0.0);
+        for (size_t a = 0; a < alive.size(); a++) step[alive[a]] = plive[a];
+      } else {
+        ensure_eigen();
+        solve_tr(n, w.m, suf, s, Vs, Delta, alpha, step);
+      }
       t_tr += ms(tt0, now());
       // predicted_reduction = -evaluate_quadratic(J, g, step) = -(0.5 |J step|^2 + step.g)
       double q = 0, l = 0;
