@@ -71,16 +71,35 @@ __global__ void ba_build_cameras_kernel(BaCamArgs a) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= a.P * a.C) return;
   const int p = idx / a.C, cam = idx - p * a.C;
-  const double* x = a.params + (size_t)p * a.n;
   double rt[12];
+  // the camera's six pose parameters: from the batch, or base point + this set's forward-difference step
+  // (ba_perturb_kernel's rule, fused: one launch less per linearisation)
+  double q[6];
+  if (a.params) {
+    const double* x = a.params + (size_t)p * a.n;
+    for (int k = 0; k < 6; k++) q[k] = cam ? x[(cam - 1) * 7 + 2 + k] : 0.0;
+  } else {
+    const int j = p - 1;  // perturbed parameter of this set (-1: none)
+    for (int k = 0; k < 6; k++) {
+      const int idxp = (cam - 1) * 7 + 2 + k;
+      double v = cam ? a.x[idxp] : 0.0;
+      if (cam && idxp == j) v = v + a.rel_step * (v >= 0.0 ? 1.0 : -1.0) * fmax(1.0, fabs(v));
+      q[k] = v;
+    }
+    if (cam == 0 && j >= 0) {  // dx_j = (x_j + h_j) - x_j, also for the dead focal entries
+      const double v = a.x[j];
+      const double x1 = v + a.rel_step * (v >= 0.0 ? 1.0 : -1.0) * fmax(1.0, fabs(v));
+      a.hvec[j] = x1 - v;
+    }
+  }
   if (cam == 0) {
     for (int k = 0; k < 12; k++) rt[k] = 0.0;
     rt[0] = rt[4] = rt[8] = 1.0;
   } else {
-    rotvec_to_matrix(x + (cam - 1) * 7 + 2, rt);
-    rt[9] = x[(cam - 1) * 7 + 5];
-    rt[10] = x[(cam - 1) * 7 + 6];
-    rt[11] = x[(cam - 1) * 7 + 7];
+    rotvec_to_matrix(q, rt);
+    rt[9] = q[3];
+    rt[10] = q[4];
+    rt[11] = q[5];
   }
   double* RT = a.RT + (size_t)p * a.stride_RT + 12 * cam;
   for (int k = 0; k < 12; k++) RT[k] = rt[k];
@@ -187,8 +206,18 @@ __global__ __launch_bounds__(64) void ba_gram_kernel(const double* __restrict__ 
   }
 }
 
-__global__ void ba_gram_reduce_kernel(const double* __restrict__ partial, int NP, int ksplit,
-                                      double* __restrict__ G) {
+__device__ void ba_cost_block(const double* __restrict__ r, const int32_t* __restrict__ valid, int64_t m,
+                              int f32_residuals, int use_cauchy, double* __restrict__ out);
+
+__global__ __launch_bounds__(256) void ba_gram_reduce_kernel(const double* __restrict__ partial, int NP, int ksplit,
+                                                             double* __restrict__ G, const double* __restrict__ r,
+                                                             const int32_t* __restrict__ valid, int64_t m,
+                                                             int f32_residuals, int use_cauchy,
+                                                             double* __restrict__ cost_out) {
+  if (cost_out && blockIdx.x == gridDim.x - 1) {  // the extra workgroup: cost of residual row r
+    ba_cost_block(r, valid, m, f32_residuals, use_cauchy, cost_out);
+    return;
+  }
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= NP * NP) return;
   double s = 0.0;
@@ -210,17 +239,26 @@ hipError_t launch_ba_gram(const double* Jaug, int64_t m_pad, int NP, double* par
   hipLaunchKernelGGL(ba_gram_kernel, dim3(nt * nt, ksplit), dim3(64), 0, stream, Jaug, m_pad, NP, ksplit,
                      partial);
   hipLaunchKernelGGL(ba_gram_reduce_kernel, dim3((NP * NP + 255) / 256), dim3(256), 0, stream, partial, NP,
-                     ksplit, G);
+                     ksplit, G, (const double*)nullptr, (const int32_t*)nullptr, (int64_t)0, 0, 0, (double*)nullptr);
+  return hipGetLastError();
+}
+
+hipError_t launch_ba_gram_cost(const double* Jaug, int64_t m_pad, int NP, double* partial, int ksplit, double* G,
+                               const double* r, const int32_t* valid, int64_t m, int f32_residuals, int use_cauchy,
+                               double* cost_out, hipStream_t stream) {
+  const int nt = NP / 16;
+  hipLaunchKernelGGL(ba_gram_kernel, dim3(nt * nt, ksplit), dim3(64), 0, stream, Jaug, m_pad, NP, ksplit,
+                     partial);
+  hipLaunchKernelGGL(ba_gram_reduce_kernel, dim3((NP * NP + 255) / 256 + 1), dim3(256), 0, stream, partial, NP,
+                     ksplit, G, r, valid, m, f32_residuals, use_cauchy, cost_out);
   return hipGetLastError();
 }
 
 // ---------------------------------------------------------------- cost of one residual vector
 // cost = 0.5 * sum rho(f^2) over the valid points (scipy loss_function(..., cost_only=True));
 // out[1] = 1 when every residual is finite.  Single workgroup, fixed-order tree -> reproducible.
-__global__ __launch_bounds__(256) void ba_cost_kernel(const double* __restrict__ r,
-                                                      const int32_t* __restrict__ valid, int64_t m,
-                                                      int f32_residuals, int use_cauchy,
-                                                      double* __restrict__ out) {
+__device__ void ba_cost_block(const double* __restrict__ r, const int32_t* __restrict__ valid, int64_t m,
+                              int f32_residuals, int use_cauchy, double* __restrict__ out) {
   __shared__ double sh[256];
   __shared__ int bad;
   if (threadIdx.x == 0) bad = 0;
@@ -243,6 +281,13 @@ __global__ __launch_bounds__(256) void ba_cost_kernel(const double* __restrict__
     out[0] = 0.5 * sh[0];
     out[1] = bad ? 0.0 : 1.0;
   }
+}
+
+__global__ __launch_bounds__(256) void ba_cost_kernel(const double* __restrict__ r,
+                                                      const int32_t* __restrict__ valid, int64_t m,
+                                                      int f32_residuals, int use_cauchy,
+                                                      double* __restrict__ out) {
+  ba_cost_block(r, valid, m, f32_residuals, use_cauchy, out);
 }
 
 hipError_t launch_ba_cost(const double* r, const int32_t* valid, int64_t m, int f32_residuals,

@@ -342,13 +342,17 @@ int ba_wait(mocap_ctx* ctx) {
 }
 
 // residuals for P parameter vectors already in w.d_params -> w.d_r [P][N]
-int ba_eval_device(mocap_ctx* ctx, BaWork& w, int P, const double* params = nullptr) {
+int ba_eval_device(mocap_ctx* ctx, BaWork& w, int P, const double* params = nullptr, const double* fd_x = nullptr,
+                   double rel_step = 0.0) {
   BaCamArgs ca;
   ca.C = w.C;
   ca.n = w.n;
   ca.P = P;
   ca.uniformK = w.uniformK;
-  ca.params = params ? params : w.d_params;
+  ca.params = fd_x ? nullptr : (params ? params : w.d_params);
+  ca.x = fd_x;
+  ca.rel_step = rel_step;
+  ca.hvec = w.d_hvec;
   ca.K = ctx->d_K9;
   ca.Pq = w.d_Pq;
   ca.RT = w.d_RT;
@@ -388,12 +392,11 @@ int ba_cost_at(mocap_ctx* ctx, BaWork& w, const double* x, int f32, int cauchy, 
 
 // linearise at x: G = [J|f]^T [J|f] (host copy, NP x NP), cost
 int ba_linearize(mocap_ctx* ctx, BaWork& w, const double* x, int f32, int cauchy, std::vector<double>& G,
-                 double& cost) {
+                 double& cost, bool* finite = nullptr) {
   memcpy(w.h_x, x, sizeof(double) * w.n);  // pinned, read by the kernel directly (zero-copy)
   // scipy _numdiff: rel_step = sqrt(eps of the residual dtype) for the 2-point scheme
   const double rel_step = f32 ? std::sqrt((double)1.1920928955078125e-07) : std::sqrt(kEps);
-  HIP_TRY(ctx, launch_ba_perturb(w.h_x, w.n, rel_step, w.d_params, w.d_hvec, ctx->stream));
-  int rc = ba_eval_device(ctx, w, w.n + 1);
+  int rc = ba_eval_device(ctx, w, w.n + 1, nullptr, w.h_x, rel_step);  // perturbation fused into the table build
   if (rc) return rc;
   BaJacArgs ja;
   ja.n = w.n;
@@ -410,12 +413,13 @@ int ba_linearize(mocap_ctx* ctx, BaWork& w, const double* x, int f32, int cauchy
   HIP_TRY(ctx, launch_ba_jacobian(ja, ctx->stream));
   // G and the (cost, finite) pair are written straight into pinned host memory by the reduce / cost kernels
   const size_t nG = (size_t)w.NP * w.NP, span = (size_t)(w.d_cost - w.d_G) + 2;
-  HIP_TRY(ctx, launch_ba_gram(w.d_Jaug, w.m_pad, w.NP, w.d_partial, w.ksplit, w.h_G, ctx->stream));
-  HIP_TRY(ctx, launch_ba_cost(w.d_r, w.d_valid, w.m, f32, cauchy, w.h_G + span - 2, ctx->stream));
+  HIP_TRY(ctx, launch_ba_gram_cost(w.d_Jaug, w.m_pad, w.NP, w.d_partial, w.ksplit, w.h_G, w.d_r, w.d_valid, w.m, f32,
+                                   cauchy, w.h_G + span - 2, ctx->stream));
   rc = ba_wait(ctx);
   if (rc) return rc;
   G.assign(w.h_G, w.h_G + nG);
   cost = w.h_G[span - 2];
+  if (finite) *finite = w.h_G[span - 1] != 0.0;
   return MOCAP_OK;
 }
 
@@ -595,7 +599,9 @@ extern "C" int mocap_ba_solve(mocap_ctx* ctx, double* x, int64_t N, const double
   std::vector<int> order(n), alive;
   std::vector<double> Va, lama, eig_ms, lin_ms, Blive, glive, plive;
   CholTR chol;
-  bool use_chol = false, eig_ready = false;
+  bool use_chol = false, eig_ready = false, have_trial = false;
+  const bool speculate = !getenv("MOCAP_BA_NO_SPECULATION");
+  std::vector<double> G_trial;
 
   while (true) {
     if (need_factor) {
@@ -670,6 +676,7 @@ extern "C" int mocap_ba_solve(mocap_ctx* ctx, double* x, int64_t N, const double
     };
     if (!use_chol) ensure_eigen();
     double actual_reduction = -1, step_norm = 0, cost_new = cost;
+    have_trial = false;
     while (actual_reduction <= 0 && nfev < max_nfev) {
       const auto tt0 = now();
       if (use_chol && !solve_tr_chol(chol, Blive, glive, Delta, alpha, plive)) use_chol = false;  // ill-conditioned
@@ -693,7 +700,15 @@ extern "C" int mocap_ba_solve(mocap_ctx* ctx, double* x, int64_t N, const double
       for (int i = 0; i < n; i++) x_new[i] = xv[i] + step[i];
       bool finite = true;
       const auto tc0 = now();
-      rc = ba_cost_at(ctx, w, x_new.data(), f32_residuals, use_cauchy, cost_new, finite);
+      // Speculative linearisation: the trial point is evaluated together with its forward-difference batch
+      // (one launch sequence, latency-bound either way).  Nine steps in ten are accepted, and then the
+      // Jacobian scipy would compute next at x_new is already here; a rejected step discards it.
+      if (speculate) {
+        rc = ba_linearize(ctx, w, x_new.data(), f32_residuals, use_cauchy, G_trial, cost_new, &finite);
+        have_trial = rc == MOCAP_OK;
+      } else {
+        rc = ba_cost_at(ctx, w, x_new.data(), f32_residuals, use_cauchy, cost_new, finite);
+      }
       if (rc) return rc;
       t_cost += ms(tc0, now());
       nfev++;
@@ -730,8 +745,12 @@ extern "C" int mocap_ba_solve(mocap_ctx* ctx, double* x, int64_t N, const double
       cost = cost_new;
       if (!termination) {  // (scipy re-linearises even when it is about to stop; the result is unused)
         const auto tl0 = now();
-        rc = ba_linearize(ctx, w, xv.data(), f32_residuals, use_cauchy, G, cost_new);
-        if (rc) return rc;
+        if (have_trial) {
+          G.swap(G_trial);  // linearised at x_new already (the last trial of the loop above is the accepted one)
+        } else {
+          rc = ba_linearize(ctx, w, xv.data(), f32_residuals, use_cauchy, G, cost_new);
+          if (rc) return rc;
+        }
         t_lin += ms(tl0, now());
         if (prof) lin_ms.push_back(ms(tl0, now()));
         njev++;

@@ -130,7 +130,10 @@ hipError_t launch_triangulate(const TriArgs& a, hipStream_t stream);
 // ---- bundle adjustment building blocks (csrc/ba_kernels.hip)
 struct BaCamArgs {
   int C, n, P, uniformK;
-  const double* params;  // [P][n]
+  const double* params;  // [P][n], or null: the finite-difference batch of `x` is formed on the fly
+  const double* x;       // [n] base point (params == null): set 0 = x, set 1 + j = x + h_j e_j
+  double rel_step;       // h_j = rel_step * sign(x_j) * max(1, |x_j|) (scipy _numdiff), written to hvec
+  double* hvec;          // [n]
   const double* K;       // [C][9]
   double* Pq;            // [P][...]
   double* RT;            // [P][C][12]
@@ -157,6 +160,10 @@ hipError_t launch_ba_jacobian(const BaJacArgs& a, hipStream_t stream);
 // G = Jaug^T Jaug on the matrix cores (v_mfma_f64_16x16x4_f64); G [NP][NP]
 hipError_t launch_ba_gram(const double* Jaug, int64_t m_pad, int NP, double* partial, int ksplit,
                           double* G, hipStream_t stream);
+// the same, with the cost of residual row r (launch_ba_cost) evaluated by one extra workgroup of the reduce launch
+hipError_t launch_ba_gram_cost(const double* Jaug, int64_t m_pad, int NP, double* partial, int ksplit, double* G,
+                               const double* r, const int32_t* valid, int64_t m, int f32_residuals, int use_cauchy,
+                               double* cost_out, hipStream_t stream);
 int ba_gram_ksplit(int64_t m_pad, int NP);
 
 // cost-only evaluation: sum of rho over valid points of residual row r [N]
