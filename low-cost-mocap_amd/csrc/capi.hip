@@ -94,6 +94,8 @@ extern "C" void mocap_destroy(mocap_ctx* ctx) {
   ctx->tables.release();
   for (auto& b : ctx->scratch) b.release();
   ctx->frame_ws.release();
+  if (ctx->live_pin) (void)hipHostFree(ctx->live_pin);
+  if (ctx->live_event) (void)hipEventDestroy(ctx->live_event);
   ctx->img_map.release();
   ctx->img_rot.release();
   ctx->img_mask.release();
@@ -487,6 +489,54 @@ extern "C" int mocap_match_triangulate(mocap_ctx* ctx, int64_t n_frames, int M_m
                b_corr = sizeof(int16_t) * F * K_max * C, b_i = sizeof(int32_t) * F;
   auto al = [](size_t x) { return (x + 255) / 256 * 256; };
   const size_t total = al(b_xyz) + al(b_err) + al(b_blobs) + al(b_counts) + al(b_corr) + 3 * al(b_i);
+  if (total <= (size_t)256 * 1024) {
+    // Live tracking (one or a few frames per call, helpers.py:94): zero-copy through pinned host memory.
+    // The kernels read the blobs from, and write the points to, device-visible host memory; eight small
+    // copy-engine transfers and a sleeping stream synchronise cost several times the kernels themselves.
+    if (total > ctx->live_pin_cap) {
+      if (ctx->live_pin) (void)hipHostFree(ctx->live_pin);
+      ctx->live_pin = nullptr;
+      ctx->live_pin_cap = 0;
+      HIP_TRY(ctx, hipHostMalloc(&ctx->live_pin, (size_t)256 * 1024, hipHostMallocDefault));
+      ctx->live_pin_cap = (size_t)256 * 1024;
+    }
+    if (!ctx->live_event) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->live_event, hipEventDisableTiming));
+    char* p = (char*)ctx->live_pin;
+    double* h_xyz = (double*)p;       p += al(b_xyz);
+    double* h_err = (double*)p;       p += al(b_err);
+    float* h_blobs = (float*)p;       p += al(b_blobs);
+    int32_t* h_counts = (int32_t*)p;  p += al(b_counts);
+    int16_t* h_corr = (int16_t*)p;    p += al(b_corr);
+    int32_t* h_n_out = (int32_t*)p;   p += al(b_i);
+    int32_t* h_status = (int32_t*)p;  p += al(b_i);
+    int32_t* h_n_cand = (int32_t*)p;
+    memcpy(h_blobs, blobs, b_blobs);
+    memcpy(h_counts, counts, b_counts);
+    int rc = match_dev_locked(ctx, n_frames, M_max, h_blobs, h_counts, gate_px, K_max, G_cap, h_xyz, h_err, h_corr,
+                              h_n_out, h_status, h_n_cand);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipEventRecord(ctx->live_event, ctx->stream));
+    for (long spins = 0;; spins++) {
+      const hipError_t e = hipEventQuery(ctx->live_event);
+      if (e == hipSuccess) break;
+      if (e != hipErrorNotReady) return ctx->hip_fail(e, "hipEventQuery");
+      if (spins > 2000000) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        break;
+      }
+    }
+    memcpy(n_out, h_n_out, b_i);
+    memcpy(status, h_status, b_i);
+    if (n_cand) memcpy(n_cand, h_n_cand, b_i);
+    // only the slots the kernel wrote (n_out per frame) carry data; the caller's buffers keep their fill beyond
+    for (size_t f = 0; f < F; f++) {
+      const size_t k = (size_t)(h_n_out[f] < 0 ? 0 : (h_n_out[f] > K_max ? K_max : h_n_out[f]));
+      memcpy(xyz + f * K_max * 3, h_xyz + f * K_max * 3, sizeof(double) * 3 * k);
+      memcpy(err + f * K_max, h_err + f * K_max, sizeof(double) * k);
+      memcpy(corr + f * K_max * C, h_corr + f * K_max * C, sizeof(int16_t) * C * k);
+    }
+    return MOCAP_OK;
+  }
   DevBuf& s = ctx->scratch[0];
   if (s.reserve(total)) return ctx->fail(MOCAP_E_HIP, "hipMalloc(%zu) failed", total);
   char* p = (char*)s.ptr;

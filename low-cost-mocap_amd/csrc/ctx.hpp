@@ -37,6 +37,9 @@ struct mocap_ctx {
   void* ba_pin = nullptr;
   size_t ba_pin_cap = 0;
   hipEvent_t ba_event = nullptr;
+  void* live_pin = nullptr;  // zero-copy staging of the live (few frames per call) host entry point
+  size_t live_pin_cap = 0;
+  hipEvent_t live_event = nullptr;
   DevBuf world;             // 16 doubles: the to-world matrix of the fused epilogue
   bool world_on = false;
   // blob extraction (mocap_set_image_params): frame geometry, undistortion maps, mask workspace
