@@ -80,14 +80,15 @@ __global__ void ba_build_cameras_kernel(BaCamArgs a) {
     for (int k = 0; k < 6; k++) q[k] = cam ? x[(cam - 1) * 7 + 2 + k] : 0.0;
   } else {
     const int j = p - 1;  // perturbed parameter of this set (-1: none)
+    const double* xb = a.x ? a.x : a.x_inline;
     for (int k = 0; k < 6; k++) {
       const int idxp = (cam - 1) * 7 + 2 + k;
-      double v = cam ? a.x[idxp] : 0.0;
+      double v = cam ? xb[idxp] : 0.0;
       if (cam && idxp == j) v = v + a.rel_step * (v >= 0.0 ? 1.0 : -1.0) * fmax(1.0, fabs(v));
       q[k] = v;
     }
     if (cam == 0 && j >= 0) {  // dx_j = (x_j + h_j) - x_j, also for the dead focal entries
-      const double v = a.x[j];
+      const double v = xb[j];
       const double x1 = v + a.rel_step * (v >= 0.0 ? 1.0 : -1.0) * fmax(1.0, fabs(v));
       a.hvec[j] = x1 - v;
     }
@@ -227,9 +228,11 @@ __global__ __launch_bounds__(256) void ba_gram_reduce_kernel(const double* __res
 
 int ba_gram_ksplit(int64_t m_pad, int NP) {
   (void)NP;
-  int64_t ks = m_pad / 256;
+  // one wave per 16 x 16 tile and K slice: a wave's loop is a chain of dependent load -> MFMA steps (~0.3 us
+  // each, nothing to overlap with), so short slices finish sooner: 8 steps (32 rows) per wave, up to 256 slices
+  int64_t ks = m_pad / 32;
   if (ks < 1) ks = 1;
-  if (ks > 64) ks = 64;
+  if (ks > 256) ks = 256;
   return (int)ks;
 }
 

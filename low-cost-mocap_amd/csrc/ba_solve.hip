@@ -351,6 +351,10 @@ int ba_eval_device(mocap_ctx* ctx, BaWork& w, int P, const double* params = null
   ca.uniformK = w.uniformK;
   ca.params = fd_x ? nullptr : (params ? params : w.d_params);
   ca.x = fd_x;
+  if (fd_x && w.n <= 64) {  // small rigs: the base point rides in the kernel arguments
+    memcpy(ca.x_inline, fd_x, sizeof(double) * w.n);
+    ca.x = nullptr;
+  }
   ca.rel_step = rel_step;
   ca.hvec = w.d_hvec;
   ca.K = ctx->d_K9;

@@ -15,10 +15,13 @@
 //   filter2D   = 5x5 integer correlation, clamp to [0, 255], reflect-101 borders
 //   grey       = (B*9798 + G*19235 + R*3735 + 16384) >> 15 on the channel-swapped frame, mask = grey > 51
 //
-// Two kernels:
+// Three kernels:
+//   blob_square_kernel    pre-pass: rot90 + make_square into a zero-framed layout, so that the gather below
+//                         has one path (no border / feather / rotation logic per tap); records the min / max
+//                         byte per (16-row band, 16-byte segment) for the exact dark-tile early-out.
 //   blob_mask_kernel      one workgroup per 64 x 64 output tile: the whole chain for the tile runs out of
-//                         LDS (undistorted 76 x 76 x 3 region -> row pass -> column pass -> 5x5 -> grey),
-//                         HBM sees the raw frame once (through L2 for the halo) and 1 bit per pixel out.
+//                         LDS (table-driven bilinear gather of the 76 x 76 x 3 region -> row pass (dot4) ->
+//                         column pass (dot2) -> 5x5 (signed dot4) -> grey), 1 bit per pixel out.
 //   blob_contour_kernel   one workgroup per image: border following WITHOUT the sequential raster scan of
 //                         Suzuki-Abe.  Every border (outer or hole) is a cycle of the Moore-tracing step
 //                         map; a cycle is identified by the smallest "horizontal pair" it passes
@@ -47,10 +50,6 @@ constexpr int BP = 68;              // its row stride (bytes): the 5x5 stage rea
 constexpr int VT = 78;              // stride (u16) of the column-major row-pass result: 76 rows + pad
 constexpr int kBlobThreads = 256;
 
-__device__ __forceinline__ int reflect101(int i, int n) {
-  i = i < 0 ? -i : i;
-  return i >= n ? 2 * (n - 1) - i : i;
-}
 
 }  // namespace
 

@@ -132,6 +132,7 @@ struct BaCamArgs {
   int C, n, P, uniformK;
   const double* params;  // [P][n], or null: the finite-difference batch of `x` is formed on the fly
   const double* x;       // [n] base point (params == null): set 0 = x, set 1 + j = x + h_j e_j
+  double x_inline[64];   // the same by value when n <= 64 (x == null): kernel arguments, no PCIe read
   double rel_step;       // h_j = rel_step * sign(x_j) * max(1, |x_j|) (scipy _numdiff), written to hvec
   double* hvec;          // [n]
   const double* K;       // [C][9]

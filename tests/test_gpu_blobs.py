@@ -63,6 +63,26 @@ def test_blobs_match_reference_golden(core, name):
             assert np.array_equal(res["blobs"][f, c, :n], g["ref_points"][f, c, :n].astype(np.float32))
 
 
+def test_helpers_mirror_returns_the_reference_lists(core):
+    """helpers.camera_read_find_dots = the per-camera body of Cameras._camera_read + _find_dot: same frames,
+    same nested lists ([[None, None]] for an empty camera) as the reference produced for the golden frames."""
+    from mocap_core import helpers
+    g = load_golden("blobs_c3_calib_rot")
+    helpers.set_core(core)
+    helpers.set_camera_params([{"intrinsic_matrix": g["K"][c].tolist(), "distortion_coef": g["dist"][c].tolist(),
+                                "rotation": int(g["rotation"][c])} for c in range(3)])
+    frames, image_points = helpers.camera_read_find_dots(list(g["images"][0]))
+    assert np.array_equal(np.array(frames), g["ref_frames"][0])
+    for c in range(3):
+        n = int(g["ref_counts"][0, c])
+        want = g["ref_points"][0, c, :n].tolist() if n else [[None, None]]
+        assert image_points[c] == want
+    # an empty camera yields the reference's sentinel
+    blank = np.zeros_like(g["images"][0])
+    _, pts = helpers.camera_read_find_dots(list(blank), want_frames=False)
+    assert pts == [[[None, None]]] * 3
+
+
 def test_synthetic_rig_frames(core):
     rig = synth.ring_rig(4)
     images, truth = synth.render_camera_frames(rig, 3, 8, seed=11)
