@@ -170,7 +170,7 @@ __global__ __launch_bounds__(kBlobThreads) void blob_mask_kernel(BlobArgs a) {
   const int WP = S + 2 * kSquarePad;
   const uint8_t* sq = a.squared + (size_t)img * (S + 2) * WP * 3;
   const uint32_t* tab = a.gather + ((size_t)a.cam_lens[cam] * tiles * tiles + tile) * kBlobGather;
-  const uint32_t row_bytes = (uint32_t)WP * 3;
+  const uint8_t* sq_below = sq + (size_t)WP * 3;  // the row under a tap
   const int words = (S + 63) / 64;
   unsigned long long* mask = a.mask + (size_t)img * S * words;
 
@@ -230,9 +230,9 @@ __global__ __launch_bounds__(kBlobThreads) void blob_mask_kernel(BlobArgs a) {
 #pragma unroll
     for (int k = 0; k < CH; k++)
       if (base / kBlobThreads + k < kIters) {
-        const uint8_t* p = sq + (mm[k] & 0x3fffffu);
-        __builtin_memcpy(&tt[k], p, 8);
-        __builtin_memcpy(&bb[k], p + row_bytes, 8);
+        const uint32_t off = mm[k] & 0x3fffffu;  // the same 32-bit lane offset against two uniform row bases
+        __builtin_memcpy(&tt[k], sq + off, 8);
+        __builtin_memcpy(&bb[k], sq_below + off, 8);
       }
 #pragma unroll
     for (int k = 0; k < CH; k++)
