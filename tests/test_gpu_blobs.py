@@ -214,6 +214,23 @@ def test_other_frame_geometries(core, rows, cols):
     assert np.array_equal(res["blobs"][ok], ref["blobs"][ok])
 
 
+def test_argument_errors_mirror_the_reference_domain():
+    """Geometries for which the reference's make_square raises (square frames, portrait after rot90, too little
+    padding) are rejected, not guessed at; calls before the lens model is set fail loudly."""
+    from mocap_core.capi import MocapCore, MocapError
+    fresh = MocapCore(0)
+    with pytest.raises(MocapError):                             # MOCAP_E_NOCAMS: no lens model yet
+        fresh._check(fresh.lib.mocap_find_blobs(fresh._h, 1, None, 4, None, None, None, None, None))
+    d = [synth.REFERENCE_DISTORTION]
+    for rows, cols, rot in ((320, 320, [0]), (310, 320, [0]), (240, 320, [1]), (240, 320, [3]), (320, 240, [0]), (240, 324, [0])):
+        with pytest.raises(MocapError):
+            fresh.set_image_params(rows, cols, [REF_K], d, rot)
+    fresh.set_image_params(240, 320, [REF_K], d, [2])          # the valid domain still works afterwards
+    out = fresh.find_blobs(np.zeros((0, 1, 240, 320, 3), dtype=np.uint8))
+    assert out["counts"].shape == (0, 1)
+    fresh.close()
+
+
 def test_blank_and_saturated_frames(core):
     images = np.zeros((1, 2, 240, 320, 3), dtype=np.uint8)
     images[0, 1] = 255                             # one huge blob touching every border of the frame area
