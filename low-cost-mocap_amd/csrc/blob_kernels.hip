@@ -26,9 +26,10 @@
 //                         Suzuki-Abe.  Every border (outer or hole) is a cycle of the Moore-tracing step
 //                         map; a cycle is identified by the smallest "horizontal pair" it passes
 //                         (foreground pixel with background at its left = where the raster scan would
-//                         have started an outer border, or at its right = a hole border).  All pairs are
-//                         traced in parallel, the pair that finds itself to be its cycle's minimum owns the
-//                         contour and accumulates the Green's-theorem sums (exact integers).  Parents come
+//                         have started an outer border, or at its right = a hole border).  Every pair walks
+//                         to the next pair of its border (work = total border length), pointer jumping over
+//                         these links finds each cycle's minimum in log2(pairs) rounds, and the pairs add
+//                         their segments' Green's-theorem sums to their contour (exact integers).  Parents come
 //                         from the pair met by walking left on the start row (Suzuki's LNBD rule, stated
 //                         geometrically), output order = pre-order with siblings in reverse discovery order
 //                         (cvInsertNodeIntoTree).  The parity tests check it against the sequential
@@ -369,7 +370,8 @@ namespace {
 struct ContourLds {
   uint32_t* msk;      // [(S+2)][stride] padded binary image, bit x of row y = pixel (y-1, x-1)
   uint32_t* pkey;     // [P_cap] horizontal pairs in raster order: ((y * 1024 + x) << 1) | type
-  uint32_t* pmin;     // [P_cap] smallest pair key on the pair's cycle
+  uint16_t* pnext[2]; // [P_cap] x 2: index of the next pair on the pair's border (double-buffered pointer jumping)
+  uint16_t* pmin[2];  // [P_cap] x 2: smallest pair INDEX seen on the border so far (pairs are sorted: index order = key order)
   uint32_t* ckey;     // [N_cap] start pair of each contour (discovery order)
   long long* ca;      // [N_cap][3] a00, a10, a01
   int* cleft;         // [N_cap] contour met by walking left from the start (-1 = frame)
@@ -398,24 +400,31 @@ __device__ __forceinline__ uint32_t ring8(const uint32_t* msk, int stride, int y
 
 __device__ __forceinline__ uint32_t pair_key(int y, int x, int type) { return ((uint32_t)(y * 1024 + x) << 1) | type; }
 
-// Follows the border cycle through the pair (pixel (y0, x0), background neighbour in direction d0 = 4
-// left / 0 right).  Returns the smallest horizontal pair on the cycle; with MOMENTS also the polygon sums
-// of cv::moments (contourMoments) over the cycle's vertex sequence, in original pixel coordinates.
+// From the horizontal pair (pixel (y0, x0), background neighbour in direction t0 = 4 left / 0 right) follows
+// the border -- the Moore-tracing step map, scanning the 8-neighbourhood counter-clockwise from the pixel it
+// came from (OpenCV's icvFetchContour order) -- until it crosses the NEXT horizontal pair, whose key it
+// returns.  With MOMENTS also the polygon sums of cv::moments (contourMoments) over the moves made on the
+// way, in original pixel coordinates: every move of a border lies between two consecutive pair crossings, so
+// the segment sums of a cycle's pairs add up to the contour's sums (exact integers, any order).
 template <bool MOMENTS>
-__device__ uint32_t trace_cycle(const uint32_t* msk, int stride, int y0, int x0, int d0, long long* a) {
-  int y = y0, x = x0, d = d0;
-  uint32_t mink = 0xffffffffu;
+__device__ uint32_t trace_segment(const uint32_t* msk, int stride, int y0, int x0, int t0, long long* a) {
+  int y = y0, x = x0, d = t0;
   long long a00 = 0, a10 = 0, a01 = 0;
+  uint32_t next_key;
   for (;;) {
     const uint32_t nb = ring8(msk, stride, y, x);
     // scan s = d+1, d+2, ... : rotate so that bit 0 = direction d+1
     const uint32_t rot = ((nb | (nb << 8)) >> ((d + 1) & 7)) & 0xffu;
-    const int k = rot ? __builtin_ctz(rot) : 8;         // background pixels crossed before the next border pixel
-    const uint32_t crossed8 = ((1u << k) - 1u) << ((d + 1) & 7);
-    const uint32_t crossed = (crossed8 | (crossed8 >> 8)) & 0xffu;
-    if (crossed & 0x10u) mink = min(mink, pair_key(y, x, 0));
-    if (crossed & 0x01u) mink = min(mink, pair_key(y, x, 1));
-    if (y == y0 && x == x0 && ((crossed >> d0) & 1u)) break;  // crossed the starting pair again: closed
+    const int k = rot ? __builtin_ctz(rot) : 8;  // background pixels crossed before the next border pixel
+    // scan positions of the left (4) and right (0) neighbour; a pair is crossed when its position is < k.
+    // (The pair the segment starts from sits at position 7 of its own first scan: only an isolated pixel,
+    // k = 8, comes back to it.)
+    const int p4 = (3 - d) & 7, p0 = (7 - d) & 7;
+    const int first = p4 < p0 ? p4 : p0;
+    if (first < k) {
+      next_key = pair_key(y, x, p4 < p0 ? 0 : 1);
+      break;
+    }
     const int s = (d + 1 + k) & 7;
     const int nx = x + (int)((0x21000122u >> (4 * s)) & 0xfu) - 1;
     const int ny = y + (int)((0x22210001u >> (4 * s)) & 0xfu) - 1;
@@ -435,7 +444,7 @@ __device__ uint32_t trace_cycle(const uint32_t* msk, int stride, int y0, int x0,
     a[1] = a10;
     a[2] = a01;
   }
-  return mink;
+  return next_key;
 }
 
 __device__ __forceinline__ int lower_bound_u32(const uint32_t* v, int n, uint32_t key) {
@@ -484,7 +493,10 @@ __global__ __launch_bounds__(kBlobThreads) void blob_contour_kernel(BlobArgs a, 
     L.ca = (long long*)p;       p += sizeof(long long) * 3 * N_cap;
     L.msk = (uint32_t*)p;       p += sizeof(uint32_t) * SP * stride;
     L.pkey = (uint32_t*)p;      p += sizeof(uint32_t) * P_cap;
-    L.pmin = (uint32_t*)p;      p += sizeof(uint32_t) * P_cap;
+    L.pnext[0] = (uint16_t*)p;  p += sizeof(uint16_t) * P_cap;
+    L.pnext[1] = (uint16_t*)p;  p += sizeof(uint16_t) * P_cap;
+    L.pmin[0] = (uint16_t*)p;   p += sizeof(uint16_t) * P_cap;
+    L.pmin[1] = (uint16_t*)p;   p += sizeof(uint16_t) * P_cap;
     L.ckey = (uint32_t*)p;      p += sizeof(uint32_t) * N_cap;
     L.cleft = (int*)p;          p += sizeof(int) * N_cap;
     L.cpar = (int*)p;           p += sizeof(int) * N_cap;
@@ -552,19 +564,39 @@ __global__ __launch_bounds__(kBlobThreads) void blob_contour_kernel(BlobArgs a, 
   }
   __syncthreads();
 
-  // ---- 2: every pair follows its cycle to find the cycle's smallest pair
+  // ---- 2: every pair walks to the NEXT pair of its border: the borders become linked lists (cycles) of pairs.
+  // Work is bounded by the total border length, whatever the shapes.
   for (int i = tid; i < n_pairs; i += kBlobThreads) {
     const uint32_t key = L.pkey[i];
     const int y = (int)(key >> 1) / 1024, x = (int)(key >> 1) % 1024;
-    L.pmin[i] = trace_cycle<false>(L.msk, stride, y, x, (key & 1u) ? 0 : 4, nullptr);
+    const uint32_t nk = trace_segment<false>(L.msk, stride, y, x, (key & 1u) ? 0 : 4, nullptr);
+    L.pnext[0][i] = (uint16_t)lower_bound_u32(L.pkey, n_pairs, nk);
+    L.pmin[0][i] = (uint16_t)i;
   }
   __syncthreads();
+  // ---- 2b: pointer jumping: after r rounds pmin[i] = smallest pair within 2^r steps; a cycle has <= n_pairs
+  // pairs, and a minimum does not mind being met twice
+  int cur = 0;
+  for (int span = 1; span < n_pairs; span <<= 1) {
+    const uint16_t* nx = L.pnext[cur];
+    const uint16_t* mn = L.pmin[cur];
+    uint16_t* nx2 = L.pnext[cur ^ 1];
+    uint16_t* mn2 = L.pmin[cur ^ 1];
+    for (int i = tid; i < n_pairs; i += kBlobThreads) {
+      const int j = nx[i];
+      mn2[i] = min(mn[i], mn[j]);
+      nx2[i] = nx[j];
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  const uint16_t* pmin = L.pmin[cur];  // index of the border's first pair in raster order = Suzuki-Abe's start
 
-  // ---- 3: contours = pairs that are their cycle's minimum, numbered in raster (= discovery) order
+  // ---- 3: contours = pairs that are their border's minimum, numbered in raster (= discovery) order
   const int pper = (n_pairs + kBlobThreads - 1) / kBlobThreads;
   const int p_lo = min(n_pairs, tid * pper), p_hi = min(n_pairs, p_lo + pper);
   int nst = 0;
-  for (int i = p_lo; i < p_hi; i++) nst += L.pmin[i] == L.pkey[i] ? 1 : 0;
+  for (int i = p_lo; i < p_hi; i++) nst += pmin[i] == i ? 1 : 0;
   int n_cont = 0;
   int coff = block_scan_excl(nst, L.scan, &n_cont);
   if (n_cont > N_cap) {
@@ -576,15 +608,27 @@ __global__ __launch_bounds__(kBlobThreads) void blob_contour_kernel(BlobArgs a, 
     return;
   }
   for (int i = p_lo; i < p_hi; i++)
-    if (L.pmin[i] == L.pkey[i]) L.ckey[coff++] = L.pkey[i];
+    if (pmin[i] == i) L.ckey[coff++] = L.pkey[i];
+  for (int c = tid; c < 3 * n_cont; c += kBlobThreads) L.ca[c] = 0;
   __syncthreads();
 
-  // ---- 4: per contour: polygon sums, and the border met by walking left on the start row
+  // ---- 4a: polygon sums: every pair adds the sums of its segment to its contour (integer atomics: exact)
+  for (int i = tid; i < n_pairs; i += kBlobThreads) {
+    const uint32_t key = L.pkey[i];
+    const int y = (int)(key >> 1) / 1024, x = (int)(key >> 1) % 1024;
+    long long sg[3];
+    trace_segment<true>(L.msk, stride, y, x, (key & 1u) ? 0 : 4, sg);
+    const int c = lower_bound_u32(L.ckey, n_cont, L.pkey[pmin[i]]);
+    unsigned long long* dst = (unsigned long long*)(L.ca + 3 * c);
+    if (sg[0]) atomicAdd(dst, (unsigned long long)sg[0]);
+    if (sg[1]) atomicAdd(dst + 1, (unsigned long long)sg[1]);
+    if (sg[2]) atomicAdd(dst + 2, (unsigned long long)sg[2]);
+  }
+  // ---- 4b: per contour: the border met by walking left on the start row
   for (int c = tid; c < n_cont; c += kBlobThreads) {
     const uint32_t key = L.ckey[c];
     const int hole = key & 1u;
     const int y = (int)(key >> 1) / 1024, x = (int)(key >> 1) % 1024;
-    trace_cycle<true>(L.msk, stride, y, x, hole ? 0 : 4, L.ca + 3 * c);
     // outer border: nearest foreground pixel q left of the start (its pair with the background at its
     // right); hole border: left end q of the foreground run the start sits in (pair with its left)
     const uint32_t* row = L.msk + y * stride;
@@ -606,7 +650,7 @@ __global__ __launch_bounds__(kBlobThreads) void blob_contour_kernel(BlobArgs a, 
     if (q >= 0) {
       const uint32_t pk = pair_key(y, q, hole ? 0 : 1);
       const int pi = lower_bound_u32(L.pkey, n_pairs, pk);
-      left = lower_bound_u32(L.ckey, n_cont, L.pmin[pi]);
+      left = lower_bound_u32(L.ckey, n_cont, L.pkey[pmin[pi]]);
     }
     L.cleft[c] = left;
   }
@@ -655,7 +699,7 @@ __global__ __launch_bounds__(kBlobThreads) void blob_contour_kernel(BlobArgs a, 
 
 size_t blob_contour_lds_bytes(int S, int P_cap, int N_cap) {
   const int SP = S + 2, stride = (SP + 31) / 32 + 1;
-  return sizeof(long long) * 3 * N_cap + sizeof(uint32_t) * SP * stride + sizeof(uint32_t) * 2 * P_cap +
+  return sizeof(long long) * 3 * N_cap + sizeof(uint32_t) * SP * stride + (sizeof(uint32_t) + 4 * sizeof(uint16_t)) * P_cap +
          sizeof(uint32_t) * N_cap + sizeof(int) * (4 * N_cap + 1) + sizeof(int) * 16;
 }
 
