@@ -216,13 +216,46 @@ __global__ __launch_bounds__(256) void ba_gram_reduce_kernel(const double* __res
                                                              int f32_residuals, int use_cauchy,
                                                              double* __restrict__ cost_out) {
   if (cost_out && blockIdx.x == gridDim.x - 1) {  // the extra workgroup: cost of residual row r
+    if (use_cauchy < 0) {
+      // r already holds the loss values rho(f_i^2) of the valid points (written by the Jacobian kernel, one
+      // lane per point): same addends, same order as ba_cost_block, without 16 k serial log1p in one workgroup
+      __shared__ double sh[256];
+      __shared__ int bad;
+      if (threadIdx.x == 0) bad = 0;
+      __syncthreads();
+      double s = 0.0;
+      for (int64_t i = threadIdx.x; i < m; i += 256) {
+        const double v = r[i];
+        if (!isfinite(v)) bad = 1;
+        s += v;
+      }
+      sh[threadIdx.x] = s;
+      __syncthreads();
+      for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+        __syncthreads();
+      }
+      if (threadIdx.x == 0) {
+        cost_out[0] = 0.5 * sh[0];
+        cost_out[1] = bad ? 0.0 : 1.0;
+      }
+      return;
+    }
     ba_cost_block(r, valid, m, f32_residuals, use_cauchy, cost_out);
     return;
   }
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= NP * NP) return;
   double s = 0.0;
-  for (int k = 0; k < ksplit; k++) s += partial[(size_t)k * NP * NP + idx];  // fixed order
+  int k = 0;
+  for (; k + 8 <= ksplit; k += 8) {  // eight loads in flight, added in slice order (fixed order)
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) v[u] = partial[(size_t)(k + u) * NP * NP + idx];
+#pragma unroll
+    for (int u = 0; u < 8; u++) s += v[u];
+  }
+  for (; k < ksplit; k++) s += partial[(size_t)k * NP * NP + idx];
   G[idx] = s;
 }
 

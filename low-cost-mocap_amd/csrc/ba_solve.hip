@@ -256,7 +256,7 @@ struct BaWork {
   size_t stride_Pq = 0, stride_RT = 0;
   double *d_x = nullptr, *d_params = nullptr, *d_hvec = nullptr, *d_Pq = nullptr, *d_RT = nullptr,
          *d_obs = nullptr, *d_r = nullptr, *d_Jaug = nullptr, *d_partial = nullptr, *d_G = nullptr,
-         *d_cost = nullptr;
+         *d_cost = nullptr, *d_rho = nullptr;
   int32_t* d_valid = nullptr;
   std::vector<int32_t> valid;
   double *h_x = nullptr, *h_G = nullptr;  // pinned: parameter upload, [G | cost, finite] download
@@ -291,8 +291,9 @@ int ba_setup(mocap_ctx* ctx, BaWork& w, int64_t N, const double* obs, int Pmax) 
                nd_Pq = al((size_t)Pmax * w.stride_Pq), nd_RT = al((size_t)Pmax * w.stride_RT),
                nd_obs = al((size_t)N * C * 2), nd_r = al((size_t)Pmax * N),
                nd_J = al((size_t)std::max<int64_t>(w.m_pad, 4) * w.NP),
-               nd_part = al((size_t)w.ksplit * w.NP * w.NP), nd_G = al((size_t)w.NP * w.NP), nd_cost = 32;
-  const size_t total = nd_x + nd_params + nd_h + nd_Pq + nd_RT + nd_obs + nd_r + nd_J + nd_part + nd_G + nd_cost;
+               nd_part = al((size_t)w.ksplit * w.NP * w.NP), nd_G = al((size_t)w.NP * w.NP), nd_cost = 32,
+               nd_rho = al((size_t)std::max<int64_t>(w.m, 1));
+  const size_t total = nd_x + nd_params + nd_h + nd_Pq + nd_RT + nd_obs + nd_r + nd_J + nd_part + nd_G + nd_cost + nd_rho;
   if (ctx->scratch[1].reserve(total * sizeof(double))) return ctx->fail(MOCAP_E_HIP, "hipMalloc(BA workspace) failed");
   if (ctx->scratch[2].reserve(sizeof(int32_t) * (size_t)std::max<int64_t>(w.m, 1)))
     return ctx->fail(MOCAP_E_HIP, "hipMalloc(BA valid list) failed");
@@ -307,7 +308,8 @@ int ba_setup(mocap_ctx* ctx, BaWork& w, int64_t N, const double* obs, int Pmax) 
   w.d_Jaug = p;     p += nd_J;
   w.d_partial = p;  p += nd_part;
   w.d_G = p;        p += nd_G;
-  w.d_cost = p;
+  w.d_cost = p;     p += nd_cost;
+  w.d_rho = p;
   w.d_valid = (int32_t*)ctx->scratch[2].ptr;
   const size_t pin_bytes = sizeof(double) * (nd_x + nd_G + nd_cost);
   if (pin_bytes > ctx->ba_pin_cap) {
@@ -413,12 +415,12 @@ int ba_linearize(mocap_ctx* ctx, BaWork& w, const double* x, int f32, int cauchy
   ja.f32_residuals = f32;
   ja.use_cauchy = cauchy;
   ja.Jaug = w.d_Jaug;
-  ja.rho0 = nullptr;
+  ja.rho0 = w.d_rho;  // loss value per valid point: the cost is then a plain sum (fused into the Gram reduce)
   HIP_TRY(ctx, launch_ba_jacobian(ja, ctx->stream));
   // G and the (cost, finite) pair are written straight into pinned host memory by the reduce / cost kernels
   const size_t nG = (size_t)w.NP * w.NP, span = (size_t)(w.d_cost - w.d_G) + 2;
-  HIP_TRY(ctx, launch_ba_gram_cost(w.d_Jaug, w.m_pad, w.NP, w.d_partial, w.ksplit, w.h_G, w.d_r, w.d_valid, w.m, f32,
-                                   cauchy, w.h_G + span - 2, ctx->stream));
+  HIP_TRY(ctx, launch_ba_gram_cost(w.d_Jaug, w.m_pad, w.NP, w.d_partial, w.ksplit, w.h_G, w.d_rho, nullptr, w.m, f32,
+                                   -1 /* rho precomputed */, w.h_G + span - 2, ctx->stream));
   rc = ba_wait(ctx);
   if (rc) return rc;
   G.assign(w.h_G, w.h_G + nG);
