@@ -233,3 +233,31 @@ def test_seven_point_models_satisfy_their_sample():
         h2 = np.c_[p2, np.ones(7)]
         assert np.abs(np.einsum("ni,ij,nj->n", h2, F, h1)).max() < 1e-6 * np.abs(F).max() * 320 * 320
     del rng
+
+
+def test_blob_oracle_recovers_rendered_markers():
+    """Physical sanity of the restated pipeline (independent of any OpenCV detail): dots rendered at the
+    lens-DISTORTED projection come back at the IDEAL pinhole pixel, i.e. the restated undistortion map
+    really inverts the Brown-Conrady model of camera-params.json, and make_square's 40-row offset is right."""
+    from mocap_core import synth
+    rig = synth.ring_rig(3)
+    strong = (-0.35, 0.10, 0.002, -0.001, 0.0)            # enough barrel distortion to move dots by several px
+    images, truth = synth.render_camera_frames(rig, 4, 8, seed=77, dropout=0.0, dist=strong, half_extent=1.0)
+    bo = c_oracle.BlobOracle(240, 320, rig["K"], [strong] * 3)
+    res = bo.find_blobs(images, M_max=32)
+    near = total = 0
+    worst_shift = 0.0
+    for f in range(4):
+        for c in range(3):
+            uv = truth["uv"][f, c]
+            uv = uv[~np.isnan(uv[:, 0])]
+            b = res["blobs"][f, c, :res["counts"][f, c]]
+            for p in uv:
+                total += 1
+                d = np.abs(b - p).max(axis=1).min()
+                near += d < 1.5
+                # how far the lens moved this dot: the test is only meaningful if that exceeds the tolerance
+                ud, vd = synth.distort_pixels(p[0], p[1], rig["K"][c], strong)
+                worst_shift = max(worst_shift, abs(ud - p[0]), abs(vd - p[1]))
+    assert near >= 0.9 * total, (near, total)
+    assert worst_shift > 2.0
