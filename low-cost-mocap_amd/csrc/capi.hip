@@ -383,19 +383,20 @@ static int match_dev_locked(mocap_ctx* ctx, int64_t n_frames, int M_max, const f
   // per frame keeps 4x more frames in flight per CU; everything else wants 256 lanes per frame
   int T = ctx->frame_threads ? ctx->frame_threads : (ctx->C * M_max <= 32 ? 64 : 256);
   const int hit_cap = ctx->hit_cap < 1 ? 1 : (ctx->hit_cap > M_max ? M_max : ctx->hit_cap);
-  bool wide = ctx->force_wide != 0;
+  // (a narrow frame with identical intrinsics keeps blob indices in one byte with 0xFF = none: 256 slots go wide)
+  bool wide = ctx->force_wide != 0 || (M_max > 255 && ctx->cv.uniformK);
   size_t lds = 0;
   if (!wide) {
-    lds = frame_lds_bytes(ctx->C, M_max, K_max, T, hit_cap, false);
+    lds = frame_lds_bytes(ctx->C, M_max, K_max, T, hit_cap, false, ctx->cv.uniformK != 0);
     while (lds > 160 * 1024 && T > 64) {
       T /= 2;
-      lds = frame_lds_bytes(ctx->C, M_max, K_max, T, hit_cap, false);
+      lds = frame_lds_bytes(ctx->C, M_max, K_max, T, hit_cap, false, ctx->cv.uniformK != 0);
     }
     wide = lds > 160 * 1024;  // the frame state does not fit LDS: big tables go to an HBM workspace
   }
   if (wide) {
     T = kWideThreads;
-    lds = frame_lds_bytes(ctx->C, M_max, K_max, T, hit_cap, true);
+    lds = frame_lds_bytes(ctx->C, M_max, K_max, T, hit_cap, true, false);
     if (lds > 160 * 1024)
       return ctx->fail(MOCAP_E_LIMIT, "frame state needs %zu B of LDS (C=%d, M_max=%d, K_max=%d): lower K_max",
                        lds, ctx->C, M_max, K_max);
@@ -412,7 +413,7 @@ static int match_dev_locked(mocap_ctx* ctx, int64_t n_frames, int M_max, const f
   const int64_t full_grid = (int64_t)ctx->num_cus * per_cu;
   int64_t grid = full_grid < n_frames ? full_grid : n_frames;
   if (wide) {
-    a.ws_stride = frame_ws_bytes(ctx->C, M_max, K_max, T, hit_cap, true);
+    a.ws_stride = frame_ws_bytes(ctx->C, M_max, K_max, T, hit_cap, true, false);
     if (ctx->frame_ws.reserve((size_t)full_grid * a.ws_stride))
       return ctx->fail(MOCAP_E_HIP, "hipMalloc(wide-frame workspace, %zu B) failed", (size_t)full_grid * a.ws_stride);
     a.ws = (unsigned char*)ctx->frame_ws.ptr;

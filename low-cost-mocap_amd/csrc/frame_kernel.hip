@@ -82,10 +82,13 @@ struct FrameLayout {
   size_t line, dist, seg_e, seg_x, seg_g, goff, gcnt, outslot, hcount, root_blob, root_cam, claimed, nact,
       cnt, misc, lds_total;                          // always LDS
   size_t bxy, cxy, hits, dig, nh, act, hb_d, hb_k;   // LDS when narrow, workspace when wide
+  size_t bt;                                          // table mode: DLT contribution per (camera, blob)
   size_t ws_total;
   int Hs;  // hit-list capacity per (root, camera): M when narrow (no cap), H when wide
   __host__ __device__ static size_t align(size_t x, size_t a) { return (x + a - 1) / a * a; }
-  __host__ __device__ FrameLayout(int C, int M, int R, int T, int H, bool wide) {
+  // table: identical intrinsics and narrow -> the per-lane group column holds blob INDICES (1 byte per camera)
+  // and the DLT contribution of every (camera, blob) is tabulated once per frame: [C][M][10] doubles
+  __host__ __device__ FrameLayout(int C, int M, int R, int T, int H, bool wide, bool table) {
     Hs = wide ? H : M;
     size_t o = 0;
     line = o;      o += sizeof(double) * kLineStride * R;
@@ -109,7 +112,9 @@ struct FrameLayout {
     nact = o;      o += R;
     o = align(o, 16);
     size_t w = wide ? 0 : o;  // the movable arrays continue in LDS, or start a workspace
-    cxy = w;       w += sizeof(float2) * (size_t)C * T;
+    cxy = w;       w += table ? (size_t)C * T : sizeof(float2) * (size_t)C * T;
+    w = align(w, 16);
+    bt = w;        w += table ? sizeof(double) * 10 * (size_t)C * M : 0;
     hb_d = w;      w += wide ? sizeof(double) * (size_t)R * H : 0;
     bxy = w;       w += wide ? 0 : sizeof(float2) * (size_t)C * M;
     nh = w;        w += sizeof(uint16_t) * (size_t)R * C;
@@ -123,8 +128,8 @@ struct FrameLayout {
   }
 };
 
-size_t frame_lds_bytes(int C, int M, int R, int T, int H, bool wide) { return FrameLayout(C, M, R, T, H, wide).lds_total; }
-size_t frame_ws_bytes(int C, int M, int R, int T, int H, bool wide) { return FrameLayout(C, M, R, T, H, wide).ws_total; }
+size_t frame_lds_bytes(int C, int M, int R, int T, int H, bool wide, bool table) { return FrameLayout(C, M, R, T, H, wide, table && !wide).lds_total; }
+size_t frame_ws_bytes(int C, int M, int R, int T, int H, bool wide, bool table) { return FrameLayout(C, M, R, T, H, wide, table && !wide).ws_total; }
 
 // misc[] slots
 enum { MI_NROOTS = 0, MI_STATUS = 1, MI_NOUT = 2, MI_G = 3, MI_ITEM = 4, MI_DEFER = 5 };
@@ -139,7 +144,10 @@ struct FrameState {
   uint32_t *seg_g, *goff, *gcnt;
   int32_t *outslot, *cnt, *misc;
   float2 *bxy;  // [C][M]  the frame's blobs
-  float2 *cxy;  // [C][T]  this lane's current group: observation per camera (NaN = none)
+  float2 *cxy;  // [C][T]  this lane's current group: observation per camera (NaN = none)   (!TABLE)
+  uint8_t *cix; // [C][T]  this lane's current group: blob index per camera (0xFF = none)    (TABLE)
+  double *bt;   // [C][M][10] DLT contribution of every blob                                   (TABLE)
+  static constexpr bool TABLE = UNIFORM_K && !WIDE;
   uint16_t *nh, *root_blob;
   uint8_t *hits;  // [R][C][M] blob indices of the gated hits, ascending distance (M <= 256)
   uint8_t *dig;   // [C][T]    this lane's odometer digits
@@ -150,7 +158,7 @@ struct FrameState {
 
   __device__ FrameState(const FrameArgs& p_, unsigned char* smem)
       : p(p_), cv(p_.cv), C(p_.cv.C), M(p_.M), R(p_.K_max), tid(threadIdx.x) {
-    const FrameLayout L(C, M, R, T, p_.H, WIDE);
+    const FrameLayout L(C, M, R, T, p_.H, WIDE, TABLE);
     Hs = L.Hs;
     line = (double*)(smem + L.line);
     dist = (double*)(smem + L.dist);
@@ -171,6 +179,8 @@ struct FrameState {
     unsigned char* big = WIDE ? p_.ws + (size_t)blockIdx.x * p_.ws_stride : smem;
     bxy = (float2*)(big + L.bxy);  // wide: re-pointed at the input frame in match()
     cxy = (float2*)(big + L.cxy) + tid;
+    cix = (uint8_t*)(big + L.cxy) + tid;
+    bt = (double*)(big + L.bt);
     hits = (uint8_t*)(big + L.hits);
     dig = (uint8_t*)(big + L.dig) + tid;
     nh = (uint16_t*)(big + L.nh);
@@ -196,6 +206,21 @@ struct FrameState {
       if (tid == 0) misc[MI_STATUS] = 0;
     }
     __syncthreads();
+    if (TABLE) {
+      // DLT contribution of every blob, once per frame: a candidate group then ADDS ten doubles per view
+      // instead of rebuilding two rows of A and their outer products (the Cartesian product revisits every
+      // blob thousands of times)
+      for (int i = tid; i < C * M; i += T) {
+        const int c = i / M, k = i - c * M;
+        if (k < cnt[c]) {
+          const float2 v = bxy[i];
+          double Bc[10];
+          dlt_contribution(Bc, as_ctab(cv.Pq + 12 * c), (double)v.x, (double)v.y);
+#pragma unroll
+          for (int e = 0; e < 10; e++) bt[(size_t)i * 10 + e] = Bc[e];
+        }
+      }
+    }
     {  // roots from camera 0 (helpers.py:349,357)
       const int n0 = cnt[0];
       for (int r = tid; r < n0 && r < R; r += T) {
@@ -502,7 +527,10 @@ struct FrameState {
         }
       }
       dig[(size_t)c * T] = (uint8_t)dgt;
-      cxy[(size_t)c * T] = s == kNone ? make_float2(qn, qn) : bxy[(size_t)c * M + s];
+      if (TABLE)
+        cix[(size_t)c * T] = s == kNone ? (uint8_t)0xFF : (uint8_t)s;
+      else
+        cxy[(size_t)c * T] = s == kNone ? make_float2(qn, qn) : bxy[(size_t)c * M + s];
     }
   }
 
@@ -517,7 +545,10 @@ struct FrameState {
       const bool wrap = d >= nhr[c];
       if (wrap) d = 0;
       dig[(size_t)c * T] = (uint8_t)d;
-      cxy[(size_t)c * T] = bxy[(size_t)c * M + hr[(size_t)c * Hs + d]];
+      if (TABLE)
+        cix[(size_t)c * T] = hr[(size_t)c * Hs + d];
+      else
+        cxy[(size_t)c * T] = bxy[(size_t)c * M + hr[(size_t)c * Hs + d]];
       if (!wrap) break;
     }
   }
@@ -549,9 +580,29 @@ struct FrameState {
         y = (double)v.y;
         return true;
       };
+      // table mode: the column holds blob indices; 0xFF marks "camera not in the group"
+      auto contrib = [&](int c, double (&B)[10]) -> bool {
+        const uint32_t k = cix[(size_t)c * T];
+        if (k == 0xFFu) return false;
+        const double* t = bt + ((size_t)c * M + k) * 10;
+#pragma unroll
+        for (int e = 0; e < 10; e++) B[e] = B[e] + t[e];
+        return true;
+      };
+      auto obs_ix = [&](int c, double& x, double& y) -> bool {
+        const uint32_t k = cix[(size_t)c * T];
+        if (k == 0xFFu) return false;
+        const float2 v = bxy[(size_t)c * M + k];
+        x = (double)v.x;
+        y = (double)v.y;
+        return true;
+      };
       while (true) {
         double X[3], e;
-        triangulate_and_score<UNIFORM_K, true, F32R>(cv, obs, obs, X, e);
+        if constexpr (TABLE)
+          triangulate_and_score_tab<true, F32R>(cv, contrib, obs_ix, X, e);
+        else
+          triangulate_and_score<UNIFORM_K, true, F32R>(cv, obs, obs, X, e);
         if (!have || e < best_e) {  // strict <: first minimum within the lane's ascending run
           have = true;
           best_e = e;
@@ -827,7 +878,7 @@ static hipError_t launch_T(const FrameArgs& a, int mode, int grid, size_t lds, h
 }
 
 hipError_t launch_frame_kernel(const FrameArgs& a, int mode, int threads, int grid, hipStream_t stream) {
-  const size_t lds = frame_lds_bytes(a.cv.C, a.M, a.K_max, threads, a.H, a.wide != 0);
+  const size_t lds = frame_lds_bytes(a.cv.C, a.M, a.K_max, threads, a.H, a.wide != 0, a.cv.uniformK != 0);
   if (a.wide) return threads == kWideThreads ? launch_T<kWideThreads, true>(a, mode, grid, lds, stream) : hipErrorInvalidValue;
   switch (threads) {
     case 64: return launch_T<64, false>(a, mode, grid, lds, stream);

@@ -53,8 +53,9 @@ struct FrameArgs {
 };
 
 constexpr int kWideThreads = 1024;  // workgroup size of the wide-frame variant (one workgroup per CU)
-size_t frame_lds_bytes(int C, int M, int R, int T, int H, bool wide);
-size_t frame_ws_bytes(int C, int M, int R, int T, int H, bool wide);
+// table = identical intrinsics (CamView::uniformK): per-blob DLT contributions tabulated in LDS (narrow frames only)
+size_t frame_lds_bytes(int C, int M, int R, int T, int H, bool wide, bool table);
+size_t frame_ws_bytes(int C, int M, int R, int T, int H, bool wide, bool table);
 hipError_t launch_frame_kernel(const FrameArgs& a, int mode, int threads, int grid, hipStream_t stream);
 
 // object (drone) locator over the frame path's output (reference helpers.py:424-480), csrc/post_kernels.hip

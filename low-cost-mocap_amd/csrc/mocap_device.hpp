@@ -242,9 +242,12 @@ __device__ __forceinline__ void smallest_eigvec4(double (&a)[10], double (&out)[
 __device__ __forceinline__ void smallest_eigvec4(double (&a)[10], double (&out)[4]) { smallest_eigvec4_cholesky(a, out); }
 #endif
 
-// DLT accumulation of one view: rows y*P2 - P1 and P0 - x*P2 (helpers.py:315-316) into B.
-__device__ __forceinline__ void dlt_accumulate(double (&B)[10], ctab_t P, double x,
-                                               double y) {
+// DLT contribution of one view: rows ra = y*P2 - P1 and rb = P0 - x*P2 (helpers.py:315-316),
+// Bc = ra ra^T + rb rb^T (packed symmetric).  B = A^T A is the sum of the views' contributions in camera
+// order (helpers.py:318 hands A^T A to LAPACK: its internal order is not pinned).  Keeping the contribution
+// a function of (camera, observation) alone lets the frame kernel tabulate it once per blob instead of once
+// per candidate group -- and every path (table or not, frame or explicit triangulation) rounds identically.
+__device__ __forceinline__ void dlt_contribution(double (&Bc)[10], ctab_t P, double x, double y) {
   double ra[4], rb[4];
 #pragma unroll
   for (int k = 0; k < 4; k++) {
@@ -254,7 +257,14 @@ __device__ __forceinline__ void dlt_accumulate(double (&B)[10], ctab_t P, double
 #pragma unroll
   for (int i = 0; i < 4; i++)
 #pragma unroll
-    for (int j = i; j < 4; j++) B[sidx(i, j)] = fma(ra[i], ra[j], fma(rb[i], rb[j], B[sidx(i, j)]));
+    for (int j = i; j < 4; j++) Bc[sidx(i, j)] = fma(ra[i], ra[j], rb[i] * rb[j]);
+}
+
+__device__ __forceinline__ void dlt_accumulate(double (&B)[10], ctab_t P, double x, double y) {
+  double Bc[10];
+  dlt_contribution(Bc, P, x, y);
+#pragma unroll
+  for (int e = 0; e < 10; e++) B[e] = B[e] + Bc[e];
 }
 
 // cv.projectPoints restated (helpers.py:231-237; OpenCV cvProjectPoints2, 3x3 R, no distortion):
@@ -286,21 +296,11 @@ __device__ __forceinline__ void reproject_sq(ctab_t RT, ctab_t K4, const double 
 //   (float64 array path of errors.mean(), helpers.py:241); otherwise left to right.
 //   F32R: reproduce OpenCV's float32 roundings (MOCAP_OPT_F32_ROUNDING).
 // Returns the number of views; X / err are valid when it is >= 2.
-template <bool UNIFORM_K, bool PAIRWISE, bool F32R, class Obs1, class Obs2>
-__device__ __forceinline__ int triangulate_and_score(const CamView& cv, Obs1&& obs1, Obs2&& obs2,
-                                                     double (&X)[3], double& err) {
+// Second half of triangulate_and_score: null vector of B (v views accumulated), point, reprojection error.
+template <bool UNIFORM_K, bool PAIRWISE, bool F32R, class Obs2>
+__device__ __forceinline__ void solve_and_score(const CamView& cv, double (&B)[10], int v, Obs2&& obs2,
+                                                double (&X)[3], double& err) {
   const int C = cv.C;
-  double B[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  int v = 0;
-  for (int c = 0; c < C; c++) {
-    double x, y;
-    if (obs1(c, x, y)) {
-      ctab_t P = as_ctab(UNIFORM_K ? cv.Pq + 12 * c : cv.Pq + 12 * ((size_t)v * C + c));
-      dlt_accumulate(B, P, x, y);
-      v++;
-    }
-  }
-  if (v <= 1) return v;  // helpers.py:300
   double vec[4];
   smallest_eigvec4(B, vec);
   const double rw = recip_refined(vec[3]);
@@ -354,6 +354,39 @@ __device__ __forceinline__ int triangulate_and_score(const CamView& cv, Obs1&& o
     }
   }
   err = (pw ? spw : seq) / (double)(2 * v);
+}
+
+template <bool UNIFORM_K, bool PAIRWISE, bool F32R, class Obs1, class Obs2>
+__device__ __forceinline__ int triangulate_and_score(const CamView& cv, Obs1&& obs1, Obs2&& obs2,
+                                                     double (&X)[3], double& err) {
+  const int C = cv.C;
+  double B[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  int v = 0;
+  for (int c = 0; c < C; c++) {
+    double x, y;
+    if (obs1(c, x, y)) {
+      ctab_t P = as_ctab(UNIFORM_K ? cv.Pq + 12 * c : cv.Pq + 12 * ((size_t)v * C + c));
+      dlt_accumulate(B, P, x, y);
+      v++;
+    }
+  }
+  if (v <= 1) return v;  // helpers.py:300
+  solve_and_score<UNIFORM_K, PAIRWISE, F32R>(cv, B, v, obs2, X, err);
+  return v;
+}
+
+// The same with the views' DLT contributions already tabulated (frame kernel, identical intrinsics):
+// contrib(c, B) adds camera c's contribution for the group's blob to B and returns true, or returns false
+// when the camera is not in the group.
+template <bool PAIRWISE, bool F32R, class Contrib, class Obs2>
+__device__ __forceinline__ int triangulate_and_score_tab(const CamView& cv, Contrib&& contrib, Obs2&& obs2,
+                                                         double (&X)[3], double& err) {
+  const int C = cv.C;
+  double B[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  int v = 0;
+  for (int c = 0; c < C; c++) v += contrib(c, B) ? 1 : 0;
+  if (v <= 1) return v;
+  solve_and_score<true, PAIRWISE, F32R>(cv, B, v, obs2, X, err);
   return v;
 }
 
