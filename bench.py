@@ -313,6 +313,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ba", action="store_true")
     ap.add_argument("--no-blobs", action="store_true")
+    ap.add_argument("--no-latency", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -461,7 +462,7 @@ def main():
             if not args.no_cpu_baseline and default_wl:
                 line["cpu_baseline"] = cpu_baseline(rig, blobs, counts)
                 line["config"]["host_cores"] = os.cpu_count()
-            if default_wl:
+            if default_wl and not args.no_latency:
                 core.set_stream(0)
                 line["latency"] = frame_latency(core, blobs, counts)
             if not args.no_blobs and default_wl:
