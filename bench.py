@@ -353,19 +353,33 @@ def main():
     d_status = torch.zeros(F, dtype=torch.int32, device=dev)
     d_ncand = torch.zeros(F, dtype=torch.int32, device=dev)
 
-    def hot_path():
-        core.match_triangulate_dev(F, M, d_blobs.data_ptr(), d_counts.data_ptr(), gate, K_MAX, G_CAP,
-                                   d_xyz.data_ptr(), d_err.data_ptr(), d_corr.data_ptr(), d_nout.data_ptr(),
-                                   d_status.data_ptr(), d_ncand.data_ptr())
+    def hot_path(lo=0, hi=None):
+        hi = F if hi is None else hi
+        core.match_triangulate_dev(hi - lo, M, d_blobs[lo:].data_ptr(), d_counts[lo:].data_ptr(), gate, K_MAX, G_CAP,
+                                   d_xyz[lo:].data_ptr(), d_err[lo:].data_ptr(), d_corr[lo:].data_ptr(),
+                                   d_nout[lo:].data_ptr(), d_status[lo:].data_ptr(), d_ncand[lo:].data_ptr())
+
+    # N > 1: the four output arrays are gathered as they are (no packing pass: measured at ~10 % of a step).
+    # MOCAP_BENCH_FORCE_SUB=s cuts a step's batch into s sub-batches with their own gathers, which would hide
+    # all but 1/s of the LAST step's exchange -- measured on one GPU the smaller launches cost more (s = 2: +3.9 %,
+    # 4: +11.7 %, the candidate counts are heavy-tailed) than that tail is worth, so the default is one batch;
+    # the variable also exercises the N > 1 loop on a single GPU.
+    SUB = int(os.environ.get("MOCAP_BENCH_FORCE_SUB", 0)) or 1
+    multi = world > 1 or SUB > 1
+    bounds = [(F * i // SUB, F * (i + 1) // SUB) for i in range(SUB)]
 
     def step():
         """One pass over the batch, then the one exchange of the path: final tracks -> rank 0.  The
-        gather is queued asynchronously (RCCL's own stream) so it overlaps the next step's kernels;
+        gathers are queued asynchronously (RCCL's own stream) so they overlap the following kernels;
         every handle is completed inside the timed region."""
-        hot_path()
-        if world > 1:
-            return mdist.gather_records_async(mdist.pack_records(d_nout, d_xyz, d_err, d_corr), dst=0)
-        return None
+        if not multi:
+            hot_path()
+            return []
+        hs = []
+        for lo, hi in bounds:
+            hot_path(lo, hi)
+            hs += mdist.gather_tracks_async((d_nout[lo:hi], d_xyz[lo:hi], d_err[lo:hi], d_corr[lo:hi]), dst=0)
+        return hs
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -374,8 +388,7 @@ def main():
         torch.cuda.synchronize(dev)
 
     for _ in range(args.warmup):
-        h = step()
-        if h is not None:
+        for h in step():
             h.result()
     fence()
     # kernel time with HIP events on the stream the kernel is launched on (torch's current stream)
@@ -383,13 +396,18 @@ def main():
     pending = []
     t0 = time.perf_counter()
     for i in range(args.steps):
+        if not multi:
+            ev[i][0].record(stream)
+            hot_path()
+            ev[i][1].record(stream)
+            continue
         ev[i][0].record(stream)
-        hot_path()
-        ev[i][1].record(stream)
-        if world > 1:
-            pending.append(mdist.gather_records_async(mdist.pack_records(d_nout, d_xyz, d_err, d_corr), dst=0))
-            if len(pending) > 2:          # at most two exchanges in flight (bounds the staging memory)
+        for lo, hi in bounds:
+            hot_path(lo, hi)
+            pending += mdist.gather_tracks_async((d_nout[lo:hi], d_xyz[lo:hi], d_err[lo:hi], d_corr[lo:hi]), dst=0)
+            while len(pending) > 2 * SUB * 4:   # at most two steps' exchanges in flight (bounds the staging memory)
                 pending.pop(0).result()
+        ev[i][1].record(stream)
     for h in pending:
         h.result()
     fence()

@@ -131,12 +131,21 @@ def _worker(rank, world, port, out_path):
     # the pipelined form bench.py uses: several exchanges in flight, completed later, same bytes
     handles = [mdist.gather_records_async(rec.clone(), dst=0) for _ in range(3)]
     later = [h.result() for h in handles]
+    # the form without the packing pass (bench.py at N > 1): one asynchronous gather per output array
+    arrays = (torch.from_numpy(res["n_out"]), torch.from_numpy(res["xyz"]), torch.from_numpy(res["err"]),
+              torch.from_numpy(res["corr"]))
+    parts = [h.result() for h in mdist.gather_tracks_async(arrays, dst=0)]
     if rank == 0:
         got = mdist.unpack_records(allrec, C, K)
         np.savez(out_path, **got)
         assert all(torch.equal(x, allrec) for x in later)
+        nF = allrec.shape[0]
+        assert np.array_equal(parts[0].numpy().view(np.int32).reshape(nF), got["n_out"])
+        assert np.array_equal(parts[1].numpy().view(np.float64).reshape(nF, K, 3), got["xyz"], equal_nan=True)
+        assert np.array_equal(parts[2].numpy().view(np.float64).reshape(nF, K), got["err"], equal_nan=True)
+        assert np.array_equal(parts[3].numpy().view(np.int16).reshape(nF, K, C), got["corr"])
     else:
-        assert allrec is None and all(x is None for x in later)
+        assert allrec is None and all(x is None for x in later) and all(x is None for x in parts)
     dist.barrier()
     dist.destroy_process_group()
 
