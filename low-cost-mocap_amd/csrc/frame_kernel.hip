@@ -85,6 +85,7 @@ struct FrameLayout {
   size_t bt;                                          // table mode: DLT contribution per (camera, blob)
   size_t ws_total;
   int Hs;  // hit-list capacity per (root, camera): M when narrow (no cap), H when wide
+  bool hb_lds;  // wide: hit buffers in LDS
   __host__ __device__ static size_t align(size_t x, size_t a) { return (x + a - 1) / a * a; }
   // table: identical intrinsics and narrow -> the per-lane group column holds blob INDICES (1 byte per camera)
   // and the DLT contribution of every (camera, blob) is tabulated once per frame: [C][M][10] doubles
@@ -111,17 +112,24 @@ struct FrameLayout {
     claimed = o;   o += M;
     nact = o;      o += R;
     o = align(o, 16);
+    // wide: the per-root hit buffers of the camera being matched are touched by a serial insertion sort per
+    // root: in LDS when they fit (64 x 256 at H = 16: 55 KB), else in the workspace (re-submits with H = M)
+    hb_lds = wide && o + align(sizeof(double) * (size_t)R * H, 16) + align((size_t)R * H, 16) <= (size_t)150 * 1024;
+    if (hb_lds) {
+      hb_d = o;    o += align(sizeof(double) * (size_t)R * H, 16);
+      hb_k = o;    o += align((size_t)R * H, 16);
+    }
     size_t w = wide ? 0 : o;  // the movable arrays continue in LDS, or start a workspace
     cxy = w;       w += table ? (size_t)C * T : sizeof(float2) * (size_t)C * T;
     w = align(w, 16);
     bt = w;        w += table ? sizeof(double) * 10 * (size_t)C * M : 0;
-    hb_d = w;      w += wide ? sizeof(double) * (size_t)R * H : 0;
+    if (!hb_lds) { hb_d = w; w += wide ? sizeof(double) * (size_t)R * H : 0; }
     bxy = w;       w += wide ? 0 : sizeof(float2) * (size_t)C * M;
     nh = w;        w += sizeof(uint16_t) * (size_t)R * C;
     hits = w;      w += (size_t)R * C * Hs;
     dig = w;       w += (size_t)C * T;
     act = w;       w += (size_t)R * C;
-    hb_k = w;      w += wide ? (size_t)R * H : 0;
+    if (!hb_lds) { hb_k = w; w += wide ? (size_t)R * H : 0; }
     w = align(w, 256);
     lds_total = wide ? o : align(w, 16);
     ws_total = wide ? w : 0;
@@ -185,8 +193,8 @@ struct FrameState {
     dig = (uint8_t*)(big + L.dig) + tid;
     nh = (uint16_t*)(big + L.nh);
     act = (uint8_t*)(big + L.act);
-    hb_d = (double*)(big + L.hb_d);
-    hb_k = (uint8_t*)(big + L.hb_k);
+    hb_d = (double*)((L.hb_lds ? smem : big) + L.hb_d);
+    hb_k = (uint8_t*)((L.hb_lds ? smem : big) + L.hb_k);
   }
 
   // ---------------------------------------------------------------- phases A-C
@@ -247,9 +255,10 @@ struct FrameState {
       // B1 (wave 0, which also owns B5: no workgroup barrier between B5 of camera i-1 and this):
       // epipolar line of every root in camera i.  cv.computeCorrespondEpilines on a float32
       // point: double math, scale by 1/sqrt(a^2+b^2), float32 result (helpers.py:363-364).
-      if (tid < 64) {
+      if (WIDE) __syncthreads();  // B5 of the previous camera (wave 0) -> B1 on every lane
+      if (WIDE || tid < 64) {
         const int nr = misc[MI_NROOTS];
-        for (int r = tid; r < nr; r += 64) {
+        for (int r = tid; r < nr; r += (WIDE ? T : 64)) {
           const int rc = root_cam[r], rb = root_blob[r];
           ctab_t Fm = as_ctab(cv.F + 9 * ((size_t)rc * C + i));
           const float2 rp = bxy[(size_t)rc * M + rb];
@@ -276,7 +285,7 @@ struct FrameState {
           nh[(size_t)r * C + i] = 0;
           if (WIDE) hcount[r] = 0;
         }
-        for (int k = tid; k < M; k += 64) claimed[k] = 0;
+        for (int k = tid; k < M; k += (WIDE ? T : 64)) claimed[k] = 0;
       }
       __syncthreads();
       const int nroots = misc[MI_NROOTS];
