@@ -288,7 +288,9 @@ extern "C" int mocap_set_image_params(mocap_ctx* ctx, int C, int rows, int cols,
   HIP_TRY(ctx, hipMemcpyAsync(ctx->img_map.ptr, map.data(), map.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(ctx->img_rot.ptr, rot.data(), C * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  if (ctx->img_S != S) ctx->img_sq_images = 0;  // the zero frame of the squared workspace has another shape
+  // another frame geometry: the rows the pre-pass leaves untouched (zero frame, empty rows) are different ones,
+  // so the workspace must be cleared again before its next use
+  if (ctx->img_S != S || ctx->img_rows != rows) ctx->img_sq_images = 0;
   ctx->img_C = C;
   ctx->img_rows = rows;
   ctx->img_cols = cols;
