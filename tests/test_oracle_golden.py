@@ -261,3 +261,62 @@ def test_blob_oracle_recovers_rendered_markers():
                 worst_shift = max(worst_shift, abs(ud - p[0]), abs(vd - p[1]))
     assert near >= 0.9 * total, (near, total)
     assert worst_shift > 2.0
+
+
+# ----------------------------------------------------------------------------- known answers of the restated OpenCV calls
+def test_find_contours_known_answers():
+    """Facts about cv.findContours / cv.moments that are common knowledge among OpenCV users and follow from
+    its border-following definition: a filled 3x3 square gives the 4 corner pixels, starting at the top-left
+    one and going down first (counter-clockwise on screen), with polygon area 4 (through pixel centres), not 9;
+    a single pixel is a 1-point contour of area 0; a 2-pixel bar has area 0; contours come bottom-most first;
+    a ring has an outer contour and a hole contour (an octagon: hole borders cut corners) whose parent is the outer one."""
+    from oracle import cv_image_restate as ci
+    m = np.zeros((7, 8), dtype=np.uint8)
+    m[1:4, 1:4] = 255
+    cs, h = ci.find_contours(m, ci.RETR_TREE, ci.CHAIN_APPROX_SIMPLE)
+    assert len(cs) == 1 and cs[0][:, 0].tolist() == [[1, 1], [1, 3], [3, 3], [3, 1]]
+    mo = ci.moments(cs[0])
+    assert mo["m00"] == 4.0 and mo["m10"] / mo["m00"] == 2.0 and mo["m01"] / mo["m00"] == 2.0
+    m = np.zeros((6, 6), dtype=np.uint8)
+    m[2, 3] = 255
+    cs, _ = ci.find_contours(m, ci.RETR_TREE, ci.CHAIN_APPROX_SIMPLE)
+    assert len(cs) == 1 and cs[0][:, 0].tolist() == [[3, 2]] and ci.moments(cs[0])["m00"] == 0.0
+    m[2, 4] = 255
+    cs, _ = ci.find_contours(m, ci.RETR_TREE, ci.CHAIN_APPROX_SIMPLE)
+    assert len(cs) == 1 and ci.moments(cs[0])["m00"] == 0.0          # a 2-pixel bar encloses nothing
+    m = np.zeros((10, 10), dtype=np.uint8)
+    m[1:3, 1:3] = 255
+    m[6:9, 5:8] = 255
+    cs, _ = ci.find_contours(m, ci.RETR_TREE, ci.CHAIN_APPROX_SIMPLE)
+    assert [c[0, 0].tolist() for c in cs] == [[5, 6], [1, 1]]          # the lower blob first
+    m = np.zeros((9, 9), dtype=np.uint8)
+    m[1:8, 1:8] = 255
+    m[3:6, 3:6] = 0
+    cs, h = ci.find_contours(m, ci.RETR_TREE, ci.CHAIN_APPROX_SIMPLE)
+    assert len(cs) == 2 and h[0, 0, 3] == -1 and h[0, 1, 3] == 0 and h[0, 0, 2] == 1
+    # the hole border runs over the foreground pixels 8-connected around the hole: it cuts the four corners
+    assert cs[1][:, 0].tolist() == [[2, 3], [3, 2], [5, 2], [6, 3], [6, 5], [5, 6], [3, 6], [2, 5]]
+    assert ci.moments(cs[0])["m00"] == 36.0 and ci.moments(cs[1])["m00"] == 14.0
+
+
+def test_image_filters_known_answers():
+    """The fixed-point pieces against values that follow from their definitions: the 9-tap kernel sums to 256
+    and is symmetric; blurring / sharpening a constant image leaves it constant (the sharpening kernel sums to 0:
+    constant -> 0); a lens without distortion has the identity map; BT.601 grey of (255, 255, 255) is 255;
+    the threshold is strict at floor(255 * 0.2) = 51."""
+    from oracle import blob_oracle as bo
+    from oracle import cv_image_restate as ci
+    k = ci.gaussian_kernel_fixed(9, 0)
+    assert sum(k) == 256 and k == k[::-1] and k[4] == max(k)
+    img = np.full((24, 24, 3), 77, dtype=np.uint8)
+    assert (ci.gaussian_blur(img, (9, 9), 0) == 77).all()
+    assert (ci.filter2d(img, -1, bo.SHARPEN) == 0).all() and int(bo.SHARPEN.sum()) == 0
+    sx, sy, fx, fy = ci.undistort_map([[300.0, 0, 100], [0, 310.0, 90], [0, 0, 1]], [0, 0, 0, 0, 0], 64, 64)
+    yy, xx = np.mgrid[0:64, 0:64]
+    assert np.array_equal(sx, xx) and np.array_equal(sy, yy) and not fx.any() and not fy.any()
+    ramp = np.arange(64 * 64 * 3, dtype=np.uint32).reshape(64, 64, 3).astype(np.uint8)
+    assert np.array_equal(ci.undistort(ramp, [[300.0, 0, 100], [0, 310.0, 90], [0, 0, 1]], [0, 0, 0, 0, 0]), ramp)
+    white = np.full((2, 2, 3), 255, dtype=np.uint8)
+    assert (ci.cvt_color(white, ci.COLOR_RGB2GRAY) == 255).all()
+    g = np.array([[50, 51, 52]], dtype=np.uint8)
+    assert ci.threshold(g, 255 * 0.2, 255, ci.THRESH_BINARY)[1].tolist() == [[0, 0, 255]]
