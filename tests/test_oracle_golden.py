@@ -320,3 +320,32 @@ def test_image_filters_known_answers():
     assert (ci.cvt_color(white, ci.COLOR_RGB2GRAY) == 255).all()
     g = np.array([[50, 51, 52]], dtype=np.uint8)
     assert ci.threshold(g, 255 * 0.2, 255, ci.THRESH_BINARY)[1].tolist() == [[0, 0, 255]]
+
+
+def test_pose_restatement_known_answers():
+    """Geometry the restated calibration calls must satisfy whatever OpenCV's internals are: on exact
+    correspondences RANSAC keeps every point and its F is the rig's fundamental matrix up to scale; E = K2^T F K1
+    has singular values (s, s, 0); the four candidates of motionFromEssential contain the true relative pose."""
+    from mocap_core import synth
+    from oracle import cv_pose_restate as cp
+    rig = synth.ring_rig(2)
+    obs, _ = synth.make_ba_observations(rig, 80, seed=4, noise_px=0.0, dropout=0.0)
+    p1, p2 = obs[:, 0].astype(np.float32), obs[:, 1].astype(np.float32)
+    F, mask, info = cp.find_fundamental_mat(p1, p2, cp.FM_RANSAC, 1.0, 0.99999, return_info=True)
+    assert info["inliers"] == 80 and mask.all()
+    K, R, t = rig["K"][0], rig["R"][1], rig["t"][1]
+    tx = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
+    F_true = np.linalg.inv(K).T @ tx @ R @ np.linalg.inv(K)
+    Fn, Ft = F / np.linalg.norm(F), F_true / np.linalg.norm(F_true)
+    if (Fn * Ft).sum() < 0:
+        Fn = -Fn
+    np.testing.assert_allclose(Fn, Ft, atol=5e-3)              # up to scale and sign; points are float32 pixels
+    E = cp.essential_from_fundamental(F, K, K)
+    sv = np.linalg.svd(E, compute_uv=False)
+    assert abs(sv[0] - sv[1]) < 2e-3 * sv[0] and sv[2] < 2e-3 * sv[0]
+    Rs, ts = cp.motion_from_essential(E)
+    tn = t / np.linalg.norm(t)
+    best = min(max(np.abs(Rc - R).max(), np.abs(tc.ravel() - tn).max()) for Rc, tc in zip(Rs, ts))
+    assert best < 5e-3
+    for Rc in Rs:
+        assert abs(np.linalg.det(Rc) - 1) < 1e-9
