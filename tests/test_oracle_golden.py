@@ -349,3 +349,32 @@ def test_pose_restatement_known_answers():
     assert best < 5e-3
     for Rc in Rs:
         assert abs(np.linalg.det(Rc) - 1) < 1e-9
+
+
+def test_hot_path_cv_restatements_known_answers():
+    """The three OpenCV calls of the hot path, against what their definitions imply for exact data:
+    fundamentalFromProjections gives x2^T F x1 = 0 for every projected 3-D point; computeCorrespondEpilines
+    returns the unit-normal line F x through the matching point; projectPoints equals K (R X + t)."""
+    from mocap_core import synth
+    from oracle import cv_restate as cr
+    rig = synth.ring_rig(3)
+    rng = np.random.default_rng(2)
+    X = rng.uniform(-0.5, 0.5, (20, 3)) @ rig["R0"].T + rig["centre"]
+    P = [mo.projection_matrix(rig["K"][c], rig["R"][c], rig["t"][c]) for c in range(3)]
+    F = cr.fundamental_from_projections(P[0], P[2])
+    uv = []
+    for c in (0, 2):
+        h = (P[c] @ np.c_[X, np.ones(20)].T).T
+        uv.append(h[:, :2] / h[:, 2:3])
+    h1, h2 = np.c_[uv[0], np.ones(20)], np.c_[uv[1], np.ones(20)]
+    assert np.abs(np.einsum("ni,ij,nj->n", h2, F, h1)).max() < 1e-9 * np.abs(F).max() * 320 * 320
+    saved = cr.F32_ROUNDING
+    try:
+        cr.F32_ROUNDING = False
+        lines = cr.compute_correspond_epilines(uv[0].astype(np.float32), 1, F)[:, 0]
+        assert np.allclose(np.hypot(lines[:, 0], lines[:, 1]), 1.0)
+        assert np.abs(np.einsum("ni,ni->n", lines, h2)).max() < 1e-3          # float32 input pixels
+        proj, _ = cr.project_points(X, rig["R"][2], rig["t"][2], rig["K"][2], [])
+        assert np.allclose(proj[:, 0], uv[1], atol=1e-9)
+    finally:
+        cr.F32_ROUNDING = saved
