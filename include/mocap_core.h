@@ -248,13 +248,28 @@ int mocap_ba_normal_eq(mocap_ctx* ctx, const double* x, int64_t N, const double*
                        int f32_residuals, int use_cauchy, double* JtJ, double* Jtr, double* cost,
                        double* J_out, int64_t* m_out);
 
+/* mocap_ba_trust_region_step: the subproblem of one iteration exactly as mocap_ba_solve solves it -- replaces
+ * scipy.optimize._lsq.common.solve_lsq_trust_region (scipy _lsq/common.py:57-, called from _lsq/trf.py:495) --
+ *     min 0.5 p^T JtJ p + Jtr^T p   subject to |p| <= Delta
+ * stated on the normal equations (JtJ [n][n], Jtr [n] as mocap_ba_normal_eq returns them; m = rows of J, used
+ * only by scipy's full-rank threshold eps*m*s_max).  *alpha_io: Levenberg-Marquardt parameter in (scipy's
+ * initial_alpha; 0 = none) and out.  method 0 = what mocap_ba_solve does (exactly-zero rows/columns deflated;
+ * Cholesky secular iteration when any were found, i.e. scipy's rank-deficient branch; symmetric
+ * eigen-decomposition otherwise or when a pivot collapses), 1 = eigen-decomposition always, 2 = Cholesky
+ * (MOCAP_E_NOCONV when a pivot collapses).  step [n] out; info [2] (may be NULL) = {method used (1|2), live
+ * parameters}.  Host-only arithmetic: exported so that parity tests can compare the step itself. */
+int mocap_ba_trust_region_step(mocap_ctx* ctx, int n, int64_t m, const double* JtJ, const double* Jtr,
+                               double Delta, double* alpha_io, int method, double* step, int32_t* info);
+
 /* mocap_ba_solve: resident Levenberg-Marquardt / trust-region loop (the algorithm of
  * scipy.optimize.least_squares(method="trf", loss="cauchy"), helpers.py:287-289, restated
  * on the normal equations).  x [n] in/out.
  *   ftol, xtol, gtol    termination tolerances (reference: ftol=1e-2, others 1e-8)
  *   max_iter            cap on LM iterations (0 = 100*n like scipy's max_nfev)
  *   f32_residuals       see above
- *   info [8]            (may be NULL) {iterations, nfev, status, cost0, cost, optimality, m, elapsed_ms} */
+ *   info [10]           (may be NULL) {iterations, nfev, status, cost0, cost, optimality, m, elapsed_ms, njev, 0}:
+ *                       nfev / njev / status / cost / optimality as scipy's OptimizeResult reports them
+ *                       (njev = 1 + accepted steps); iterations also counts passes whose every trial was rejected */
 int mocap_ba_solve(mocap_ctx* ctx, double* x, int64_t N, const double* obs, double ftol, double xtol,
                    double gtol, int max_iter, int f32_residuals, int use_cauchy, double* info);
 

@@ -125,10 +125,68 @@ hipError_t launch_ba_build_cameras(const BaCamArgs& a, hipStream_t stream) {
 }
 
 // ---------------------------------------------------------------- Jacobian + robust scaling
-// J[i][j] = (r_j[i] - r_0[i]) / dx_j ; with f32_residuals the residuals are first rounded to
-// float32 and differenced in float32, as the reference does (helpers.py:273 + _numdiff).
-// Cauchy loss (f_scale = 1): z = f^2, rho0 = log1p(z), rho1 = 1/(1+z), rho2 = -1/(1+z)^2;
-// J_scale = sqrt(max(rho1 + 2 rho2 f^2, EPS)); f <- f rho1 / J_scale ; J <- J_scale J.
+// J[i][j] = (r_j[i] - r_0[i]) / dx_j.  Cauchy loss (f_scale = 1): z = f^2, rho0 = log1p(z), rho1 = 1/(1+z),
+// rho2 = -1/(1+z)^2; J_scale = sqrt(max(rho1 + 2 rho2 f^2, EPS)); f <- f rho1 / J_scale ; J <- J_scale J.
+//
+// f32_residuals: the reference hands scipy a float32 residual vector (helpers.py:273), and NumPy's type rules
+// then decide the precision of every intermediate.  Restated operation by operation (NumPy 2 promotion):
+//   _numdiff._dense_difference:  df = fun(x1) - f0          float32 - float32 -> float32
+//                                J^T[i] = df / dx            float32 array / np.float64 scalar -> float64
+//   least_squares.loss_function: z = (f / f_scale) ** 2      float32
+//   least_squares.cauchy:        rho[0] = log1p(z), t = 1 + z, rho[1] = 1 / t, rho[2] = -1 / t**2
+//                                                            all float32, stored into the float64 `rho` array
+//   common.scale_for_robust_loss_function:
+//                                J_scale = rho[1] + 2 * rho[2] * f**2    float64 (f**2 is the float32 z)
+//                                f *= rho[1] / J_scale       float64 product, rounded into the float32 `f`
+// float32 log1p is taken correctly rounded (libm / SVML versions differ in the last bit; unpinned).
+struct CauchyTerms {
+  double f;       // residual as the optimizer sees it (float32-rounded when emulated)
+  double rho0;    // loss value
+  double jscale;  // row scale of J
+  double fs;      // scaled residual
+};
+__device__ inline CauchyTerms cauchy_terms(double r, int f32_residuals, int use_cauchy) {
+  CauchyTerms c;
+  if (f32_residuals) {
+    const float f = (float)r;
+    const float z = f * f;
+    c.f = (double)f;
+    if (!use_cauchy) {  // loss="linear": cost = 0.5 * np.dot(f, f) on the float32 vector
+      c.rho0 = (double)z;
+      c.jscale = 1.0;
+      c.fs = (double)f;
+      return c;
+    }
+    const float t = 1.0f + z;
+    const float rho1 = 1.0f / t;
+    const float rho2 = -1.0f / (t * t);
+    c.rho0 = (double)(float)log1p((double)z);
+    double js = (double)rho1 + (2.0 * (double)rho2) * (double)z;
+    if (js < 2.220446049250313e-16) js = 2.220446049250313e-16;
+    js = sqrt(js);
+    c.jscale = js;
+    c.fs = (double)(float)((double)f * ((double)rho1 / js));
+    return c;
+  }
+  c.f = r;
+  const double z = r * r;
+  if (!use_cauchy) {
+    c.rho0 = z;
+    c.jscale = 1.0;
+    c.fs = r;
+    return c;
+  }
+  const double t = 1.0 + z;
+  const double rho1 = 1.0 / t, rho2 = -1.0 / (t * t);
+  c.rho0 = log1p(z);
+  double js = rho1 + 2.0 * rho2 * z;
+  if (js < 2.220446049250313e-16) js = 2.220446049250313e-16;
+  js = sqrt(js);
+  c.jscale = js;
+  c.fs = r * (rho1 / js);
+  return c;
+}
+
 __global__ __launch_bounds__(256) void ba_jacobian_kernel(BaJacArgs a) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // valid-row index (fastest)
   const int j = blockIdx.y;                                          // column of Jaug
@@ -137,30 +195,19 @@ __global__ __launch_bounds__(256) void ba_jacobian_kernel(BaJacArgs a) {
   double out = 0.0;
   if (i < a.m && j <= a.n) {
     const int64_t idx = a.valid[i];
-    double f0 = a.r[idx];
-    if (a.f32_residuals) f0 = (double)(float)f0;
-    double jscale = 1.0, fs = f0, rho0 = f0 * f0;
-    if (a.use_cauchy) {
-      const double z = f0 * f0;
-      const double t = 1.0 + z;
-      const double rho1 = 1.0 / t, rho2 = -1.0 / (t * t);
-      rho0 = log1p(z);
-      jscale = rho1 + 2.0 * rho2 * (f0 * f0);
-      if (jscale < 2.220446049250313e-16) jscale = 2.220446049250313e-16;
-      jscale = sqrt(jscale);
-      fs = f0 * (rho1 / jscale);
-    }
+    const double r0 = a.r[idx];
+    const CauchyTerms c = cauchy_terms(r0, a.f32_residuals, a.use_cauchy);
     if (j == a.n) {
-      out = fs;
-      if (a.rho0) a.rho0[i] = rho0;
+      out = c.fs;
+      if (a.rho0) a.rho0[i] = c.rho0;
     } else {
-      double fj = a.r[(size_t)(1 + j) * a.N + idx];
+      const double fj = a.r[(size_t)(1 + j) * a.N + idx];
       double df;
       if (a.f32_residuals)
-        df = (double)((float)fj - (float)f0);
+        df = (double)((float)fj - (float)r0);
       else
-        df = fj - f0;
-      out = (df / a.hvec[j]) * jscale;
+        df = fj - r0;
+      out = (df / a.hvec[j]) * c.jscale;
     }
   }
   if (j < a.NP) a.Jaug[(size_t)i * a.NP + j] = out;
@@ -301,11 +348,9 @@ __device__ void ba_cost_block(const double* __restrict__ r, const int32_t* __res
   __syncthreads();
   double s = 0.0;
   for (int64_t i = threadIdx.x; i < m; i += 256) {
-    double f = r[valid[i]];
-    if (f32_residuals) f = (double)(float)f;
-    if (!isfinite(f)) bad = 1;
-    const double z = f * f;
-    s += use_cauchy ? log1p(z) : z;
+    const CauchyTerms c = cauchy_terms(r[valid[i]], f32_residuals, use_cauchy);
+    if (!isfinite(c.f)) bad = 1;
+    s += c.rho0;
   }
   sh[threadIdx.x] = s;
   __syncthreads();

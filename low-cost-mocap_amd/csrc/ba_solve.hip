@@ -401,7 +401,10 @@ int ba_linearize(mocap_ctx* ctx, BaWork& w, const double* x, int f32, int cauchy
                  double& cost, bool* finite = nullptr) {
   memcpy(w.h_x, x, sizeof(double) * w.n);  // pinned, read by the kernel directly (zero-copy)
   // scipy _numdiff: rel_step = sqrt(eps of the residual dtype) for the 2-point scheme
-  const double rel_step = f32 ? std::sqrt((double)1.1920928955078125e-07) : std::sqrt(kEps);
+  // (_eps_for_method returns np.finfo(np.float32).eps ** 0.5, a np.float32 scalar under NumPy 2 promotion:
+  // the square root is taken AND rounded in float32 -- 1.7e-8 off the float64 root, which is enough to move
+  // x + h and flip float32 roundings in ~1 % of the differenced residuals)
+  const double rel_step = f32 ? (double)std::sqrt(1.1920928955078125e-07f) : std::sqrt(kEps);
   int rc = ba_eval_device(ctx, w, w.n + 1, nullptr, w.h_x, rel_step);  // perturbation fused into the table build
   if (rc) return rc;
   BaJacArgs ja;
@@ -571,6 +574,116 @@ bool solve_tr_chol(CholTR& ch, const std::vector<double>& B, const std::vector<d
   return true;
 }
 
+// The subproblem solver as mocap_ba_solve drives it: dead parameters deflated exactly, then the Cholesky
+// secular iteration when J has zero columns (scipy's rank-deficient branch) and the eigen path otherwise or when
+// a pivot collapses.  Shared by the LM loop's test entry point below.
+struct TrSubproblem {
+  int n = 0;
+  int64_t m = 0;
+  std::vector<int> alive, order;
+  std::vector<double> A, Va, lama, V, lam, s, suf, Vs, Blive, glive, plive;
+  CholTR chol;
+  bool use_chol = false, eig_ready = false;
+  const double* JtJ = nullptr;
+  const double* g = nullptr;
+  // method: 0 = as mocap_ba_solve (Cholesky when rank-deficient), 1 = always eigen, 2 = Cholesky or fail
+  void prepare(int n_, int64_t m_, const double* JtJ_, const double* g_, int method) {
+    n = n_;
+    m = m_;
+    JtJ = JtJ_;
+    g = g_;
+    alive.clear();
+    for (int i = 0; i < n; i++) {
+      bool any = false;
+      for (int j = 0; j < n && !any; j++) any = JtJ[(size_t)i * n + j] != 0.0;
+      if (any) alive.push_back(i);
+    }
+    const int na = (int)alive.size();
+    A.assign((size_t)na * na, 0.0);
+    for (int a = 0; a < na; a++)
+      for (int b = 0; b < na; b++) A[(size_t)a * na + b] = JtJ[(size_t)alive[a] * n + alive[b]];
+    use_chol = method != 1 && na > 0 && (na < n || method == 2);
+    eig_ready = false;
+    if (use_chol) {
+      chol.na = na;
+      Blive = A;
+      glive.resize(na);
+      for (int a = 0; a < na; a++) glive[a] = g[alive[a]];
+    }
+  }
+  void ensure_eigen() {
+    if (eig_ready) return;
+    eig_ready = true;
+    const int na = (int)alive.size();
+    sym_eig(na, A, Va, lama);
+    V.assign((size_t)n * n, 0.0);
+    lam.assign(n, 0.0);
+    for (int k = 0; k < na; k++) {
+      lam[k] = lama[k];
+      for (int a = 0; a < na; a++) V[(size_t)alive[a] * n + k] = Va[(size_t)a * na + k];
+    }
+    {
+      int k = na;
+      for (int i = 0; i < n; i++)
+        if (!std::binary_search(alive.begin(), alive.end(), i)) V[(size_t)i * n + k++] = 1.0;
+    }
+    order.resize(n);
+    s.resize(n);
+    suf.resize(n);
+    Vs.resize((size_t)n * n);
+    for (int i = 0; i < n; i++) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return lam[a] > lam[b]; });
+    for (int k = 0; k < n; k++) {
+      const int src = order[k];
+      s[k] = std::sqrt(std::max(lam[src], 0.0));
+      double acc = 0;
+      for (int i = 0; i < n; i++) {
+        Vs[(size_t)i * n + k] = V[(size_t)i * n + src];
+        acc += V[(size_t)i * n + src] * g[i];
+      }
+      suf[k] = acc;  // s * U^T f = V^T J^T f
+    }
+  }
+  // returns the method that produced the step (1 eigen, 2 Cholesky)
+  int solve(double Delta, double& alpha, std::vector<double>& step, bool chol_only = false) {
+    if (use_chol && !solve_tr_chol(chol, Blive, glive, Delta, alpha, plive)) {
+      if (chol_only) return 0;
+      use_chol = false;  // ill-conditioned live block
+    }
+    if (use_chol) {
+      step.assign(n, 0.0);
+      for (size_t a = 0; a < alive.size(); a++) step[alive[a]] = plive[a];
+      return 2;
+    }
+    ensure_eigen();
+    solve_tr(n, m, suf, s, Vs, Delta, alpha, step);
+    return 1;
+  }
+};
+
+extern "C" int mocap_ba_trust_region_step(mocap_ctx* ctx, int n, int64_t m, const double* JtJ, const double* Jtr,
+                                          double Delta, double* alpha_io, int method, double* step, int32_t* info) {
+  // host-only arithmetic on caller-owned buffers: no context state is touched (ctx may be NULL; it only
+  // receives the error text)
+  if (n < 1 || !JtJ || !Jtr || !alpha_io || !step || !(Delta > 0) || method < 0 || method > 2)
+    return ctx ? ctx->fail(MOCAP_E_ARG, "mocap_ba_trust_region_step: bad argument") : MOCAP_E_ARG;
+  TrSubproblem tr;
+  tr.prepare(n, m, JtJ, Jtr, method);
+  std::vector<double> p;
+  double alpha = *alpha_io;
+  const int used = tr.solve(Delta, alpha, p, method == 2);
+  if (!used)
+    return ctx ? ctx->fail(MOCAP_E_NOCONV, "mocap_ba_trust_region_step: Cholesky pivot collapsed (method 2 has no fallback)")
+               : MOCAP_E_NOCONV;
+  memcpy(step, p.data(), sizeof(double) * n);
+  *alpha_io = alpha;
+  if (info) {
+    info[0] = used;
+    info[1] = (int32_t)tr.alive.size();
+  }
+  return MOCAP_OK;
+}
+
 extern "C" int mocap_ba_solve(mocap_ctx* ctx, double* x, int64_t N, const double* obs, double ftol, double xtol,
                               double gtol, int max_iter, int f32_residuals, int use_cauchy, double* info) {
   if (!ctx) return MOCAP_E_ARG;
@@ -591,8 +704,7 @@ extern "C" int mocap_ba_solve(mocap_ctx* ctx, double* x, int64_t N, const double
   if (w.m < 1) return ctx->fail(MOCAP_E_ARG, "mocap_ba_solve: no point is seen by two cameras");
   const int max_nfev = max_iter > 0 ? max_iter : 100 * n;  // scipy: max_nfev = 100 * n
 
-  std::vector<double> xv(x, x + n), G, JtJ((size_t)n * n), g(n), A, V, lam, s(n), suf(n), Vs((size_t)n * n),
-      step, x_new(n), tmp(n);
+  std::vector<double> xv(x, x + n), G, JtJ((size_t)n * n), g(n), step, x_new(n);
   double cost = 0;
   rc = ba_linearize(ctx, w, xv.data(), f32_residuals, use_cauchy, G, cost);
   if (rc) return rc;
@@ -602,10 +714,9 @@ extern "C" int mocap_ba_solve(mocap_ctx* ctx, double* x, int64_t N, const double
   if (Delta == 0) Delta = 1.0;
   double alpha = 0.0, g_norm = 0.0;
   bool need_factor = true;
-  std::vector<int> order(n), alive;
-  std::vector<double> Va, lama, eig_ms, lin_ms, Blive, glive, plive;
-  CholTR chol;
-  bool use_chol = false, eig_ready = false, have_trial = false;
+  std::vector<double> eig_ms, lin_ms;
+  TrSubproblem tr;
+  bool have_trial = false;
   const bool speculate = !getenv("MOCAP_BA_NO_SPECULATION");
   std::vector<double> G_trial;
 
@@ -621,78 +732,22 @@ extern "C" int mocap_ba_solve(mocap_ctx* ctx, double* x, int64_t N, const double
     if (g_norm < gtol) termination = 1;
     if (termination || nfev >= max_nfev) break;
     if (need_factor) {
-      const auto te0 = now();
       // Parameters without any effect (the dead focal entries, helpers.py:267-270) give exactly-zero
       // rows and columns of J^T J.  SciPy sees them as exactly-zero singular values of J; an
       // eigen-solver working on the squared matrix would return +-eps*lam_max instead, i.e. singular
-      // values ~1e-8 that pass the full-rank test.  Deflate them exactly: solve the live block only.
-      alive.clear();
-      for (int i = 0; i < n; i++) {
-        bool any = false;
-        for (int j = 0; j < n && !any; j++) any = JtJ[(size_t)i * n + j] != 0.0;
-        if (any) alive.push_back(i);
-      }
-      const int na = (int)alive.size();
-      A.assign((size_t)na * na, 0.0);
-      for (int a = 0; a < na; a++)
-        for (int b = 0; b < na; b++) A[(size_t)a * na + b] = JtJ[(size_t)alive[a] * n + alive[b]];
-      // exactly-zero columns of J <=> rank-deficient for scipy: the secular iteration needs no spectrum
-      use_chol = na < n && na > 0 && !getenv("MOCAP_BA_EIGEN");
-      eig_ready = false;
-      if (use_chol) {
-        chol.na = na;
-        Blive = A;
-        glive.resize(na);
-        for (int a = 0; a < na; a++) glive[a] = g[alive[a]];
-        t_eig += ms(te0, now());
-      }
+      // values ~1e-8 that pass the full-rank test.  Deflate them exactly: solve the live block only
+      // (TrSubproblem::prepare).  Exactly-zero columns of J <=> rank-deficient for scipy: the secular
+      // iteration needs no spectrum (Cholesky path).
+      const auto te0 = now();
+      tr.prepare(n, w.m, JtJ.data(), g.data(), getenv("MOCAP_BA_EIGEN") ? 1 : 0);
+      t_eig += ms(te0, now());
       need_factor = false;
     }
-    auto ensure_eigen = [&]() {
-      if (eig_ready) return;
-      eig_ready = true;
-      const auto te0 = now();
-      const int na = (int)alive.size();
-      sym_eig(na, A, Va, lama);
-      V.assign((size_t)n * n, 0.0);
-      lam.assign(n, 0.0);
-      for (int k = 0; k < na; k++) {
-        lam[k] = lama[k];
-        for (int a = 0; a < na; a++) V[(size_t)alive[a] * n + k] = Va[(size_t)a * na + k];
-      }
-      {
-        int k = na;
-        for (int i = 0; i < n; i++)
-          if (!std::binary_search(alive.begin(), alive.end(), i)) V[(size_t)i * n + k++] = 1.0;
-      }
-      t_eig += ms(te0, now());
-      if (prof) eig_ms.push_back(ms(te0, now()));
-      for (int i = 0; i < n; i++) order[i] = i;
-      std::sort(order.begin(), order.end(), [&](int a, int b) { return lam[a] > lam[b]; });
-      for (int k = 0; k < n; k++) {
-        const int src = order[k];
-        s[k] = std::sqrt(std::max(lam[src], 0.0));
-        double acc = 0;
-        for (int i = 0; i < n; i++) {
-          Vs[(size_t)i * n + k] = V[(size_t)i * n + src];
-          acc += V[(size_t)i * n + src] * g[i];
-        }
-        suf[k] = acc;  // s * U^T f = V^T J^T f
-      }
-    };
-    if (!use_chol) ensure_eigen();
     double actual_reduction = -1, step_norm = 0, cost_new = cost;
     have_trial = false;
     while (actual_reduction <= 0 && nfev < max_nfev) {
       const auto tt0 = now();
-      if (use_chol && !solve_tr_chol(chol, Blive, glive, Delta, alpha, plive)) use_chol = false;  // ill-conditioned
-      if (use_chol) {
-        step.assign(n, 0.0);
-        for (size_t a = 0; a < alive.size(); a++) step[alive[a]] = plive[a];
-      } else {
-        ensure_eigen();
-        solve_tr(n, w.m, suf, s, Vs, Delta, alpha, step);
-      }
+      tr.solve(Delta, alpha, step);
       t_tr += ms(tt0, now());
       // predicted_reduction = -evaluate_quadratic(J, g, step) = -(0.5 |J step|^2 + step.g)
       double q = 0, l = 0;
@@ -749,7 +804,8 @@ extern "C" int mocap_ba_solve(mocap_ctx* ctx, double* x, int64_t N, const double
     if (actual_reduction > 0) {
       xv = x_new;
       cost = cost_new;
-      if (!termination) {  // (scipy re-linearises even when it is about to stop; the result is unused)
+      njev++;              // scipy re-linearises even when it is about to stop (trf.py:534); the result is unused,
+      if (!termination) {  // so only the count is kept
         const auto tl0 = now();
         if (have_trial) {
           G.swap(G_trial);  // linearised at x_new already (the last trial of the loop above is the accepted one)
@@ -759,7 +815,6 @@ extern "C" int mocap_ba_solve(mocap_ctx* ctx, double* x, int64_t N, const double
         }
         t_lin += ms(tl0, now());
         if (prof) lin_ms.push_back(ms(tl0, now()));
-        njev++;
         need_factor = true;
       }
     }
@@ -795,6 +850,8 @@ extern "C" int mocap_ba_solve(mocap_ctx* ctx, double* x, int64_t N, const double
     info[5] = g_norm;
     info[6] = (double)w.m;
     info[7] = std::chrono::duration<double, std::milli>(t_end - t_begin).count();
+    info[8] = njev;
+    info[9] = 0.0;
   }
   return termination ? MOCAP_OK : MOCAP_E_NOCONV;
 }

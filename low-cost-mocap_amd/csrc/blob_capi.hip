@@ -182,7 +182,7 @@ extern "C" int mocap_set_image_params(mocap_ctx* ctx, int C, int rows, int cols,
   const int ay = (S - rows) / 2;
   if (cols != S || ay < 8 || S - ay - rows < 8)
     return ctx->fail(MOCAP_E_ARG, "frames must be landscape with >= 8 rows of square padding (reference make_square)");
-  if (S > 832) return ctx->fail(MOCAP_E_LIMIT, "frame edge %d exceeds 832 (contour tables + padded mask must fit 160 KB of LDS)", S);
+  if (S > kBlobMaxEdge) return ctx->fail(MOCAP_E_LIMIT, "frame edge %d exceeds 832 (contour tables + padded mask must fit 160 KB of LDS)", S);
   if (cols % 16) return ctx->fail(MOCAP_E_ARG, "frame width must be a multiple of 16");
   std::vector<int32_t> rot(C, 0);
   for (int c = 0; c < C; c++) {

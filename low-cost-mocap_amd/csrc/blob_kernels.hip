@@ -50,6 +50,7 @@ constexpr int BW = BT + 2 * HF;     // 68: blurred region edge
 constexpr int BP = 68;              // its row stride (bytes): the 5x5 stage reads at most column 67
 constexpr int VT = 78;              // stride (u16) of the column-major row-pass result: 76 rows + pad
 constexpr int kBlobThreads = 256;
+constexpr int kActSlots = kBlobActSlots;  // 16-byte segments per lane per row in the pre-pass
 
 
 }  // namespace
@@ -80,8 +81,15 @@ __global__ __launch_bounds__(kBlobThreads) void blob_square_kernel(BlobArgs a) {
   const int row_bytes = a.cols * 3;
   // activity of this band: per 16-byte segment the min / max byte over the band's rows (what the frame rows
   // hold AFTER feather scaling, i.e. exactly the bytes the mask kernel will gather)
-  __shared__ uint32_t act[4][64];
-  uint32_t mn = 0x00ff00ffu, mx = 0u;  // two 16-bit fields, min / max over even and odd bytes alike
+  // A lane owns segments lane, lane + 64, ... of a row (rows up to kActSlots * 1024 bytes: the host rejects
+  // wider frames), one accumulator pair per segment.
+  __shared__ uint32_t act[4][kActSlots * 64];
+  uint32_t mn[kActSlots], mx[kActSlots];  // two 16-bit fields, min / max over even and odd bytes alike
+#pragma unroll
+  for (int j = 0; j < kActSlots; j++) {
+    mn[j] = 0x00ff00ffu;
+    mx[j] = 0u;
+  }
 #pragma unroll
   for (int k = 0; k < kSquareRows / 4; k++) {
     const int Y = first + grp * kSquareRows + wave * (kSquareRows / 4) + k;
@@ -98,7 +106,10 @@ __global__ __launch_bounds__(kBlobThreads) void blob_square_kernel(BlobArgs a) {
     if (rot == 0) {
       // 16 bytes per lane: rows start 16-byte aligned in both layouts (cols % 16 == 0 checked by the host)
       const uint8_t* src = raw + (size_t)r * row_bytes;
-      for (int i = lane * 16; i < row_bytes; i += 64 * 16) {
+#pragma unroll
+      for (int j = 0; j < kActSlots; j++) {
+        const int i = (j * 64 + lane) * 16;
+        if (i >= row_bytes) break;
         uint4 v = *(const uint4*)(src + i);
         if (scale != 8) {
           uint32_t* w = (uint32_t*)&v;
@@ -115,8 +126,8 @@ __global__ __launch_bounds__(kBlobThreads) void blob_square_kernel(BlobArgs a) {
 #pragma unroll
           for (int q = 0; q < 4; q++) {
             const uint32_t e = w[q] & 0x00ff00ffu, o = (w[q] >> 8) & 0x00ff00ffu;
-            mn = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(v2u16, mn), __builtin_elementwise_min(__builtin_bit_cast(v2u16, e), __builtin_bit_cast(v2u16, o))));
-            mx = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(v2u16, mx), __builtin_elementwise_max(__builtin_bit_cast(v2u16, e), __builtin_bit_cast(v2u16, o))));
+            mn[j] = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(v2u16, mn[j]), __builtin_elementwise_min(__builtin_bit_cast(v2u16, e), __builtin_bit_cast(v2u16, o))));
+            mx[j] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(v2u16, mx[j]), __builtin_elementwise_max(__builtin_bit_cast(v2u16, e), __builtin_bit_cast(v2u16, o))));
           }
         }
       }
@@ -128,22 +139,28 @@ __global__ __launch_bounds__(kBlobThreads) void blob_square_kernel(BlobArgs a) {
         dst[3 * x + 1] = (uint8_t)((p[1] * scale) >> 3);
         dst[3 * x + 2] = (uint8_t)((p[2] * scale) >> 3);
       }
-      mn = 0u;  // rotated cameras: no activity summary -> "full range", their tiles are never skipped
-      mx = 0x00ff00ffu;
+#pragma unroll
+      for (int j = 0; j < kActSlots; j++) {  // rotated cameras: no activity summary -> "full range", their tiles are never skipped
+        mn[j] = 0u;
+        mx[j] = 0x00ff00ffu;
+      }
     }
   }
   if (a.activity) {
-    const uint32_t lo = min(mn & 0xffffu, mn >> 16), hi = max(mx & 0xffffu, mx >> 16);
-    act[wave][lane] = lo | hi << 8;
+#pragma unroll
+    for (int j = 0; j < kActSlots; j++) {
+      const uint32_t lo = min(mn[j] & 0xffffu, mn[j] >> 16), hi = max(mx[j] & 0xffffu, mx[j] >> 16);
+      act[wave][j * 64 + lane] = lo | hi << 8;
+    }
     __syncthreads();
     const int segs = row_bytes / 16;
-    if (wave == 0 && lane < segs) {
+    for (int s = threadIdx.x; s < segs; s += kBlobThreads) {
       uint32_t l = 255u, h = 0u;
       for (int w2 = 0; w2 < 4; w2++) {
-        l = min(l, act[w2][lane] & 0xffu);
-        h = max(h, act[w2][lane] >> 8);
+        l = min(l, act[w2][s] & 0xffu);
+        h = max(h, act[w2][s] >> 8);
       }
-      uint8_t* o = a.activity + (((size_t)img * groups + grp) * segs + lane) * 2;
+      uint8_t* o = a.activity + (((size_t)img * groups + grp) * segs + s) * 2;
       o[0] = (uint8_t)l;
       o[1] = (uint8_t)h;
     }

@@ -82,6 +82,8 @@ constexpr int kBlobHalo = 6;   // 4 (9x9 Gaussian) + 2 (5x5 filter)
 constexpr int kBlobRegion = (kBlobTile + 2 * kBlobHalo) * (kBlobTile + 2 * kBlobHalo);  // 5776 region pixels per tile
 constexpr int kBlobGather = ((kBlobRegion + 255) / 256) * 256;  // gather-table entries per tile (padded to 256)
 constexpr int kSquareRows = 16;  // squared rows per workgroup of the pre-pass = one band of the activity map
+constexpr int kBlobMaxEdge = 832;  // widest frame: contour tables + padded mask must fit 160 KB of LDS
+constexpr int kBlobActSlots = (kBlobMaxEdge * 3 / 16 + 63) / 64;  // 16-byte row segments per pre-pass lane (3)
 constexpr int kSquarePad = 16;  // zero pixels left and right of a squared-frame row (keeps rows 16-byte aligned)
 struct BlobArgs {
   int64_t n_images;        // images of this launch; camera = (img_base + image) % C

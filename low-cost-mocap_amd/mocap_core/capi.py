@@ -58,6 +58,7 @@ SIGNATURES = {
     "mocap_find_fundamental": (_i32, [_vp, _i64, _vp, _vp, _dbl, _dbl, _i32, _vp, _vp, _vp]),
     "mocap_ba_residuals": (_i32, [_vp, _i32, _vp, _i64, _vp, _vp]),
     "mocap_ba_normal_eq": (_i32, [_vp, _vp, _i64, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "mocap_ba_trust_region_step": (_i32, [_vp, _i32, _i64, _vp, _vp, _dbl, _vp, _i32, _vp, _vp]),
     "mocap_ba_solve": (_i32, [_vp, _vp, _i64, _vp, _dbl, _dbl, _dbl, _i32, _i32, _i32, _vp]),
 }
 
@@ -192,13 +193,14 @@ class MocapCore:
         bad = np.nonzero(res["status"])[0]
         if bad.size:
             F, C, M, _ = np.shape(blobs)
+            k0 = res["xyz"].shape[1]
             self._apply_frame_limits(M, self._force_wide)
             try:
+                # never less root capacity than the first call had (a caller's K_max may exceed C*M)
                 big = self.match_triangulate(np.asarray(blobs)[bad], np.asarray(counts)[bad], gate_px,
-                                             min(C * M, 1024), 1 << 24)
+                                             max(k0, min(C * M, 1024)), 1 << 24)
             finally:
                 self._apply_frame_limits(self._hit_cap, self._force_wide)
-            k0 = res["xyz"].shape[1]
             if big["n_out"].max(initial=0) > k0:
                 grow = int(big["n_out"].max())
                 for key, fill in (("xyz", np.nan), ("err", np.nan), ("corr", -1)):
@@ -344,13 +346,25 @@ class MocapCore:
             out["J"] = J[:m.value]
         return out
 
+    def ba_trust_region_step(self, JtJ, Jtr, m, Delta, alpha=0.0, method=0):
+        """The trust-region subproblem as mocap_ba_solve solves it -> (step, alpha, {"method", "live"})."""
+        JtJ = np.ascontiguousarray(JtJ, dtype=np.float64)
+        n = JtJ.shape[0]
+        Jtr = np.ascontiguousarray(Jtr, dtype=np.float64).reshape(n)
+        a = ctypes.c_double(float(alpha))
+        step = np.zeros(n)
+        info = np.zeros(2, dtype=np.int32)
+        self._check(self.lib.mocap_ba_trust_region_step(self._h, n, int(m), _p(JtJ), _p(Jtr), float(Delta),
+                                                        ctypes.addressof(a), int(method), _p(step), _p(info)))
+        return step, a.value, {"method": int(info[0]), "live": int(info[1])}
+
     def ba_solve(self, x0, obs, ftol=1e-2, xtol=1e-8, gtol=1e-8, max_iter=0, f32_residuals=True,
                  use_cauchy=True):
         x = np.array(x0, dtype=np.float64)
         obs = np.ascontiguousarray(obs, dtype=np.float64).reshape(-1, self.C, 2)
-        info = np.zeros(8)
+        info = np.zeros(10)
         rc = self._check(self.lib.mocap_ba_solve(self._h, _p(x), obs.shape[0], _p(obs), float(ftol), float(xtol),
                                                  float(gtol), int(max_iter), int(f32_residuals), int(use_cauchy),
                                                  _p(info)), allow=(MOCAP_E_NOCONV,))
-        keys = ("iterations", "nfev", "status", "cost0", "cost", "optimality", "m", "elapsed_ms")
+        keys = ("iterations", "nfev", "status", "cost0", "cost", "optimality", "m", "elapsed_ms", "njev")
         return x, dict(zip(keys, info.tolist()), converged=(rc == MOCAP_OK))

@@ -30,6 +30,8 @@ _state = {
     "cam_key": None,         # bytes of (K, R, t) currently uploaded
     "lock": threading.Lock(),
     "ba_mode": "resident",   # "resident" (LM loop in the core) | "scipy" (reference optimizer, GPU residuals)
+    "img_key": None,         # (rows, cols, K, dist, rot) of the lens model currently uploaded
+    "to_world": None,        # last Cameras.to_world_coords_matrix handed to set_to_world_coords_matrix
 }
 
 
@@ -41,14 +43,19 @@ def get_core(device_id=0):
 
 def set_core(core):
     """Use an existing MocapCore (e.g. one per GPU in a frame-sharded run)."""
-    _state["core"] = core
-    _state["cam_key"] = None
+    with _state["lock"]:
+        _state["core"] = core
+        _state["cam_key"] = None      # cameras, lens model and world transform live in the context:
+        _state["img_key"] = None      # re-upload them to the new one on first use
+        if core is not None and _state["to_world"] is not None:
+            core.set_world_transform(_state["to_world"])
 
 
 def set_camera_params(camera_params):
     """camera_params: list of {"intrinsic_matrix": 3x3 list, ...} (api/camera-params.json)."""
     _state["camera_params"] = [dict(p) for p in camera_params]
     _state["cam_key"] = None
+    _state["img_key"] = None
 
 
 def set_bundle_adjustment_mode(mode):
@@ -169,6 +176,12 @@ def find_point_correspondance_and_object_points(image_points, camera_poses, fram
         core = _upload_cameras(camera_poses)
         blobs, counts = pack_frame(image_points)
         res = core.match_triangulate_auto(blobs, counts, gate_px=5.0)
+    if int(res["status"][0]) != 0:
+        # still over a cap after the worst-case re-submit (> 2^24 candidate groups for one root, > 2^32 per
+        # frame, C*M > 1024 roots): the reference would enumerate the full product; an empty answer would be
+        # silently wrong
+        raise capi.MocapError(f"frame exceeds the core's limits (status {int(res['status'][0])}): "
+                              "candidate groups / roots over the caps of include/mocap_core.h")
     k = int(res["n_out"][0])
     if k == 0:
         return np.array([]), np.array([]), frames
@@ -202,12 +215,16 @@ def camera_read_find_dots(raw_frames, M_max=64, want_frames=True):
     with _state["lock"]:
         core = get_core()
         key = (rows, cols, K.tobytes(), dist.tobytes(), rot.tobytes())
-        if _state.get("img_key") != key:
+        if _state["img_key"] != key:
             core.set_image_params(rows, cols, K, dist, rot)
             _state["img_key"] = key
         res = core.find_blobs(raw[None], M_max=M_max, want_processed=want_frames)
         if (res["status"] & capi.BLOB_ST_POINT_OVERFLOW).any():     # more dots than slots: ask again
             res = core.find_blobs(raw[None], M_max=int(res["n_contours"].max()) + 1, want_processed=want_frames)
+    if (res["status"] & capi.BLOB_ST_CAP_OVERFLOW).any():
+        cams = np.nonzero(res["status"][0] & capi.BLOB_ST_CAP_OVERFLOW)[0].tolist()
+        raise capi.MocapError(f"camera(s) {cams}: more contours than the blob stage's largest tables hold "
+                              "(BLOB_ST_CAP_OVERFLOW); no centroids were produced for them")
     image_points = []
     for c in range(C):
         n = int(res["counts"][0, c])
@@ -222,6 +239,7 @@ def set_to_world_coords_matrix(to_world_coords_matrix):
     world coordinates -- the loop at helpers.py:96-103 runs fused in the kernel's store.  None = off
     (camera-0 coordinates, exactly what find_point_correspondance_and_object_points returns upstream)."""
     with _state["lock"]:
+        _state["to_world"] = None if to_world_coords_matrix is None else np.array(to_world_coords_matrix, dtype=np.float64)
         get_core().set_world_transform(to_world_coords_matrix)
 
 
@@ -313,7 +331,8 @@ def bundle_adjustment(image_points, camera_poses, socketio, return_info=False):
                 return r[~np.isnan(r)].astype(np.float32)       # helpers.py:273
 
             res = optimize.least_squares(residual_function, x0, verbose=0, loss="cauchy", ftol=1e-2)
-            x, info = res.x, {"iterations": res.njev, "nfev": res.nfev, "status": res.status, "cost": res.cost}
+            x, info = res.x, {"iterations": res.njev, "njev": res.njev, "nfev": res.nfev, "status": res.status,
+                       "cost": res.cost, "optimality": res.optimality}
         _state["cam_key"] = None
     poses = _params_to_camera_poses(x)
     if socketio is not None:

@@ -214,6 +214,44 @@ def test_other_frame_geometries(core, rows, cols):
     assert np.array_equal(res["blobs"][ok], ref["blobs"][ok])
 
 
+@pytest.mark.parametrize("rows,cols", [(240, 352), (480, 640), (600, 832)])
+def test_dark_tile_early_out_on_wide_frames(core, rows, cols):
+    """Rows wider than 1024 bytes (cols > 341): the pre-pass's activity map has more than 64 segments per
+    row.  Sparse frames (the default configuration: early-out on, no processed output) must give the same
+    centroids with the early-out on and off and equal the C oracle -- dots are placed in the right-hand part
+    of the frame, whose segments a 64-entry activity row would never have written (round-1 advisor finding)."""
+    from oracle import c_oracle
+    rng = np.random.default_rng(cols)
+    C, F = 2, 2
+    K = np.array([[cols * 1.0, 0, cols / 2], [0, cols * 1.0, cols / 2], [0, 0, 1]])
+    images = np.zeros((F, C, rows, cols, 3), dtype=np.uint8)
+    yy, xx = np.mgrid[0:rows, 0:cols]
+    for f in range(F):
+        for c in range(C):
+            img = np.zeros((rows, cols), dtype=np.float32)
+            for k in range(10):
+                # most dots beyond byte 1024 of a row, a few on the left
+                cx = rng.uniform(345, cols - 8) if (k < 8 and cols > 360) else rng.uniform(8, cols - 8)
+                cy, sg = rng.uniform(8, rows - 8), rng.uniform(1.0, 3.0)
+                img += 400 * np.exp(-((xx - cx) ** 2 + (yy - cy) ** 2) / (2 * sg * sg))
+            images[f, c] = np.clip(img, 0, 255).astype(np.uint8)[..., None]
+    images[1, 0] = np.maximum(images[1, 0], rng.integers(0, 3, images[1, 0].shape, dtype=np.uint8))   # range 2: still skippable
+    dists = [synth.REFERENCE_DISTORTION, [-0.2, 0.1, 0.002, -0.001, 0.05]]
+    core.set_image_params(rows, cols, [K, K], dists, [0, 0])
+    try:
+        core.set_blob_options(skip_dark_tiles=True)
+        on = core.find_blobs(images, M_max=64)
+        core.set_blob_options(skip_dark_tiles=False)
+        off = core.find_blobs(images, M_max=64)
+    finally:
+        core.set_blob_options(skip_dark_tiles=True)
+    ref = c_oracle.BlobOracle(rows, cols, [K, K], dists, [0, 0]).find_blobs(images, M_max=64)
+    assert ref["counts"].min() >= 6
+    for k in ("blobs", "counts", "n_contours"):
+        assert np.array_equal(on[k], off[k]), k
+        assert np.array_equal(on[k], ref[k]), k
+
+
 def test_argument_errors_mirror_the_reference_domain():
     """Geometries for which the reference's make_square raises (square frames, portrait after rot90, too little
     padding) are rejected, not guessed at; calls before the lens model is set fail loudly."""
