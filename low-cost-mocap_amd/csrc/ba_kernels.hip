@@ -67,6 +67,37 @@ __device__ inline void rotvec_to_matrix(const double* rv, double* R) {
   R[8] = -x2 - y2 + z2 + w2;
 }
 
+// Pose parameters of camera `cam` in parameter set p of a forward-difference batch around xb: set 0 = xb,
+// set 1 + j = xb + h_j e_j with scipy's step rule (see ba_perturb_kernel) -> rt = [R row-major | t].
+__device__ inline void ba_fd_camera_pose(const double* xb, double rel_step, int p, int cam, double (&rt)[12]) {
+  if (cam == 0) {
+    for (int k = 0; k < 12; k++) rt[k] = 0.0;
+    rt[0] = rt[4] = rt[8] = 1.0;
+    return;
+  }
+  const int j = p - 1;  // perturbed parameter of this set (-1: none)
+  double q[6];
+  for (int k = 0; k < 6; k++) {
+    const int idxp = (cam - 1) * 7 + 2 + k;
+    double v = xb[idxp];
+    if (idxp == j) v = v + rel_step * (v >= 0.0 ? 1.0 : -1.0) * fmax(1.0, fabs(v));
+    q[k] = v;
+  }
+  rotvec_to_matrix(q, rt);
+  rt[9] = q[3];
+  rt[10] = q[4];
+  rt[11] = q[5];
+}
+
+// one row-block of P = K @ [R | t] (helpers.py:306-307)
+__device__ inline void ba_projection(const double* K, const double (&rt)[12], double* P) {
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 4; c++) {
+      const double r0 = c < 3 ? rt[c] : rt[9], r1 = c < 3 ? rt[3 + c] : rt[10], r2 = c < 3 ? rt[6 + c] : rt[11];
+      P[r * 4 + c] = K[r * 3 + 0] * r0 + K[r * 3 + 1] * r1 + K[r * 3 + 2] * r2;
+    }
+}
+
 __global__ void ba_build_cameras_kernel(BaCamArgs a) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= a.P * a.C) return;
@@ -74,48 +105,35 @@ __global__ void ba_build_cameras_kernel(BaCamArgs a) {
   double rt[12];
   // the camera's six pose parameters: from the batch, or base point + this set's forward-difference step
   // (ba_perturb_kernel's rule, fused: one launch less per linearisation)
-  double q[6];
   if (a.params) {
     const double* x = a.params + (size_t)p * a.n;
+    double q[6];
     for (int k = 0; k < 6; k++) q[k] = cam ? x[(cam - 1) * 7 + 2 + k] : 0.0;
-  } else {
-    const int j = p - 1;  // perturbed parameter of this set (-1: none)
-    const double* xb = a.x ? a.x : a.x_inline;
-    for (int k = 0; k < 6; k++) {
-      const int idxp = (cam - 1) * 7 + 2 + k;
-      double v = cam ? xb[idxp] : 0.0;
-      if (cam && idxp == j) v = v + a.rel_step * (v >= 0.0 ? 1.0 : -1.0) * fmax(1.0, fabs(v));
-      q[k] = v;
+    if (cam == 0) {
+      for (int k = 0; k < 12; k++) rt[k] = 0.0;
+      rt[0] = rt[4] = rt[8] = 1.0;
+    } else {
+      rotvec_to_matrix(q, rt);
+      rt[9] = q[3];
+      rt[10] = q[4];
+      rt[11] = q[5];
     }
+  } else {
+    const int j = p - 1;
+    const double* xb = a.x ? a.x : a.x_inline;
+    ba_fd_camera_pose(xb, a.rel_step, p, cam, rt);
     if (cam == 0 && j >= 0) {  // dx_j = (x_j + h_j) - x_j, also for the dead focal entries
       const double v = xb[j];
       const double x1 = v + a.rel_step * (v >= 0.0 ? 1.0 : -1.0) * fmax(1.0, fabs(v));
       a.hvec[j] = x1 - v;
     }
   }
-  if (cam == 0) {
-    for (int k = 0; k < 12; k++) rt[k] = 0.0;
-    rt[0] = rt[4] = rt[8] = 1.0;
-  } else {
-    rotvec_to_matrix(q, rt);
-    rt[9] = q[3];
-    rt[10] = q[4];
-    rt[11] = q[5];
-  }
   double* RT = a.RT + (size_t)p * a.stride_RT + 12 * cam;
   for (int k = 0; k < 12; k++) RT[k] = rt[k];
   // P = K[j] @ [R | t] (helpers.py:306-307); j = compacted view index <= cam
   const int jn = a.uniformK ? 1 : cam + 1;
-  for (int j = 0; j < jn; j++) {
-    const double* K = a.K + 9 * j;
-    double* P = a.Pq + (size_t)p * a.stride_Pq + 12 * (a.uniformK ? (size_t)cam : (size_t)j * a.C + cam);
-    for (int r = 0; r < 3; r++)
-      for (int c = 0; c < 4; c++) {
-        const double r0 = c < 3 ? rt[c] : rt[9], r1 = c < 3 ? rt[3 + c] : rt[10],
-                     r2 = c < 3 ? rt[6 + c] : rt[11];
-        P[r * 4 + c] = K[r * 3 + 0] * r0 + K[r * 3 + 1] * r1 + K[r * 3 + 2] * r2;
-      }
-  }
+  for (int j = 0; j < jn; j++)
+    ba_projection(a.K + 9 * j, rt, a.Pq + (size_t)p * a.stride_Pq + 12 * (a.uniformK ? (size_t)cam : (size_t)j * a.C + cam));
 }
 
 hipError_t launch_ba_build_cameras(const BaCamArgs& a, hipStream_t stream) {
@@ -334,6 +352,302 @@ hipError_t launch_ba_gram_cost(const double* Jaug, int64_t m_pad, int NP, double
                      partial);
   hipLaunchKernelGGL(ba_gram_reduce_kernel, dim3((NP * NP + 255) / 256 + 1), dim3(256), 0, stream, partial, NP,
                      ksplit, G, r, valid, m, f32_residuals, use_cauchy, cost_out);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- one linearisation in ONE launch
+// An LM iteration is a chain of small dependent steps, so its cost is launch and round-trip latency, not
+// arithmetic.  This kernel does everything between "the host knows x" and "the host has
+// G = [J|f]^T [J|f] and the cost": camera tables of the forward-difference parameter sets, all residual
+// evaluations, float32 differencing + Cauchy scaling, the Gram matrix on the FP64 matrix cores, the
+// cross-workgroup reduction, and the hand-over to the host through pinned memory.
+//
+//   workgroup (chunk k, group q), 16 waves: wave w evaluates ONE parameter set on the chunk's 64 points.  The
+//     set's cameras are built by the workgroup itself into LDS (Rodrigues + K[R|t]) and read back as
+//     broadcasts; residuals go to r[p][point] in HBM.  Only LIVE sets are evaluated: the focal entries of the
+//     parameter vector have no effect on the residuals (helpers.py:267-270 writes them into a temporary), so
+//     their forward differences are exact zeros in the reference as well -- 1 + 6 (C-1) sets instead of
+//     2 + 7 (C-1).
+//   the LAST workgroup to finish a chunk (device-scope counter) owns the chunk's 64 rows of Jaug = [J | f | 0]:
+//     builds them in LDS, v_mfma_f64_16x16x4_f64 over the upper-triangle 16 x 16 tiles (tiles round-robin over
+//     its waves, 16 K-steps each: a 16 x 16 x 4 FP64 MFMA occupies its SIMD for 64 clocks, so the Gram matrix has
+//     to be spread over the chunks' workgroups -- one workgroup doing all of it would need 17 us), writes the
+//     chunk's partial tiles.
+//   the LAST chunk owner adds the partials in chunk order (fixed order -> bit-reproducible whichever
+//     workgroup happens to be last) and stores G, cost and the completion stamp into pinned host memory.
+// What the structure is shaped by (measured, gfx950): an agent-scope release (write-back of an XCD's L2) costs
+// 16 us when every wave of 208 workgroups issues one, 3.5 us with one per workgroup and 64 workgroups; a round of
+// dependent loads of lines another XCD just wrote is ~3 us; a spilled register reloaded inside a loop ~1 us --
+// so: few, fat workgroups, one fence each, as few dependent rounds as possible.  Counters return to zero inside
+// the launch (no memset between launches).
+constexpr int kFusedWaves = 16, kFusedThreads = 64 * kFusedWaves;  // one parameter set per wave
+
+// slot of a live parameter set (0 = base point, 1 + k = k-th live parameter) -> parameter set index p
+__device__ __forceinline__ int ba_live_set(int slot) {
+  if (slot == 0) return 0;
+  const int k = slot - 1;
+  return 1 + 7 * (k / 6) + 2 + k % 6;  // x = [f0, (f_i, rotvec 3, t 3) ...]: entries 0 and 1 + 7 i are the dead focals
+}
+__device__ __forceinline__ bool ba_live_param(int j, int n) { return j < n && j != 0 && (j - 1) % 7 != 0; }
+
+template <bool UNIFORM_K, bool F32R>
+__global__ __launch_bounds__(kFusedThreads) void ba_fused_kernel(BaFusedArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  __shared__ int sh_last;
+  __shared__ double sh_red[8];
+  __shared__ double xs[128];  // base point (dynamic per-thread indexing of the by-value argument would go through scratch)
+  const int chunk = blockIdx.x, grp = blockIdx.y;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int C = a.C, n = a.n, NP = a.NP;
+  const int64_t N = a.N;
+  const int nsets = 1 + 6 * (C - 1);  // live parameter sets
+  const size_t nPq = UNIFORM_K ? (size_t)12 * C : (size_t)12 * C * C;
+  const size_t set_stride = (size_t)12 * C + nPq;  // [RT C*12 | Pq]
+  double* tabs = lds;                               // [kFusedWaves][set_stride]
+  for (int k = tid; k < n; k += kFusedThreads) xs[k] = a.x[k];
+  __syncthreads();
+  if (a.debug_stop && chunk == 0 && grp == 0 && tid == 0) *(volatile double*)(a.out + (size_t)NP * NP + 2) = a.stamp;
+  if (a.debug_stop == 1) return;
+  // ---- phase 0: cameras of this group's parameter sets
+  for (int t = tid; t < kFusedWaves * C; t += kFusedThreads) {
+    const int w = t / C, cam = t - w * C, slot = kFusedWaves * grp + w;
+    if (slot >= nsets) continue;
+    double rt[12];
+    ba_fd_camera_pose(xs, a.rel_step, ba_live_set(slot), cam, rt);
+    double* T = tabs + (size_t)w * set_stride;
+    for (int k = 0; k < 12; k++) T[12 * cam + k] = rt[k];
+    const int jn = UNIFORM_K ? 1 : cam + 1;
+    for (int j = 0; j < jn; j++)
+      ba_projection(a.K + 9 * j, rt, T + 12 * C + 12 * (UNIFORM_K ? (size_t)cam : (size_t)j * C + cam));
+  }
+  __syncthreads();
+  if (a.debug_stop == 2) return;
+  // ---- phase 1: residual of (set p, point idx) = re-triangulation + mean squared reprojection error
+  const double qnan = __longlong_as_double(0x7ff8000000000000ll);
+  {
+    const int slot = kFusedWaves * grp + wave;
+    const int p = ba_live_set(slot);
+    const int64_t idx = (int64_t)chunk * 64 + lane;
+    if (slot < nsets && idx < N) {
+      LdsCamView cv;
+      cv.C = C;
+      cv.uniformK = UNIFORM_K;
+      cv.f32_rounding = F32R;
+      cv.RT = (ltab_t)(tabs + (size_t)wave * set_stride);
+      cv.Pq = (ltab_t)(tabs + (size_t)wave * set_stride + 12 * C);
+      cv.K4 = a.K4;
+      const double* o = a.obs + (size_t)idx * C * 2;
+      auto obs = [&](int c, double& x, double& y) -> bool {
+        x = o[2 * c];
+        y = o[2 * c + 1];
+        return !(isnan(x) || isnan(y));
+      };
+      double X[3], e = qnan;
+      const int v = triangulate_and_score<UNIFORM_K, false, F32R>(cv, obs, obs, X, e);
+      // NaN = fewer than two views (no residual entry, helpers.py:207-208); a seen point whose error is not
+      // a number is handed on as +inf so that the all-finite check of the trust-region loop still sees it
+      a.r[(size_t)p * N + idx] = v < 2 ? qnan : (isnan(e) ? __longlong_as_double(0x7ff0000000000000ll) : e);
+    }
+  }
+  if (a.debug_stop == 3) return;
+  // ---- who finishes the chunk?  Every wave waits for its own stores to reach L2 (workgroup-scope release), then
+  // ONE thread makes the workgroup's results visible to the other XCDs (agent-scope release = write-back of this
+  // XCD's L2: measured at 16 us when all 832 waves of the launch issue it, the single most expensive step).
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __syncthreads();
+  if (tid == 0) {
+    __threadfence();
+    sh_last = atomicAdd(&a.counters[chunk], 1) == a.groups - 1;
+    __threadfence();
+  }
+  __syncthreads();
+  if (!sh_last) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  if (tid == 0) a.counters[chunk] = 0;
+  if (a.debug_stop == 4) return;
+  // ---- phase 2: the chunk's rows of Jaug (LDS, aliases the camera tables), cost terms
+  const int LD = NP + 1;  // row stride of Jaug in LDS: lanes = rows store without a 64-way bank conflict
+  double* Jaug = lds;     // [64][LD]
+  {
+    const int row = lane, cg = wave;
+    const int64_t idx = (int64_t)chunk * 64 + row;
+    // all global loads first (the rows were written by other workgroups, possibly on another XCD: ~2 us each
+    // if they were issued one after the other)
+    constexpr int kMaxCols = 128 / kFusedWaves;  // NP <= 128
+    double fj[kMaxCols];
+    double r0 = __longlong_as_double(0x7ff8000000000000ll);
+    if (idx < N) {
+      r0 = a.r[idx];
+#pragma unroll
+      for (int q = 0; q < kMaxCols; q++) {
+        const int j = cg + kFusedWaves * q;
+        fj[q] = ba_live_param(j, n) ? a.r[(size_t)(1 + j) * N + idx] : 0.0;
+      }
+    }
+    const bool valid = !isnan(r0);
+    CauchyTerms ct = {0.0, 0.0, 0.0, 0.0};
+    if (valid) ct = cauchy_terms(r0, a.f32_residuals, a.use_cauchy);
+#pragma unroll
+    for (int q = 0; q < kMaxCols; q++) {
+      const int j = cg + kFusedWaves * q;
+      if (j >= NP) break;
+      double out = 0.0;
+      if (valid) {
+        if (ba_live_param(j, n)) {
+          const double df = a.f32_residuals ? (double)((float)fj[q] - (float)r0) : fj[q] - r0;
+          // dx_j = (x_j + h_j) - x_j (scipy _numdiff._dense_difference)
+          const double xv = xs[j];
+          const double dx = (xv + a.rel_step * (xv >= 0.0 ? 1.0 : -1.0) * fmax(1.0, fabs(xv))) - xv;
+          out = (df / dx) * ct.jscale;
+        } else if (j == n) {
+          out = ct.fs;
+        }
+      }
+      Jaug[row * LD + j] = out;
+      if (a.Jaug_out && idx < N) a.Jaug_out[(size_t)idx * NP + j] = out;
+    }
+    if (cg == 0) {  // cost of the chunk: sum of the loss values in row order (fixed tree), all-finite flag
+      double v = valid ? ct.rho0 : 0.0;
+      const unsigned long long badm = __ballot(valid && !isfinite(ct.f));
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+      if (lane == 0) {
+        a.cost_part[2 * chunk] = v;
+        a.cost_part[2 * chunk + 1] = badm ? 0.0 : 1.0;
+      }
+    }
+  }
+  __syncthreads();
+  if (a.debug_stop == 5) return;
+  // ---- phase 3: partial Gram of the 64 rows, upper-triangle tiles round-robin over the waves
+  const int nt = NP / 16, ntiles = nt * (nt + 1) / 2;
+  {
+    int u = 0;
+    for (int ti = 0; ti < nt; ti++)
+      for (int tj = ti; tj < nt; tj++, u++) {
+        if (u % kFusedWaves != wave) continue;
+        const double* pa = Jaug + (size_t)(lane >> 4) * LD + ti * 16 + (lane & 15);
+        const double* pb = Jaug + (size_t)(lane >> 4) * LD + tj * 16 + (lane & 15);
+        double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+        for (int s4 = 0; s4 < 16; s4++)
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[(size_t)s4 * 4 * LD], pb[(size_t)s4 * 4 * LD], acc, 0, 0, 0);
+        double* out = a.partial + ((size_t)chunk * ntiles + u) * 256;
+#pragma unroll
+        for (int r = 0; r < 4; r++) out[r * 64 + lane] = acc[r];
+      }
+  }
+  if (a.debug_stop == 6) return;
+  // ---- who finishes the batch?
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __syncthreads();
+  if (tid == 0) {
+    __threadfence();
+    sh_last = atomicAdd(&a.counters[a.chunks], 1) == a.chunks - 1;
+    __threadfence();
+  }
+  __syncthreads();
+  if (!sh_last) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  if (tid == 0) a.counters[a.chunks] = 0;
+  if (a.debug_stop == 7) return;
+  // ---- phase 4: G = sum of the chunks' partials in chunk order -> pinned host memory (upper triangle of
+  // the leading (n+1) x (n+1) block; the host mirrors it)
+  {
+    const int reg = (tid >> 6) & 3, slot = tid >> 8;  // 256 threads per tile, kFusedThreads / 256 tiles at a time
+    constexpr int kSlots = kFusedThreads / 256;
+    const size_t cs = (size_t)ntiles * 256;
+    const double* __restrict__ part = a.partial;
+    double* __restrict__ gout = a.out;
+    for (int u0 = slot; u0 < ntiles; u0 += 2 * kSlots) {  // two tiles x sixteen chunks = 32 loads in flight per thread
+      double sum[2] = {0.0, 0.0};
+      for (int k0 = 0; k0 < a.chunks; k0 += 16) {
+        double v[2][16];
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+          for (int q = 0; q < 16; q++)
+            v[t][q] = (u0 + t * kSlots < ntiles && k0 + q < a.chunks)
+                          ? part[(size_t)(k0 + q) * cs + (size_t)(u0 + t * kSlots) * 256 + reg * 64 + lane] : 0.0;
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+          for (int q = 0; q < 16; q++)
+            if (k0 + q < a.chunks) sum[t] += v[t][q];  // chunk order
+      }
+      if (a.debug_stop == 8) {
+        if (sum[0] + sum[1] == 1.2345e-300) gout[0] = 0.0;
+        continue;
+      }
+#pragma unroll
+      for (int t = 0; t < 2; t++) {
+        const int u = u0 + t * kSlots;
+        if (u >= ntiles) break;
+        // tile index -> (ti, tj) of the upper triangle, row-major
+        int ti = 0, rem = u;
+        while (rem >= nt - ti) {
+          rem -= nt - ti;
+          ti++;
+        }
+        const int tj = ti + rem;
+        const int row = ti * 16 + (lane >> 4) + 4 * reg, col = tj * 16 + (lane & 15);
+        if (row <= col && col <= n) gout[(size_t)row * NP + col] = sum[t];
+      }
+    }
+    // cost: chunk sums added by 64 lanes with stride 64, then a fixed tree
+    if (wave == 0) {
+      double c = 0.0, fin = 1.0;
+      for (int k = lane; k < a.chunks; k += 64) {
+        c += a.cost_part[2 * k];
+        fin = fmin(fin, a.cost_part[2 * k + 1]);
+      }
+      for (int o = 32; o > 0; o >>= 1) {
+        c += __shfl_down(c, o);
+        fin = fmin(fin, __shfl_down(fin, o));
+      }
+      if (lane == 0) {
+        sh_red[0] = 0.5 * c;
+        sh_red[1] = fin;
+      }
+    }
+  }
+  if (a.debug_stop == 9) return;
+  // every wave waits for its own stores (workgroup-scope release), one thread publishes to the host
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __syncthreads();
+  if (tid == 0) {
+    double* tail = a.out + (size_t)NP * NP;
+    tail[0] = sh_red[0];
+    tail[1] = sh_red[1];
+    __threadfence_system();
+    *(volatile double*)(tail + 2) = a.stamp;  // the host spins on this word
+  }
+}
+
+size_t ba_fused_lds_bytes(int C, int NP, bool uniformK) {
+  const size_t set_stride = (size_t)12 * C + (uniformK ? (size_t)12 * C : (size_t)12 * C * C);
+  const size_t tabs = kFusedWaves * set_stride * sizeof(double), jaug = (size_t)64 * (NP + 1) * sizeof(double);
+  return tabs > jaug ? tabs : jaug;
+}
+
+int ba_fused_groups(int C) { return (1 + 6 * (C - 1) + kFusedWaves - 1) / kFusedWaves; }
+int ba_fused_owners(int chunks) { return chunks; }
+
+bool ba_fused_eligible(int C, int n, int NP, bool uniformK) {
+  return n <= 127 && ba_fused_lds_bytes(C, NP, uniformK) <= 150 * 1024;
+}
+
+hipError_t launch_ba_fused(const BaFusedArgs& a, hipStream_t stream) {
+  void (*k)(BaFusedArgs);
+  if (a.f32_rounding)
+    k = a.uniformK ? ba_fused_kernel<true, true> : ba_fused_kernel<false, true>;
+  else
+    k = a.uniformK ? ba_fused_kernel<true, false> : ba_fused_kernel<false, false>;
+  const size_t lds = ba_fused_lds_bytes(a.C, a.NP, a.uniformK);
+  if (lds > 64 * 1024) {  // above the default dynamic-LDS limit (non-identical intrinsics: tables per compacted index)
+    const hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(k, dim3((unsigned)a.chunks, (unsigned)a.groups), dim3(kFusedThreads), lds, stream, a);
   return hipGetLastError();
 }
 

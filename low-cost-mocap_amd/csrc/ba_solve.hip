@@ -260,9 +260,14 @@ struct BaWork {
   int32_t* d_valid = nullptr;
   std::vector<int32_t> valid;
   double *h_x = nullptr, *h_G = nullptr;  // pinned: parameter upload, [G | cost, finite] download
+  // one-launch linearisation (ba_fused_kernel)
+  bool fused = false;
+  int chunks = 0, groups = 0;
+  double *d_fpartial = nullptr, *d_fcost = nullptr, *d_fJaug = nullptr, *h_fout = nullptr;
+  int32_t* d_fcounters = nullptr;
 };
 
-int ba_setup(mocap_ctx* ctx, BaWork& w, int64_t N, const double* obs, int Pmax) {
+int ba_setup(mocap_ctx* ctx, BaWork& w, int64_t N, const double* obs, int Pmax, bool want_jaug = false) {
   if (!ctx->C) return ctx->fail(MOCAP_E_NOCAMS, "mocap_set_cameras has not been called");
   if (N < 1 || !obs) return ctx->fail(MOCAP_E_ARG, "bundle adjustment: bad argument");
   const int C = ctx->C;
@@ -311,17 +316,45 @@ int ba_setup(mocap_ctx* ctx, BaWork& w, int64_t N, const double* obs, int Pmax) 
   w.d_cost = p;     p += nd_cost;
   w.d_rho = p;
   w.d_valid = (int32_t*)ctx->scratch[2].ptr;
-  const size_t pin_bytes = sizeof(double) * (nd_x + nd_G + nd_cost);
+  // one launch per linearisation when the rig fits the fused kernel's LDS budget (MOCAP_BA_UNFUSED=1: the chain
+  // of five launches it replaces, kept as the fallback for large rigs and for A/B measurements)
+  // Up to 2 048 points: beyond that the chain's kernels fill the GPU and the fused kernel's last workgroup (which
+  // adds one partial per 64 rows) becomes the longer path (measured at 16 000 points: 225 vs 150 us per iteration;
+  // at 1 000 points 62.9 vs 65.0).
+  w.fused = ba_fused_eligible(C, w.n, w.NP, w.uniformK != 0) && !getenv("MOCAP_BA_UNFUSED") &&
+            (N <= 2048 || getenv("MOCAP_BA_FUSED"));
+  size_t nd_fout = 0;
+  if (w.fused) {
+    w.chunks = (int)((N + 63) / 64);
+    w.groups = ba_fused_groups(C);
+    const int nt = w.NP / 16, ntiles = nt * (nt + 1) / 2;
+    const int owners = ba_fused_owners(w.chunks);
+    const size_t nd_fp = al((size_t)owners * ntiles * 256), nd_fc = al((size_t)owners * 2),
+                 nd_cnt = al((size_t)(owners + 1) / 2 + 1), nd_fJ = want_jaug ? al((size_t)N * w.NP) : 0;
+    if (ctx->ba_fused.reserve((nd_fp + nd_fc + nd_cnt + nd_fJ) * sizeof(double)))
+      return ctx->fail(MOCAP_E_HIP, "hipMalloc(BA fused workspace) failed");
+    double* q = (double*)ctx->ba_fused.ptr;
+    w.d_fpartial = q;  q += nd_fp;
+    w.d_fcost = q;     q += nd_fc;
+    w.d_fcounters = (int32_t*)q;  q += nd_cnt;
+    w.d_fJaug = want_jaug ? q : nullptr;
+    HIP_TRY(ctx, hipMemsetAsync(w.d_fcounters, 0, nd_cnt * sizeof(double), ctx->stream));  // the kernel leaves them at zero
+    nd_fout = al((size_t)w.NP * w.NP + 3);
+  }
+  const size_t pin_bytes = sizeof(double) * (nd_x + nd_G + nd_cost + nd_fout);
   if (pin_bytes > ctx->ba_pin_cap) {
     if (ctx->ba_pin) (void)hipHostFree(ctx->ba_pin);
     ctx->ba_pin = nullptr;
     ctx->ba_pin_cap = 0;
-    HIP_TRY(ctx, hipHostMalloc(&ctx->ba_pin, pin_bytes, hipHostMallocDefault));
+    // coherent (fine-grained): the fused kernel's completion stamp is polled by the host while the kernel runs
+    HIP_TRY(ctx, hipHostMalloc(&ctx->ba_pin, pin_bytes, hipHostMallocCoherent));
     ctx->ba_pin_cap = pin_bytes;
   }
   if (!ctx->ba_event) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ba_event, hipEventDisableTiming));
   w.h_x = (double*)ctx->ba_pin;
   w.h_G = w.h_x + nd_x;
+  w.h_fout = w.fused ? w.h_G + nd_G + nd_cost : nullptr;
+  if (w.h_fout) w.h_fout[(size_t)w.NP * w.NP + 2] = -1.0;
   HIP_TRY(ctx, hipMemcpyAsync(w.d_obs, obs, sizeof(double) * (size_t)N * C * 2, hipMemcpyHostToDevice, ctx->stream));
   if (w.m)
     HIP_TRY(ctx, hipMemcpyAsync(w.d_valid, w.valid.data(), sizeof(int32_t) * (size_t)w.m, hipMemcpyHostToDevice, ctx->stream));
@@ -397,8 +430,68 @@ int ba_cost_at(mocap_ctx* ctx, BaWork& w, const double* x, int f32, int cauchy, 
 }
 
 // linearise at x: G = [J|f]^T [J|f] (host copy, NP x NP), cost
+int ba_linearize_fused(mocap_ctx* ctx, BaWork& w, const double* x, int f32, int cauchy, double rel_step,
+                       std::vector<double>& G, double& cost, bool* finite) {
+  BaFusedArgs a;
+  a.C = w.C;
+  a.n = w.n;
+  a.NP = w.NP;
+  a.uniformK = w.uniformK;
+  a.f32_rounding = ctx->cv.f32_rounding;
+  a.f32_residuals = f32;
+  a.use_cauchy = cauchy;
+  a.chunks = w.chunks;
+  a.groups = w.groups;
+  static const int dbg = getenv("MOCAP_BA_DEBUG_STOP") ? atoi(getenv("MOCAP_BA_DEBUG_STOP")) : 0;
+  a.debug_stop = dbg;
+  a.N = w.N;
+  a.rel_step = rel_step;
+  ctx->ba_stamp += 1.0;
+  a.stamp = ctx->ba_stamp;
+  memcpy(a.x, x, sizeof(double) * w.n);
+  a.K = ctx->d_K9;
+  a.K4 = ctx->cv.K4;
+  a.obs = w.d_obs;
+  a.r = w.d_r;
+  a.partial = w.d_fpartial;
+  a.cost_part = w.d_fcost;
+  a.counters = w.d_fcounters;
+  a.Jaug_out = w.d_fJaug;
+  a.out = w.h_fout;
+  HIP_TRY(ctx, launch_ba_fused(a, ctx->stream));
+  // the kernel's last workgroup stores G, the cost and then the stamp into this pinned buffer: spin on the stamp
+  // (a few microseconds; an event query costs a driver call per poll)
+  const size_t nG = (size_t)w.NP * w.NP;
+  volatile double* stamp = w.h_fout + nG + 2;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (long spins = 0; *stamp != a.stamp; spins++) {
+    if ((spins & 0xffff) == 0xffff) {
+      const hipError_t e = hipStreamQuery(ctx->stream);  // a failed launch never writes the stamp
+      if (e != hipSuccess && e != hipErrorNotReady) return ctx->hip_fail(e, "ba_fused_kernel");
+      if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 20.0)
+        return ctx->fail(MOCAP_E_HIP, "ba_fused_kernel: no completion stamp after 20 s");
+    }
+  }
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  const int n = w.n, NP = w.NP;
+  G.assign(nG, 0.0);
+  for (int i = 0; i <= n; i++)
+    for (int j = i; j <= n; j++) {
+      const double v = w.h_fout[(size_t)i * NP + j];
+      G[(size_t)i * NP + j] = v;
+      G[(size_t)j * NP + i] = v;
+    }
+  cost = w.h_fout[nG];
+  if (finite) *finite = w.h_fout[nG + 1] != 0.0;
+  return MOCAP_OK;
+}
+
 int ba_linearize(mocap_ctx* ctx, BaWork& w, const double* x, int f32, int cauchy, std::vector<double>& G,
                  double& cost, bool* finite = nullptr) {
+  if (w.fused) {
+    const double rs = f32 ? (double)std::sqrt(1.1920928955078125e-07f) : std::sqrt(kEps);
+    return ba_linearize_fused(ctx, w, x, f32, cauchy, rs, G, cost, finite);
+  }
   memcpy(w.h_x, x, sizeof(double) * w.n);  // pinned, read by the kernel directly (zero-copy)
   // scipy _numdiff: rel_step = sqrt(eps of the residual dtype) for the 2-point scheme
   // (_eps_for_method returns np.finfo(np.float32).eps ** 0.5, a np.float32 scalar under NumPy 2 promotion:
@@ -459,7 +552,7 @@ extern "C" int mocap_ba_normal_eq(mocap_ctx* ctx, const double* x, int64_t N, co
   if (!x || !JtJ || !Jtr) return ctx->fail(MOCAP_E_ARG, "mocap_ba_normal_eq: bad argument");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   BaWork w;
-  int rc = ba_setup(ctx, w, N, obs, 1 + 7 * (ctx->C - 1) + 1);
+  int rc = ba_setup(ctx, w, N, obs, 1 + 7 * (ctx->C - 1) + 1, J_out != nullptr);
   if (rc) return rc;
   std::vector<double> G;
   double c = 0;
@@ -472,7 +565,12 @@ extern "C" int mocap_ba_normal_eq(mocap_ctx* ctx, const double* x, int64_t N, co
   }
   if (cost) *cost = c;
   if (m_out) *m_out = w.m;
-  if (J_out && w.m) {
+  if (J_out && w.m && w.fused) {  // rows by point index -> the valid rows in order
+    std::vector<double> Jaug((size_t)N * NP);
+    HIP_TRY(ctx, hipMemcpy(Jaug.data(), w.d_fJaug, sizeof(double) * Jaug.size(), hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < w.m; i++)
+      for (int j = 0; j < n; j++) J_out[(size_t)i * n + j] = Jaug[(size_t)w.valid[i] * NP + j];
+  } else if (J_out && w.m) {
     std::vector<double> Jaug((size_t)w.m_pad * NP);
     HIP_TRY(ctx, hipMemcpy(Jaug.data(), w.d_Jaug, sizeof(double) * Jaug.size(), hipMemcpyDeviceToHost));
     for (int64_t i = 0; i < w.m; i++)

@@ -93,6 +93,7 @@ extern "C" void mocap_destroy(mocap_ctx* ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   ctx->tables.release();
   for (auto& b : ctx->scratch) b.release();
+  ctx->ba_fused.release();
   ctx->frame_ws.release();
   if (ctx->live_pin) (void)hipHostFree(ctx->live_pin);
   if (ctx->live_event) (void)hipEventDestroy(ctx->live_event);

@@ -37,6 +37,8 @@ struct mocap_ctx {
   void* ba_pin = nullptr;
   size_t ba_pin_cap = 0;
   hipEvent_t ba_event = nullptr;
+  DevBuf ba_fused;          // one-launch linearisation: chunk partial tiles | chunk costs | counters | (Jaug dump)
+  double ba_stamp = 0.0;    // completion stamp of the last fused launch (monotonic per context)
   void* live_pin = nullptr;  // zero-copy staging of the live (few frames per call) host entry point
   size_t live_pin_cap = 0;
   hipEvent_t live_event = nullptr;

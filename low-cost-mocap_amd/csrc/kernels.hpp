@@ -170,6 +170,32 @@ hipError_t launch_ba_gram_cost(const double* Jaug, int64_t m_pad, int NP, double
                                double* cost_out, hipStream_t stream);
 int ba_gram_ksplit(int64_t m_pad, int NP);
 
+// one linearisation in one launch (see ba_fused_kernel)
+struct BaFusedArgs {
+  int C, n, NP, uniformK, f32_rounding, f32_residuals, use_cauchy;
+  int chunks;            // ceil(N / 64)
+  int groups;            // ba_fused_groups(n) workgroups per chunk
+  int debug_stop;        // 0; timing experiments: leave the kernel after phase (debug_stop - 1), results invalid
+  int64_t N;
+  double rel_step;
+  double stamp;          // written to out[NP*NP + 2] when G and the cost are in place
+  double x[128];         // base point by value (n <= 127): kernel arguments, no PCIe read
+  const double* K;       // [C][9]
+  const double* K4;      // [j][4]
+  const double* obs;     // [N][C][2]
+  double* r;             // [n+1][N] residuals
+  double* partial;       // [chunks][tiles][256] upper-triangle Gram tiles per chunk
+  double* cost_part;     // [chunks][2] (sum of loss values, all-finite flag)
+  int32_t* counters;     // [chunks + 1], zero on entry and on exit
+  double* Jaug_out;      // null, or [N][NP]: the rows of Jaug by point index (tests)
+  double* out;           // pinned host memory [NP*NP + 3]: upper triangle of G | cost | finite | stamp
+};
+size_t ba_fused_lds_bytes(int C, int NP, bool uniformK);
+bool ba_fused_eligible(int C, int n, int NP, bool uniformK);
+int ba_fused_groups(int C);    // workgroups per chunk: ceil(live parameter sets / sets per workgroup)
+int ba_fused_owners(int chunks);  // workgroups that write Gram partials (one per chunk)
+hipError_t launch_ba_fused(const BaFusedArgs& a, hipStream_t stream);
+
 // cost-only evaluation: sum of rho over valid points of residual row r [N]
 hipError_t launch_ba_cost(const double* r, const int32_t* valid, int64_t m, int f32_residuals,
                           int use_cauchy, double* out /*[2]: cost, finite flag*/, hipStream_t stream);

@@ -41,6 +41,27 @@ struct CamView {
   const double* RT;  // [cam][12]: R row-major (9), t (3)
   const double* K4;  // [j][4]: fx, fy, cx, cy
   const double* F;   // [a][b][9]: fundamentalFromProjections(P_a, P_b) (helpers.py:362)
+  // table accessors used by the geometry core below (offsets in doubles); wave-uniform -> scalar loads
+  __device__ __forceinline__ ctab_t pq(size_t off) const { return as_ctab(Pq + off); }
+  __device__ __forceinline__ ctab_t rt(size_t off) const { return as_ctab(RT + off); }
+  __device__ __forceinline__ ctab_t k4(size_t off) const { return as_ctab(K4 + off); }
+};
+
+// The same view with the pose-dependent tables (Pq, RT) in LDS: bundle adjustment builds the cameras of a
+// parameter vector inside the kernel that consumes them (csrc/ba_kernels.hip), where the scalar cache cannot be
+// used (it is not coherent with stores of the same kernel).  Wave-uniform LDS addresses are broadcast reads.
+typedef const double __attribute__((address_space(3))) * ltab_t;
+struct LdsCamView {
+  int C;
+  int uniformK;
+  int f32_rounding;
+  int _pad;
+  ltab_t Pq;         // layouts as CamView
+  ltab_t RT;
+  const double* K4;  // intrinsics do not depend on the parameter vector (dead focal entries, helpers.py:267-270)
+  __device__ __forceinline__ ltab_t pq(size_t off) const { return Pq + off; }
+  __device__ __forceinline__ ltab_t rt(size_t off) const { return RT + off; }
+  __device__ __forceinline__ ctab_t k4(size_t off) const { return as_ctab(K4 + off); }
 };
 
 // ---- packed symmetric 4x4: (0,0)=0 (0,1)=1 (0,2)=2 (0,3)=3 (1,1)=4 (1,2)=5 (1,3)=6 (2,2)=7 (2,3)=8 (3,3)=9
@@ -247,7 +268,8 @@ __device__ __forceinline__ void smallest_eigvec4(double (&a)[10], double (&out)[
 // order (helpers.py:318 hands A^T A to LAPACK: its internal order is not pinned).  Keeping the contribution
 // a function of (camera, observation) alone lets the frame kernel tabulate it once per blob instead of once
 // per candidate group -- and every path (table or not, frame or explicit triangulation) rounds identically.
-__device__ __forceinline__ void dlt_contribution(double (&Bc)[10], ctab_t P, double x, double y) {
+template <class Tab>
+__device__ __forceinline__ void dlt_contribution(double (&Bc)[10], Tab P, double x, double y) {
   double ra[4], rb[4];
 #pragma unroll
   for (int k = 0; k < 4; k++) {
@@ -260,7 +282,8 @@ __device__ __forceinline__ void dlt_contribution(double (&Bc)[10], ctab_t P, dou
     for (int j = i; j < 4; j++) Bc[sidx(i, j)] = fma(ra[i], ra[j], rb[i] * rb[j]);
 }
 
-__device__ __forceinline__ void dlt_accumulate(double (&B)[10], ctab_t P, double x, double y) {
+template <class Tab>
+__device__ __forceinline__ void dlt_accumulate(double (&B)[10], Tab P, double x, double y) {
   double Bc[10];
   dlt_contribution(Bc, P, x, y);
 #pragma unroll
@@ -269,8 +292,8 @@ __device__ __forceinline__ void dlt_accumulate(double (&B)[10], ctab_t P, double
 
 // cv.projectPoints restated (helpers.py:231-237; OpenCV cvProjectPoints2, 3x3 R, no distortion):
 // squared pixel residuals of one view.  X already rounded to float32 when F32R.
-template <bool F32R>
-__device__ __forceinline__ void reproject_sq(ctab_t RT, ctab_t K4, const double (&X)[3], double ox,
+template <bool F32R, class Tab>
+__device__ __forceinline__ void reproject_sq(Tab RT, ctab_t K4, const double (&X)[3], double ox,
                                              double oy, double& du2, double& dv2) {
   double x = RT[0] * X[0] + RT[1] * X[1] + RT[2] * X[2] + RT[9];
   double y = RT[3] * X[0] + RT[4] * X[1] + RT[5] * X[2] + RT[10];
@@ -297,8 +320,8 @@ __device__ __forceinline__ void reproject_sq(ctab_t RT, ctab_t K4, const double 
 //   F32R: reproduce OpenCV's float32 roundings (MOCAP_OPT_F32_ROUNDING).
 // Returns the number of views; X / err are valid when it is >= 2.
 // Second half of triangulate_and_score: null vector of B (v views accumulated), point, reprojection error.
-template <bool UNIFORM_K, bool PAIRWISE, bool F32R, class Obs2>
-__device__ __forceinline__ void solve_and_score(const CamView& cv, double (&B)[10], int v, Obs2&& obs2,
+template <bool UNIFORM_K, bool PAIRWISE, bool F32R, class View, class Obs2>
+__device__ __forceinline__ void solve_and_score(const View& cv, double (&B)[10], int v, Obs2&& obs2,
                                                 double (&X)[3], double& err) {
   const int C = cv.C;
   double vec[4];
@@ -327,7 +350,7 @@ __device__ __forceinline__ void solve_and_score(const CamView& cv, double (&B)[1
       double x, y;
       if (obs2(c0 + u, x, y)) {
         double du2, dv2;
-        reproject_sq<F32R>(as_ctab(cv.RT + 12 * (c0 + u)), as_ctab(cv.K4 + 4 * (UNIFORM_K ? 0 : j)), Xp, x, y, du2, dv2);
+        reproject_sq<F32R>(cv.rt(12 * (c0 + u)), cv.k4(4 * (UNIFORM_K ? 0 : j)), Xp, x, y, du2, dv2);
         seq = seq + du2;
         seq = seq + dv2;
         if (PAIRWISE) {
@@ -343,7 +366,7 @@ __device__ __forceinline__ void solve_and_score(const CamView& cv, double (&B)[1
     double x, y;
     if (obs2(c, x, y)) {
       double du2, dv2;
-      reproject_sq<F32R>(as_ctab(cv.RT + 12 * c), as_ctab(cv.K4 + 4 * (UNIFORM_K ? 0 : j)), Xp, x, y, du2, dv2);
+      reproject_sq<F32R>(cv.rt(12 * c), cv.k4(4 * (UNIFORM_K ? 0 : j)), Xp, x, y, du2, dv2);
       seq = seq + du2;
       seq = seq + dv2;
       if (PAIRWISE) {
@@ -356,8 +379,8 @@ __device__ __forceinline__ void solve_and_score(const CamView& cv, double (&B)[1
   err = (pw ? spw : seq) / (double)(2 * v);
 }
 
-template <bool UNIFORM_K, bool PAIRWISE, bool F32R, class Obs1, class Obs2>
-__device__ __forceinline__ int triangulate_and_score(const CamView& cv, Obs1&& obs1, Obs2&& obs2,
+template <bool UNIFORM_K, bool PAIRWISE, bool F32R, class View, class Obs1, class Obs2>
+__device__ __forceinline__ int triangulate_and_score(const View& cv, Obs1&& obs1, Obs2&& obs2,
                                                      double (&X)[3], double& err) {
   const int C = cv.C;
   double B[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -365,8 +388,7 @@ __device__ __forceinline__ int triangulate_and_score(const CamView& cv, Obs1&& o
   for (int c = 0; c < C; c++) {
     double x, y;
     if (obs1(c, x, y)) {
-      ctab_t P = as_ctab(UNIFORM_K ? cv.Pq + 12 * c : cv.Pq + 12 * ((size_t)v * C + c));
-      dlt_accumulate(B, P, x, y);
+      dlt_accumulate(B, cv.pq(UNIFORM_K ? (size_t)12 * c : 12 * ((size_t)v * C + c)), x, y);
       v++;
     }
   }
