@@ -25,6 +25,7 @@
 
 #include "../../include/mocap_core.h"
 #include "ctx.hpp"
+#include "tr_host.hpp"
 
 using namespace mocap;
 
@@ -579,99 +580,6 @@ extern "C" int mocap_ba_normal_eq(mocap_ctx* ctx, const double* x, int64_t N, co
   return MOCAP_OK;
 }
 
-// The same trust-region subproblem without an eigen-decomposition, for the case the reference always is in:
-// J has exactly-zero columns (the dead focal parameters, helpers.py:267-270), so `full_rank` of
-// solve_lsq_trust_region is False, no Gauss-Newton step is tried and alpha_lower = 0; all the secular
-// iteration needs is  |p(a)|  and  d|p|/da  for  p(a) = -(B + a I)^{-1} g  on the live block B = J^T J:
-//     phi(a) = |p| - Delta ,   phi'(a) = -(p^T (B + a I)^{-1} p) / |p|
-// (identical to scipy's sums over singular values: suf_k^2 / (s_k^2 + a)^3 etc.).  One Cholesky and two
-// solves per alpha (~15 k flops at 42 live parameters) instead of a 4 n^3 eigen-solve per linearisation.
-struct CholTR {
-  int na = 0;
-  std::vector<double> L, q, wv;
-  // L L^T = B + a I (row-major lower).  false = a pivot fell below 1e-10 of its diagonal entry: the block is
-  // numerically singular at this shift (e.g. the scale gauge of the rig near convergence) and the caller
-  // falls back to the eigen-decomposition, which handles vanishing singular values like scipy's SVD
-  bool factor(const std::vector<double>& B, double a) {
-    L = B;
-    for (int j = 0; j < na; j++) {
-      const double d0 = L[(size_t)j * na + j] + a;
-      double d = d0;
-      for (int k = 0; k < j; k++) d -= L[(size_t)j * na + k] * L[(size_t)j * na + k];
-      if (!(d > 1e-10 * d0)) return false;
-      d = std::sqrt(d);
-      L[(size_t)j * na + j] = d;
-      const double id = 1.0 / d;
-      for (int i = j + 1; i < na; i++) {
-        double v = L[(size_t)i * na + j];
-        const double* li = &L[(size_t)i * na];
-        const double* lj = &L[(size_t)j * na];
-        for (int k = 0; k < j; k++) v -= li[k] * lj[k];
-        L[(size_t)i * na + j] = v * id;
-      }
-    }
-    return true;
-  }
-  void solve(std::vector<double>& b) const {  // (L L^T) x = b in place
-    for (int i = 0; i < na; i++) {
-      double v = b[i];
-      for (int k = 0; k < i; k++) v -= L[(size_t)i * na + k] * b[k];
-      b[i] = v / L[(size_t)i * na + i];
-    }
-    for (int i = na - 1; i >= 0; i--) {
-      double v = b[i];
-      for (int k = i + 1; k < na; k++) v -= L[(size_t)k * na + i] * b[k];
-      b[i] = v / L[(size_t)i * na + i];
-    }
-  }
-};
-
-// solve_lsq_trust_region for a rank-deficient J (see CholTR); B, gl = live block of J^T J and of J^T f
-bool solve_tr_chol(CholTR& ch, const std::vector<double>& B, const std::vector<double>& gl, double Delta,
-                   double& alpha_io, std::vector<double>& pl) {
-  const int na = ch.na;
-  double alpha = alpha_io;
-  bool ok = true;
-  auto phi_and_derivative = [&](double a, double& phi, double& phi_prime) {
-    if (!ch.factor(B, a)) {
-      ok = false;
-      phi = phi_prime = 0;
-      return;
-    }
-    ch.q = gl;
-    ch.solve(ch.q);  // q = (B + a I)^{-1} g = -p
-    const double p_norm = norm2(ch.q);
-    ch.wv = ch.q;
-    ch.solve(ch.wv);
-    double pw = 0;
-    for (int i = 0; i < na; i++) pw += ch.q[i] * ch.wv[i];
-    phi = p_norm - Delta;
-    phi_prime = -pw / p_norm;
-  };
-  double alpha_upper = norm2(gl) / Delta;  // |suf| = |V^T g| = |g|
-  double alpha_lower = 0.0;
-  if (alpha == 0.0) alpha = std::max(0.001 * alpha_upper, std::sqrt(alpha_lower * alpha_upper));
-  for (int it = 0; it < 10; it++) {
-    if (alpha < alpha_lower || alpha > alpha_upper)
-      alpha = std::max(0.001 * alpha_upper, std::sqrt(alpha_lower * alpha_upper));
-    double phi, phi_prime;
-    phi_and_derivative(alpha, phi, phi_prime);
-    if (!ok) return false;
-    if (phi < 0) alpha_upper = alpha;
-    const double ratio = phi / phi_prime;
-    alpha_lower = std::max(alpha_lower, alpha - ratio);
-    alpha -= (phi + Delta) * ratio / Delta;
-    if (std::fabs(phi) < 0.01 * Delta) break;
-  }
-  pl = gl;
-  if (!ch.factor(B, alpha)) return false;
-  ch.solve(pl);
-  double pn = norm2(pl);
-  for (double& v : pl) v = pn > 0 ? -v * (Delta / pn) : -v;
-  alpha_io = alpha;
-  return true;
-}
-
 // The subproblem solver as mocap_ba_solve drives it: dead parameters deflated exactly, then the Cholesky
 // secular iteration when J has zero columns (scipy's rank-deficient branch) and the eigen path otherwise or when
 // a pivot collapses.  Shared by the LM loop's test entry point below.
@@ -679,8 +587,8 @@ struct TrSubproblem {
   int n = 0;
   int64_t m = 0;
   std::vector<int> alive, order;
-  std::vector<double> A, Va, lama, V, lam, s, suf, Vs, Blive, glive, plive;
-  CholTR chol;
+  std::vector<double> A, Va, lama, V, lam, s, suf, Vs, plive;
+  CholSecular chol;  // csrc/tr_host.cpp
   bool use_chol = false, eig_ready = false;
   const double* JtJ = nullptr;
   const double* g = nullptr;
@@ -703,10 +611,8 @@ struct TrSubproblem {
     use_chol = method != 1 && na > 0 && (na < n || method == 2);
     eig_ready = false;
     if (use_chol) {
-      chol.na = na;
-      Blive = A;
-      glive.resize(na);
-      for (int a = 0; a < na; a++) glive[a] = g[alive[a]];
+      chol.set(JtJ, g, n, alive.data(), na);
+      plive.resize(na);
     }
   }
   void ensure_eigen() {
@@ -744,7 +650,7 @@ struct TrSubproblem {
   }
   // returns the method that produced the step (1 eigen, 2 Cholesky)
   int solve(double Delta, double& alpha, std::vector<double>& step, bool chol_only = false) {
-    if (use_chol && !solve_tr_chol(chol, Blive, glive, Delta, alpha, plive)) {
+    if (use_chol && !chol.solve(Delta, alpha, plive.data())) {
       if (chol_only) return 0;
       use_chol = false;  // ill-conditioned live block
     }
