@@ -261,6 +261,15 @@ int mocap_ba_normal_eq(mocap_ctx* ctx, const double* x, int64_t N, const double*
 int mocap_ba_trust_region_step(mocap_ctx* ctx, int n, int64_t m, const double* JtJ, const double* Jtr,
                                double Delta, double* alpha_io, int method, double* step, int32_t* info);
 
+/* mocap_ba_profile: measurement aid (bench.py's `ba.roofline`).  `reps` linearisations at x exactly as the LM loop
+ * issues them, timed with HIP events on the context's stream, then `reps` trust-region subproblems on the
+ * resulting normal equations.  out [8] = {GPU microseconds per linearisation (event to event: every launch of
+ * one linearisation), wall-clock microseconds per linearisation (launch + wait for the result on the host),
+ * host microseconds per trust-region subproblem, kernel launches per linearisation, valid points m, padded
+ * row length NP of [J | f], 1 if the one-launch kernel ran, cost at x}. */
+int mocap_ba_profile(mocap_ctx* ctx, const double* x, int64_t N, const double* obs, int f32_residuals,
+                     int use_cauchy, int reps, double* out);
+
 /* mocap_ba_solve: resident Levenberg-Marquardt / trust-region loop (the algorithm of
  * scipy.optimize.least_squares(method="trf", loss="cauchy"), helpers.py:287-289, restated
  * on the normal equations).  x [n] in/out.

@@ -362,7 +362,7 @@ hipError_t launch_ba_gram_cost(const double* Jaug, int64_t m_pad, int NP, double
 // evaluations, float32 differencing + Cauchy scaling, the Gram matrix on the FP64 matrix cores, the
 // cross-workgroup reduction, and the hand-over to the host through pinned memory.
 //
-//   workgroup (chunk k, group q), 16 waves: wave w evaluates ONE parameter set on the chunk's 64 points.  The
+//   workgroup (chunk k, group q), kFusedWaves waves: wave w evaluates ONE parameter set on the chunk's 64 points.  The
 //     set's cameras are built by the workgroup itself into LDS (Rodrigues + K[R|t]) and read back as
 //     broadcasts; residuals go to r[p][point] in HBM.  Only LIVE sets are evaluated: the focal entries of the
 //     parameter vector have no effect on the residuals (helpers.py:267-270 writes them into a temporary), so
@@ -380,7 +380,19 @@ hipError_t launch_ba_gram_cost(const double* Jaug, int64_t m_pad, int NP, double
 // dependent loads of lines another XCD just wrote is ~3 us; a spilled register reloaded inside a loop ~1 us --
 // so: few, fat workgroups, one fence each, as few dependent rounds as possible.  Counters return to zero inside
 // the launch (no memset between launches).
-constexpr int kFusedWaves = 16, kFusedThreads = 64 * kFusedWaves;  // one parameter set per wave
+constexpr int kFusedWaves = 8, kFusedThreads = 64 * kFusedWaves;  // one parameter set per wave (A/B at 8 x 1 000: 4 waves 29.9 us, 8 waves 26.2, 16 waves 29.4 per launch)
+
+// Cross-workgroup hand-off inside the launch (MI355X_MICROARCH.md, rows handoff-flag / publish-large): payload
+// with agent-scope (sc1, write-through) stores, every wave drains its stores (vmcnt(0)), then ONE relaxed
+// agent-scope atomic on the arrival counter; the consumer reads the payload with sc1 loads.  No L2 write-back
+// fence: an agent-scope release costs 3.5 us per round here even when only one thread per workgroup issues it.
+__device__ __forceinline__ void st_agent(double* p, double v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double ld_agent(const double* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void drain_stores() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
 
 // slot of a live parameter set (0 = base point, 1 + k = k-th live parameter) -> parameter set index p
 __device__ __forceinline__ int ba_live_set(int slot) {
@@ -446,24 +458,18 @@ __global__ __launch_bounds__(kFusedThreads) void ba_fused_kernel(BaFusedArgs a) 
       const int v = triangulate_and_score<UNIFORM_K, false, F32R>(cv, obs, obs, X, e);
       // NaN = fewer than two views (no residual entry, helpers.py:207-208); a seen point whose error is not
       // a number is handed on as +inf so that the all-finite check of the trust-region loop still sees it
-      a.r[(size_t)p * N + idx] = v < 2 ? qnan : (isnan(e) ? __longlong_as_double(0x7ff0000000000000ll) : e);
+      st_agent(&a.r[(size_t)p * N + idx], v < 2 ? qnan : (isnan(e) ? __longlong_as_double(0x7ff0000000000000ll) : e));
     }
   }
   if (a.debug_stop == 3) return;
-  // ---- who finishes the chunk?  Every wave waits for its own stores to reach L2 (workgroup-scope release), then
-  // ONE thread makes the workgroup's results visible to the other XCDs (agent-scope release = write-back of this
-  // XCD's L2: measured at 16 us when all 832 waves of the launch issue it, the single most expensive step).
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  // ---- who finishes the chunk?
+  drain_stores();
   __syncthreads();
-  if (tid == 0) {
-    __threadfence();
-    sh_last = atomicAdd(&a.counters[chunk], 1) == a.groups - 1;
-    __threadfence();
-  }
+  if (tid == 0)
+    sh_last = __hip_atomic_fetch_add(&a.counters[chunk], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.groups - 1;
   __syncthreads();
   if (!sh_last) return;
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  if (tid == 0) a.counters[chunk] = 0;
+  if (tid == 0) __hip_atomic_store(&a.counters[chunk], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (a.debug_stop == 4) return;
   // ---- phase 2: the chunk's rows of Jaug (LDS, aliases the camera tables), cost terms
   const int LD = NP + 1;  // row stride of Jaug in LDS: lanes = rows store without a 64-way bank conflict
@@ -477,11 +483,11 @@ __global__ __launch_bounds__(kFusedThreads) void ba_fused_kernel(BaFusedArgs a) 
     double fj[kMaxCols];
     double r0 = __longlong_as_double(0x7ff8000000000000ll);
     if (idx < N) {
-      r0 = a.r[idx];
+      r0 = ld_agent(&a.r[idx]);
 #pragma unroll
       for (int q = 0; q < kMaxCols; q++) {
         const int j = cg + kFusedWaves * q;
-        fj[q] = ba_live_param(j, n) ? a.r[(size_t)(1 + j) * N + idx] : 0.0;
+        fj[q] = ba_live_param(j, n) ? ld_agent(&a.r[(size_t)(1 + j) * N + idx]) : 0.0;
       }
     }
     const bool valid = !isnan(r0);
@@ -511,8 +517,8 @@ __global__ __launch_bounds__(kFusedThreads) void ba_fused_kernel(BaFusedArgs a) 
       const unsigned long long badm = __ballot(valid && !isfinite(ct.f));
       for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
       if (lane == 0) {
-        a.cost_part[2 * chunk] = v;
-        a.cost_part[2 * chunk + 1] = badm ? 0.0 : 1.0;
+        st_agent(&a.cost_part[2 * chunk], v);
+        st_agent(&a.cost_part[2 * chunk + 1], badm ? 0.0 : 1.0);
       }
     }
   }
@@ -533,22 +539,18 @@ __global__ __launch_bounds__(kFusedThreads) void ba_fused_kernel(BaFusedArgs a) 
           acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[(size_t)s4 * 4 * LD], pb[(size_t)s4 * 4 * LD], acc, 0, 0, 0);
         double* out = a.partial + ((size_t)chunk * ntiles + u) * 256;
 #pragma unroll
-        for (int r = 0; r < 4; r++) out[r * 64 + lane] = acc[r];
+        for (int r = 0; r < 4; r++) st_agent(&out[r * 64 + lane], acc[r]);
       }
   }
   if (a.debug_stop == 6) return;
   // ---- who finishes the batch?
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  drain_stores();
   __syncthreads();
-  if (tid == 0) {
-    __threadfence();
-    sh_last = atomicAdd(&a.counters[a.chunks], 1) == a.chunks - 1;
-    __threadfence();
-  }
+  if (tid == 0)
+    sh_last = __hip_atomic_fetch_add(&a.counters[a.chunks], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.chunks - 1;
   __syncthreads();
   if (!sh_last) return;
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  if (tid == 0) a.counters[a.chunks] = 0;
+  if (tid == 0) __hip_atomic_store(&a.counters[a.chunks], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (a.debug_stop == 7) return;
   // ---- phase 4: G = sum of the chunks' partials in chunk order -> pinned host memory (upper triangle of
   // the leading (n+1) x (n+1) block; the host mirrors it)
@@ -567,7 +569,7 @@ __global__ __launch_bounds__(kFusedThreads) void ba_fused_kernel(BaFusedArgs a) 
 #pragma unroll
           for (int q = 0; q < 16; q++)
             v[t][q] = (u0 + t * kSlots < ntiles && k0 + q < a.chunks)
-                          ? part[(size_t)(k0 + q) * cs + (size_t)(u0 + t * kSlots) * 256 + reg * 64 + lane] : 0.0;
+                          ? ld_agent(&part[(size_t)(k0 + q) * cs + (size_t)(u0 + t * kSlots) * 256 + reg * 64 + lane]) : 0.0;
 #pragma unroll
         for (int t = 0; t < 2; t++)
 #pragma unroll
@@ -597,8 +599,8 @@ __global__ __launch_bounds__(kFusedThreads) void ba_fused_kernel(BaFusedArgs a) 
     if (wave == 0) {
       double c = 0.0, fin = 1.0;
       for (int k = lane; k < a.chunks; k += 64) {
-        c += a.cost_part[2 * k];
-        fin = fmin(fin, a.cost_part[2 * k + 1]);
+        c += ld_agent(&a.cost_part[2 * k]);
+        fin = fmin(fin, ld_agent(&a.cost_part[2 * k + 1]));
       }
       for (int o = 32; o > 0; o >>= 1) {
         c += __shfl_down(c, o);

@@ -688,6 +688,68 @@ extern "C" int mocap_ba_trust_region_step(mocap_ctx* ctx, int n, int64_t m, cons
   return MOCAP_OK;
 }
 
+extern "C" int mocap_ba_profile(mocap_ctx* ctx, const double* x, int64_t N, const double* obs, int f32_residuals,
+                                int use_cauchy, int reps, double* out) {
+  if (!ctx) return MOCAP_E_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (!x || !out || reps < 1) return ctx->fail(MOCAP_E_ARG, "mocap_ba_profile: bad argument");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  BaWork w;
+  int rc = ba_setup(ctx, w, N, obs, 1 + 7 * (ctx->C - 1) + 1);
+  if (rc) return rc;
+  std::vector<double> G;
+  double cost = 0;
+  for (int i = 0; i < 3; i++) {  // warm
+    rc = ba_linearize(ctx, w, x, f32_residuals, use_cauchy, G, cost);
+    if (rc) return rc;
+  }
+  hipEvent_t e0, e1;
+  HIP_TRY(ctx, hipEventCreate(&e0));
+  HIP_TRY(ctx, hipEventCreate(&e1));
+  double gpu_ms = 0, wall_us = 0;
+  for (int i = 0; i < reps; i++) {
+    const auto t0 = std::chrono::steady_clock::now();
+    HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
+    rc = ba_linearize(ctx, w, x, f32_residuals, use_cauchy, G, cost);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipEventRecord(e1, ctx->stream));
+    wall_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    HIP_TRY(ctx, hipEventSynchronize(e1));
+    float ms = 0;
+    HIP_TRY(ctx, hipEventElapsedTime(&ms, e0, e1));
+    gpu_ms += ms;
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  // the host side of an iteration: the trust-region subproblem at the first radius scipy would use
+  const int n = w.n, NP = w.NP;
+  std::vector<double> JtJ((size_t)n * n), g(n), step;
+  for (int i = 0; i < n; i++) {
+    for (int j = 0; j < n; j++) JtJ[(size_t)i * n + j] = G[(size_t)i * NP + j];
+    g[i] = G[(size_t)i * NP + n];
+  }
+  double Delta = 0;
+  for (int i = 0; i < n; i++) Delta += x[i] * x[i];
+  Delta = Delta > 0 ? std::sqrt(Delta) : 1.0;
+  const auto t1 = std::chrono::steady_clock::now();
+  for (int i = 0; i < reps; i++) {
+    TrSubproblem tr;
+    tr.prepare(n, w.m, JtJ.data(), g.data(), 0);
+    double alpha = 0.0;
+    tr.solve(Delta, alpha, step);
+  }
+  const double tr_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t1).count() / reps;
+  out[0] = 1e3 * gpu_ms / reps;
+  out[1] = wall_us / reps;
+  out[2] = tr_us;
+  out[3] = w.fused ? 1.0 : 5.0;
+  out[4] = (double)w.m;
+  out[5] = NP;
+  out[6] = w.fused ? 1.0 : 0.0;
+  out[7] = cost;
+  return MOCAP_OK;
+}
+
 extern "C" int mocap_ba_solve(mocap_ctx* ctx, double* x, int64_t N, const double* obs, double ftol, double xtol,
                               double gtol, int max_iter, int f32_residuals, int use_cauchy, double* info) {
   if (!ctx) return MOCAP_E_ARG;

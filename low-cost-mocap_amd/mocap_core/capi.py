@@ -59,6 +59,7 @@ SIGNATURES = {
     "mocap_ba_residuals": (_i32, [_vp, _i32, _vp, _i64, _vp, _vp]),
     "mocap_ba_normal_eq": (_i32, [_vp, _vp, _i64, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "mocap_ba_trust_region_step": (_i32, [_vp, _i32, _i64, _vp, _vp, _dbl, _vp, _i32, _vp, _vp]),
+    "mocap_ba_profile": (_i32, [_vp, _vp, _i64, _vp, _i32, _i32, _i32, _vp]),
     "mocap_ba_solve": (_i32, [_vp, _vp, _i64, _vp, _dbl, _dbl, _dbl, _i32, _i32, _i32, _vp]),
 }
 
@@ -357,6 +358,15 @@ class MocapCore:
         self._check(self.lib.mocap_ba_trust_region_step(self._h, n, int(m), _p(JtJ), _p(Jtr), float(Delta),
                                                         ctypes.addressof(a), int(method), _p(step), _p(info)))
         return step, a.value, {"method": int(info[0]), "live": int(info[1])}
+
+    def ba_profile(self, x, obs, f32_residuals=True, use_cauchy=True, reps=100):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        obs = np.ascontiguousarray(obs, dtype=np.float64).reshape(-1, self.C, 2)
+        out = np.zeros(8)
+        self._check(self.lib.mocap_ba_profile(self._h, _p(x), obs.shape[0], _p(obs), int(f32_residuals), int(use_cauchy),
+                                              int(reps), _p(out)))
+        keys = ("gpu_us_per_linearisation", "wall_us_per_linearisation", "host_tr_us", "launches", "m", "NP", "fused", "cost")
+        return dict(zip(keys, out.tolist()))
 
     def ba_solve(self, x0, obs, ftol=1e-2, xtol=1e-8, gtol=1e-8, max_iter=0, f32_residuals=True,
                  use_cauchy=True):
