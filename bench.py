@@ -47,6 +47,7 @@ WORKLOADS = {
 }
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: 8 TB/s spec
 FP64_VALU_PEAK_TF = 78.6      # MI355X FP64 vector peak
+FP64_MFMA_PEAK_TF = 78.6      # FP64 matrix peak (v_mfma_f64_16x16x4_f64, 32 flop/clk/SIMD)
 
 
 def algorithmic_bytes(counts, n_out, C, M):
@@ -64,6 +65,23 @@ def measured_traffic(frames):
         with open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")) as f:
             t = json.load(f)
         return float(t["hbm_bytes_per_frame"]) * frames
+    except Exception:
+        return None
+
+
+def executed_fp64(candidates, kernel_ms):
+    """Executed FP64 work of the frame kernel from the committed instruction-mix counter pass
+    (profiles/r02_fp64_mix.json: SQ_INSTS_VALU_{FMA,MUL,ADD,TRANS}_F64 per candidate on this kernel), scaled to
+    this launch's candidate count and divided by this run's kernel time.  None if the summary is absent."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r02_fp64_mix.json")) as f:
+            mix = json.load(f)
+        flop = float(mix["fp64_flop_per_candidate"]) * candidates
+        tf = flop / (kernel_ms * 1e-3) / 1e12
+        return {"achieved": tf, "frac": tf / FP64_VALU_PEAK_TF, "flop_per_candidate": mix["fp64_flop_per_candidate"],
+                "valu_lane_instructions_per_candidate": mix["valu_lane_instructions_per_candidate"],
+                "fp64_share_of_valu_instructions": mix["fp64_share_of_valu_instructions"],
+                "source": "profiles/r02_fp64_mix.json (rocprofv3 PMC instruction mix, FMA = 2 flop, MUL/ADD/TRANS = 1)"}
     except Exception:
         return None
 
@@ -269,7 +287,55 @@ def ba_bench_16k(core, iters=60):
                                    "cost": ref["cost"], "elapsed_ms": ref["elapsed_ms"]}}
 
 
-def ba_bench(core, iters=200):
+def ba_cpu_baseline(rig, init, obs, x0, budget_nfev=150):
+    """CPU baseline of the BA half of the metric, timed on this box in this run: the reference's own optimizer
+    call (helpers.py:287: scipy least_squares, loss="cauchy", 2-point Jacobian, float32 residuals) driven by
+    the oracle's C restatement of residual_function ("port"; single thread, BLAS pinned to 1 thread).  One
+    iteration = one accepted-or-rejected trust-region step, the unit the GPU figure counts."""
+    from scipy import optimize
+    from oracle import c_oracle
+    co = c_oracle.COracle(rig["K"], init["R"], init["t"])
+
+    def fun(x):
+        r = co.ba_residuals(x, obs)[0]
+        return r[~np.isnan(r)].astype(np.float32)
+    import contextlib
+    try:
+        from threadpoolctl import threadpool_limits
+        single = threadpool_limits(limits=1)
+    except Exception:  # pragma: no cover
+        single = contextlib.nullcontext()
+    with single:
+        fun(x0)
+        t0 = time.perf_counter()
+        # tolerances at scipy's floor: the run is ended by its evaluation budget, like the GPU figure's
+        res = optimize.least_squares(fun, x0, loss="cauchy", ftol=1e-15, xtol=None, gtol=None, max_nfev=budget_nfev)
+        dt = time.perf_counter() - t0
+        t1 = time.perf_counter()
+        for _ in range(5):
+            fun(x0)
+        t_eval = (time.perf_counter() - t1) / 5
+    out = {"value": (res.nfev - 1) / dt, "unit": "LM iterations/s", "cores": 1, "kind": "port",
+           "sample": f"{res.nfev - 1} trust-region steps ({res.njev} Jacobians of {x0.size + 1} residual evaluations) of "
+                     f"scipy.optimize.least_squares on the C restatement of residual_function (oracle/c), "
+                     f"8 cams x {obs.shape[0]} points, {dt:.1f}s", "ms_per_residual_evaluation": 1e3 * t_eval}
+    # the NumPy/Python restatement keeps the reference's structure (per-point Python loops, LAPACK SVD per point) and
+    # is bit-exact against it: one residual evaluation timed, an iteration costs n + 2 of them
+    try:
+        from oracle import mocap_oracle as mo
+        sub = obs[:100]
+        t2 = time.perf_counter()
+        mo.ba_residuals(x0, sub, [k for k in rig["K"]])
+        t_py = (time.perf_counter() - t2) * obs.shape[0] / sub.shape[0]
+        out["python_port_iterations_per_s_est"] = 1.0 / ((x0.size + 2) * t_py)
+        out["python_port_sample"] = (f"one residual evaluation of 100 points by oracle/mocap_oracle.py scaled to {obs.shape[0]}, "
+                                     f"x (n + 2) evaluations per accepted step")
+    except Exception as e:  # pragma: no cover
+        out["python_port_error"] = repr(e)
+    return out
+
+
+def ba_bench(core, iters=200, cpu=True):
     """Secondary metric: LM iterations/sec, 8 cams x 1000 points, reference settings
     (cauchy loss, float32 residual cast, 2-point Jacobian incl. the dead focal columns)."""
     from mocap_core import helpers
@@ -294,7 +360,28 @@ def ba_bench(core, iters=200):
     runs.sort(key=lambda r: r[0])
     dt, info = runs[len(runs) // 2]
     _, info_ref = core.ba_solve(x0, obs, ftol=1e-2)                             # reference stopping rule
-    return {"metric": "BA iters/sec (8 cams, 1k pts)", "value": info["iterations"] / dt,
+    prof = core.ba_profile(x0, obs, reps=200)
+    n, m = int(x0.size), int(info["m"])
+    gram_flop = 2.0 * m * n * n                                                  # J^T J, 2 m n^2
+    mfma_tf = gram_flop / (prof["gpu_us_per_linearisation"] * 1e-6) / 1e12
+    roofline = {"bound": "mfma", "achieved": mfma_tf, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                "frac": mfma_tf / FP64_MFMA_PEAK_TF, "traffic": None,
+                "kernel": ("mocap::ba_fused_kernel: one launch per linearisation (camera tables, (n_live + 1) x N residuals, "
+                           "float32 differencing, Cauchy scaling, v_mfma_f64_16x16x4_f64 Gram, reduction, zero-copy hand-over)")
+                          if prof["fused"] else "chain of 5 launches (build cameras, residuals, Jacobian, Gram, reduce)",
+                "kernel_us": prof["gpu_us_per_linearisation"], "launches_per_linearisation": int(prof["launches"]),
+                "algorithmic_flop_per_launch": gram_flop,
+                "algorithmic_bytes_per_launch": 16 * CAMS * int(obs.shape[0]) + 8 * (n + 1) * (n + 2) // 2,
+                "iteration_breakdown_us": {"gpu_linearisation": prof["gpu_us_per_linearisation"],
+                                           "launch_to_result_on_host": prof["wall_us_per_linearisation"],
+                                           "host_trust_region_subproblem": prof["host_tr_us"],
+                                           "whole_iteration": 1e6 * dt / max(info["iterations"], 1)},
+                "note": "latency bound by construction: 5 Mflop of J^T J per iteration is microseconds on the matrix cores; "
+                        "the iteration is a chain of dependent steps (launch, residual phase, two cross-XCD hand-offs, "
+                        "PCIe hand-over, host subproblem).  MFMA issue counters: profiles/r02_ba_pmc_mfma.csv"}
+    out_cpu = ba_cpu_baseline(rig, init, obs, x0) if cpu else None
+    return {"metric": "BA iters/sec (8 cams, 1k pts)", "value": info["iterations"] / dt, "roofline": roofline,
+            "cpu_baseline": out_cpu,
             "iterations": info["iterations"], "nfev": info["nfev"], "ms_per_iter": 1e3 * dt / max(info["iterations"], 1),
             "runs_ms": [round(1e3 * r[0], 2) for r in runs], "statistic": "median of 5 solves",
             "params": int(x0.size), "points": int(info["m"]),
@@ -460,7 +547,8 @@ def main():
                               "model": "SURVEY 8d work model: candidates x (92 v + 1500) flop, v = mean views "
                                        "(the kernel now needs fewer instructions than the model's Jacobi "
                                        "eigen-solve; issue-slot utilisation from PMC: profiles/)", "v_mean": v_mean,
-                              "candidates_per_launch": float(n_cand.sum())},
+                              "candidates_per_launch": float(n_cand.sum()),
+                              "executed": executed_fp64(float(n_cand.sum()), kernel_ms) if default_wl else None},
         }
         if world == 1:
             # parity gate next to the number: a prefix of the very batch that was timed, vs the oracle
@@ -487,7 +575,7 @@ def main():
                 line["blob_stage"] = blob_stage_bench(core, dev, stream)
             if not args.no_ba and default_wl:
                 core.set_stream(0)
-                line["ba"] = ba_bench(core)
+                line["ba"] = ba_bench(core, cpu=not args.no_cpu_baseline)
                 line["ba"]["calibration_16k_points"] = ba_bench_16k(core)
         print(json.dumps(line), flush=True)
     if world > 1:
