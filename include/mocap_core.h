@@ -102,6 +102,14 @@ int mocap_get_fundamental(mocap_ctx* ctx, double* F);
 int mocap_triangulate(mocap_ctx* ctx, int64_t N, const double* obs, double* xyz, double* err);
 int mocap_triangulate_dev(mocap_ctx* ctx, int64_t N, const double* d_obs, double* d_xyz, double* d_err);
 
+/* mocap_reproject: replaces calculate_reprojection_errors (helpers.py:203-241) for GIVEN object points:
+ * err[i] = mean over the seen cameras' 2 v pixel components of (obs - cv.projectPoints(xyz[i]))^2, NaN when
+ * fewer than two cameras see point i (the reference skips the entry).  The three call sites of the reference
+ * pass the triangulation of the same observations (helpers.py:272,416; index.py:275), for which
+ * mocap_triangulate's `err` output is the same number; this entry honours the function's own contract.
+ *   obs [N][C][2] (NaN unseen), xyz [N][3], err [N] */
+int mocap_reproject(mocap_ctx* ctx, int64_t N, const double* obs, const double* xyz, double* err);
+
 /* ---------------------------------------------------------------- frame path
  * Replaces find_point_correspondance_and_object_points (helpers.py:339-421) for a
  * batch of independent frames.
@@ -260,6 +268,13 @@ int mocap_ba_normal_eq(mocap_ctx* ctx, const double* x, int64_t N, const double*
  * parameters}.  Host-only arithmetic: exported so that parity tests can compare the step itself. */
 int mocap_ba_trust_region_step(mocap_ctx* ctx, int n, int64_t m, const double* JtJ, const double* Jtr,
                                double Delta, double* alpha_io, int method, double* step, int32_t* info);
+
+/* mocap_set_ba_progress: the reference's residual_function emits the current poses to the UI on every
+ * evaluation (socketio.emit("camera-pose"), helpers.py:274; App.tsx animates them).  mocap_ba_solve has no
+ * per-evaluation host round trip; it calls `cb(x, n, user)` once per ACCEPTED step with the parameter vector
+ * (on the calling thread of mocap_ba_solve, context lock held: do not call back into the same context).
+ * NULL switches it off. */
+int mocap_set_ba_progress(mocap_ctx* ctx, void (*cb)(const double* x, int n, void* user), void* user);
 
 /* mocap_ba_profile: measurement aid (bench.py's `ba.roofline`).  `reps` linearisations at x exactly as the LM loop
  * issues them, timed with HIP events on the context's stream, then `reps` trust-region subproblems on the

@@ -410,6 +410,7 @@ int ba_eval_device(mocap_ctx* ctx, BaWork& w, int P, const double* params = null
   ta.obs = w.d_obs;
   ta.xyz = nullptr;
   ta.err = w.d_r;
+  ta.xyz_in = nullptr;
   HIP_TRY(ctx, launch_triangulate(ta, ctx->stream));
   return MOCAP_OK;
 }
@@ -688,6 +689,14 @@ extern "C" int mocap_ba_trust_region_step(mocap_ctx* ctx, int n, int64_t m, cons
   return MOCAP_OK;
 }
 
+extern "C" int mocap_set_ba_progress(mocap_ctx* ctx, void (*cb)(const double* x, int n, void* user), void* user) {
+  if (!ctx) return MOCAP_E_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  ctx->ba_progress = cb;
+  ctx->ba_progress_user = user;
+  return MOCAP_OK;
+}
+
 extern "C" int mocap_ba_profile(mocap_ctx* ctx, const double* x, int64_t N, const double* obs, int f32_residuals,
                                 int use_cauchy, int reps, double* out) {
   if (!ctx) return MOCAP_E_ARG;
@@ -870,6 +879,7 @@ extern "C" int mocap_ba_solve(mocap_ctx* ctx, double* x, int64_t N, const double
     if (actual_reduction > 0) {
       xv = x_new;
       cost = cost_new;
+      if (ctx->ba_progress) ctx->ba_progress(xv.data(), n, ctx->ba_progress_user);  // once per accepted step
       njev++;              // scipy re-linearises even when it is about to stop (trf.py:534); the result is unused,
       if (!termination) {  // so only the count is kept
         const auto tl0 = now();

@@ -26,7 +26,10 @@ int mocap_ctx::fail(int code, const char* fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(buf, sizeof buf, fmt, ap);
   va_end(ap);
-  err = buf;
+  {
+    std::lock_guard<std::mutex> lk(err_mu);
+    err = buf;
+  }
   return code;
 }
 
@@ -83,6 +86,7 @@ extern "C" int mocap_create(int device_id, mocap_ctx** out) {
   if ((t = getenv("MOCAP_HEAVY_THRESHOLD"))) c->heavy_threshold = atoi(t);  // 0 disables splitting
   if ((t = getenv("MOCAP_SLICE_SIZE"))) c->slice_size = atoi(t);
   if ((t = getenv("MOCAP_FORCE_WIDE"))) c->force_wide = atoi(t) ? 1 : 0;
+  if ((t = getenv("MOCAP_PRUNE"))) c->prune = atoi(t) ? 1 : 0;  // 0: every group is reprojected in full (A/B)
   *out = c;
   return MOCAP_OK;
 }
@@ -114,7 +118,17 @@ extern "C" void mocap_destroy(mocap_ctx* ctx) {
   delete ctx;
 }
 
-extern "C" const char* mocap_last_error(const mocap_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+// The message is copied, under the error string's own lock, into a buffer owned by the CALLING thread: another thread's
+// failing call may rewrite ctx->err at any time (Flask-SocketIO handlers vs the MJPEG generator share one context).
+extern "C" const char* mocap_last_error(const mocap_ctx* ctx) {
+  if (!ctx) return "null context";
+  static thread_local std::string mine;
+  {
+    std::lock_guard<std::mutex> lk(const_cast<mocap_ctx*>(ctx)->err_mu);
+    mine = ctx->err;
+  }
+  return mine.c_str();
+}
 extern "C" const char* mocap_version(void) { return "mocap_core 0.1 (gfx950)"; }
 
 extern "C" int mocap_set_stream(mocap_ctx* ctx, void* hip_stream) {
@@ -316,6 +330,7 @@ static int triangulate_dev_locked(mocap_ctx* ctx, int64_t N, const double* d_obs
   a.obs = d_obs;
   a.xyz = d_xyz;
   a.err = d_err;
+  a.xyz_in = nullptr;
   HIP_TRY(ctx, launch_triangulate(a, ctx->stream));
   return MOCAP_OK;
 }
@@ -347,6 +362,38 @@ extern "C" int mocap_triangulate(mocap_ctx* ctx, int64_t N, const double* obs, d
   if (rc) return rc;
   HIP_TRY(ctx, hipMemcpyAsync(xyz, d_xyz, b_xyz, hipMemcpyDeviceToHost, ctx->stream));
   if (err) HIP_TRY(ctx, hipMemcpyAsync(err, d_err, b_err, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return MOCAP_OK;
+}
+
+extern "C" int mocap_reproject(mocap_ctx* ctx, int64_t N, const double* obs, const double* xyz, double* err) {
+  if (!ctx) return MOCAP_E_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (!ctx->C) return ctx->fail(MOCAP_E_NOCAMS, "mocap_set_cameras has not been called");
+  if (N < 0 || (N > 0 && (!obs || !xyz || !err))) return ctx->fail(MOCAP_E_ARG, "mocap_reproject: bad argument");
+  if (N == 0) return MOCAP_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const int C = ctx->C;
+  const size_t b_obs = sizeof(double) * (size_t)N * C * 2, b_xyz = sizeof(double) * (size_t)N * 3,
+               b_err = sizeof(double) * (size_t)N;
+  DevBuf& s = ctx->scratch[0];
+  if (s.reserve(b_obs + b_xyz + b_err)) return ctx->fail(MOCAP_E_HIP, "hipMalloc(%zu) failed", b_obs + b_xyz + b_err);
+  double* d_obs = (double*)s.ptr;
+  double* d_xyz = d_obs + (size_t)N * C * 2;
+  double* d_err = d_xyz + (size_t)N * 3;
+  HIP_TRY(ctx, hipMemcpyAsync(d_obs, obs, b_obs, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(d_xyz, xyz, b_xyz, hipMemcpyHostToDevice, ctx->stream));
+  TriArgs a;
+  a.cv = ctx->cv;
+  a.N = N;
+  a.P = 1;
+  a.stride_Pq = a.stride_RT = 0;
+  a.obs = d_obs;
+  a.xyz = nullptr;
+  a.err = d_err;
+  a.xyz_in = d_xyz;
+  HIP_TRY(ctx, launch_triangulate(a, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(err, d_err, b_err, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return MOCAP_OK;
 }
@@ -404,6 +451,7 @@ static int match_dev_locked(mocap_ctx* ctx, int64_t n_frames, int M_max, const f
   }
   a.H = hit_cap;
   a.wide = wide ? 1 : 0;
+  a.prune = ctx->prune;
   a.ws = nullptr;
   a.ws_stride = 0;
   // persistent grid: enough workgroups to fill every CU at the LDS-limited occupancy

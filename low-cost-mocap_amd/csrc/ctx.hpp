@@ -23,9 +23,11 @@ struct mocap_ctx {
   int slice_size = 0;       // 0 = automatic (MOCAP_SLICE_SIZE)
   int hit_cap = 16;         // wide frames: hits kept per (root, camera) (mocap_set_frame_limits)
   int force_wide = 0;       // route every frame batch through the wide (HBM workspace) variant
+  int prune = 1;            // stop a candidate group's reprojection once it cannot beat its root's best (exact)
   hipStream_t own_stream = nullptr, stream = nullptr;
   std::mutex mu;            // one context = one serialised caller (include/mocap_core.h)
-  std::string err;
+  std::string err;          // guarded by err_mu (written by a failing call, copied out by mocap_last_error)
+  std::mutex err_mu;
   uint32_t flags = 1u;      // MOCAP_OPT_F32_ROUNDING on by default
   int C = 0;
   std::vector<double> hK, hR, ht, hF;  // host copies (intrinsics are reused by bundle adjustment)
@@ -37,6 +39,8 @@ struct mocap_ctx {
   void* ba_pin = nullptr;
   size_t ba_pin_cap = 0;
   hipEvent_t ba_event = nullptr;
+  void (*ba_progress)(const double* x, int n, void* user) = nullptr;  // mocap_set_ba_progress
+  void* ba_progress_user = nullptr;
   DevBuf ba_fused;          // one-launch linearisation: chunk partial tiles | chunk costs | counters | (Jaug dump)
   double ba_stamp = 0.0;    // completion stamp of the last fused launch (monotonic per context)
   void* live_pin = nullptr;  // zero-copy staging of the live (few frames per call) host entry point

@@ -80,7 +80,7 @@ __device__ __forceinline__ void wave_lds_sync() {
 struct FrameLayout {
   // byte offsets, computed identically on host (sizes) and device (carving)
   size_t line, dist, seg_e, seg_x, seg_g, goff, gcnt, outslot, hcount, root_blob, root_cam, claimed, nact,
-      cnt, misc, lds_total;                          // always LDS
+      cnt, misc, rbound, lds_total;                  // always LDS
   size_t bxy, cxy, hits, dig, nh, act, hb_d, hb_k;   // LDS when narrow, workspace when wide
   size_t bt;                                          // table mode: DLT contribution per (camera, blob)
   size_t ws_total;
@@ -100,6 +100,7 @@ struct FrameLayout {
     const size_t dist_n = wide ? 0 : ((size_t)R * M > (size_t)T ? (size_t)R * M : (size_t)T);
     const size_t dist_end = dist + sizeof(double) * dist_n;
     if (dist_end > o) o = dist_end;
+    rbound = o;    o += sizeof(double) * R;   // best error seen so far per root (any lane), phase D
     seg_g = o;     o += sizeof(uint32_t) * (T + R);
     goff = o;      o += sizeof(uint32_t) * (R + 1);
     gcnt = o;      o += sizeof(uint32_t) * R;
@@ -149,6 +150,7 @@ struct FrameState {
   const int C, M, R, tid;
   int Hs;  // hit-list stride per (root, camera)
   double *line, *dist, *seg_e, *seg_x;
+  unsigned long long* rbound;  // [R] bit pattern of the smallest error any lane has found for the root (+inf at start)
   uint32_t *seg_g, *goff, *gcnt;
   int32_t *outslot, *cnt, *misc;
   float2 *bxy;  // [C][M]  the frame's blobs
@@ -172,6 +174,7 @@ struct FrameState {
     dist = (double*)(smem + L.dist);
     seg_e = (double*)(smem + L.seg_e);
     seg_x = (double*)(smem + L.seg_x);
+    rbound = (unsigned long long*)(smem + L.rbound);
     seg_g = (uint32_t*)(smem + L.seg_g);
     goff = (uint32_t*)(smem + L.goff);
     gcnt = (uint32_t*)(smem + L.gcnt);
@@ -483,6 +486,7 @@ struct FrameState {
       }
       if (over) atomicOr(&misc[MI_STATUS], MOCAP_ST_CAND_OVERFLOW_);
       nact[r] = (uint8_t)na;
+      rbound[r] = 0x7ff0000000000000ull;
       gcnt[r] = (views > 1 && !over) ? (uint32_t)total : 0u;  // helpers.py:413-414 drops 1-view roots
     }
     __syncthreads();
@@ -577,7 +581,7 @@ struct FrameState {
       int r = lo;
       uint32_t r_beg = goff[r], r_end = goff[r + 1];
       load_group<false>(r, g - r_beg);
-      double best_e = 0.0, best_X[3] = {0, 0, 0};
+      double best_e = __builtin_huge_val(), best_X[3] = {0, 0, 0};
       uint32_t best_g = 0;
       bool have = false;
       // a blob never has NaN coordinates inside a multi-view group (NaN fails the gate), so NaN
@@ -606,20 +610,35 @@ struct FrameState {
         y = (double)v.y;
         return true;
       };
+      // Selection only asks whether a group beats the best one of its root, so the reprojection of a group stops
+      // once its running sum of squares is out of reach of the smallest error ANY lane has found for the root so
+      // far (rbound, LDS, 64-bit unsigned min on the bit pattern of a non-negative double).  The global minimum
+      // and its ties are never cut short (their partial sums stay below every bound), so the result -- first
+      // minimum in candidate order -- does not depend on which lane got where first; only the amount of work does.
+      const double inf = __builtin_huge_val();
+      const bool prune = p.prune != 0;
       while (true) {
         double X[3], e;
+        const double bound = prune ? __longlong_as_double((long long)rbound[r]) : inf;
         if constexpr (TABLE)
-          triangulate_and_score_tab<true, F32R>(cv, contrib, obs_ix, X, e);
+          triangulate_and_score_tab<true, F32R>(cv, contrib, obs_ix, X, e, bound);
         else
-          triangulate_and_score<UNIFORM_K, true, F32R>(cv, obs, obs, X, e);
-        if (!have || e < best_e) {  // strict <: first minimum within the lane's ascending run
-          have = true;
-          best_e = e;
+          triangulate_and_score<UNIFORM_K, true, F32R>(cv, obs, obs, X, e, bound);
+        if (e < best_e) {  // strict <: first minimum within the lane's ascending run (best_e starts at +inf; a
+          best_e = e;      // group that was cut short or whose error is not finite never enters)
           best_g = g - r_beg;
           best_X[0] = X[0];
           best_X[1] = X[1];
           best_X[2] = X[2];
+          if (prune) atomicMin(&rbound[r], (unsigned long long)__double_as_longlong(e));
+        } else if (!have && !(e < inf)) {  // first group of the segment without a finite error (cut short, or a
+          best_e = e;                      // degenerate point): it stands unless something smaller follows; a NaN
+          best_g = g - r_beg;              // sticks, as np.argmin keeps the first NaN (helpers.py:418)
+          best_X[0] = X[0];
+          best_X[1] = X[1];
+          best_X[2] = X[2];
         }
+        have = true;
         if (++g >= g_end) break;
         if (g >= r_end) {  // leaving root r: flush the (lane, root) segment
           const int s = tid + outslot[r];
@@ -629,6 +648,7 @@ struct FrameState {
           seg_x[3 * s + 1] = best_X[1];
           seg_x[3 * s + 2] = best_X[2];
           have = false;
+          best_e = inf;
           do { r++; } while (goff[r + 1] <= g);
           r_beg = goff[r];
           r_end = goff[r + 1];

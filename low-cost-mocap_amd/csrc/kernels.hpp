@@ -50,6 +50,7 @@ struct FrameArgs {
   size_t ws_stride;
   int H;
   int wide;
+  int prune;  // cut the reprojection of a group short once it cannot beat the best of its root (exact, see evaluate())
 };
 
 constexpr int kWideThreads = 1024;  // workgroup size of the wide-frame variant (one workgroup per CU)
@@ -127,6 +128,7 @@ struct TriArgs {
   const double* obs;      // [N][C][2], NaN = unseen
   double* xyz;            // [P][N][3] or null
   double* err;            // [P][N] or null
+  const double* xyz_in;   // null, or [N][3]: score these points instead of triangulating (helpers.py:214-241)
 };
 hipError_t launch_triangulate(const TriArgs& a, hipStream_t stream);
 

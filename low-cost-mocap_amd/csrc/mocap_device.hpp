@@ -321,16 +321,31 @@ __device__ __forceinline__ void reproject_sq(Tab RT, ctab_t K4, const double (&X
 // Returns the number of views; X / err are valid when it is >= 2.
 // Second half of triangulate_and_score: null vector of B (v views accumulated), point, reprojection error.
 template <bool UNIFORM_K, bool PAIRWISE, bool F32R, class View, class Obs2>
+__device__ __forceinline__ void score_point(const View& cv, int v, Obs2&& obs2, const double (&X)[3], double& err,
+                                            double limit);
+
+// `limit` (sum of squared residuals, +inf = off): candidate selection only needs to know whether this group beats
+// the best one so far, and the residuals are a sum of non-negative terms -- once the running left-to-right sum
+// exceeds `limit` the group cannot win, and the remaining views are skipped (err = +inf).  The callers put a safety
+// factor on the limit, so a group within rounding distance of the best is never cut short.
+template <bool UNIFORM_K, bool PAIRWISE, bool F32R, class View, class Obs2>
 __device__ __forceinline__ void solve_and_score(const View& cv, double (&B)[10], int v, Obs2&& obs2,
-                                                double (&X)[3], double& err) {
-  const int C = cv.C;
+                                                double (&X)[3], double& err,
+                                                double limit = __builtin_huge_val()) {
   double vec[4];
   smallest_eigvec4(B, vec);
   const double rw = recip_refined(vec[3]);
   X[0] = div_by(vec[0], vec[3], rw);  // helpers.py:321
   X[1] = div_by(vec[1], vec[3], rw);
   X[2] = div_by(vec[2], vec[3], rw);
+  score_point<UNIFORM_K, PAIRWISE, F32R>(cv, v, obs2, X, err, limit);
+}
 
+// calculate_reprojection_error (helpers.py:214-241) of a GIVEN point X seen by v cameras.
+template <bool UNIFORM_K, bool PAIRWISE, bool F32R, class View, class Obs2>
+__device__ __forceinline__ void score_point(const View& cv, int v, Obs2&& obs2, const double (&X)[3], double& err,
+                                            double limit) {
+  const int C = cv.C;
   double Xp[3] = {X[0], X[1], X[2]};
   if (F32R) {
     Xp[0] = (double)(float)X[0];  // helpers.py:232 `.astype(np.float32)`
@@ -345,6 +360,7 @@ __device__ __forceinline__ void solve_and_score(const View& cv, double (&B)[10],
   double seq = 0.0, r[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   int j = 0;
   for (int c0 = 0; c0 < C4; c0 += 4) {
+    if (!(seq <= limit)) continue;  // cut short: whole waves skip the block once every lane is out
 #pragma unroll
     for (int u = 0; u < 4; u++) {
       double x, y;
@@ -376,12 +392,13 @@ __device__ __forceinline__ void solve_and_score(const View& cv, double (&B)[10],
       j++;
     }
   }
-  err = (pw ? spw : seq) / (double)(2 * v);
+  err = (seq <= limit) ? (pw ? spw : seq) / (double)(2 * v) : __builtin_huge_val();
 }
 
 template <bool UNIFORM_K, bool PAIRWISE, bool F32R, class View, class Obs1, class Obs2>
 __device__ __forceinline__ int triangulate_and_score(const View& cv, Obs1&& obs1, Obs2&& obs2,
-                                                     double (&X)[3], double& err) {
+                                                     double (&X)[3], double& err,
+                                                     double limit_e = __builtin_huge_val()) {
   const int C = cv.C;
   double B[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   int v = 0;
@@ -393,7 +410,7 @@ __device__ __forceinline__ int triangulate_and_score(const View& cv, Obs1&& obs1
     }
   }
   if (v <= 1) return v;  // helpers.py:300
-  solve_and_score<UNIFORM_K, PAIRWISE, F32R>(cv, B, v, obs2, X, err);
+  solve_and_score<UNIFORM_K, PAIRWISE, F32R>(cv, B, v, obs2, X, err, limit_e * (double)(2 * v) * (1.0 + 0x1p-40));
   return v;
 }
 
@@ -402,13 +419,16 @@ __device__ __forceinline__ int triangulate_and_score(const View& cv, Obs1&& obs1
 // when the camera is not in the group.
 template <bool PAIRWISE, bool F32R, class Contrib, class Obs2>
 __device__ __forceinline__ int triangulate_and_score_tab(const CamView& cv, Contrib&& contrib, Obs2&& obs2,
-                                                         double (&X)[3], double& err) {
+                                                         double (&X)[3], double& err,
+                                                         double limit_e = __builtin_huge_val()) {
   const int C = cv.C;
   double B[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   int v = 0;
   for (int c = 0; c < C; c++) v += contrib(c, B) ? 1 : 0;
   if (v <= 1) return v;
-  solve_and_score<true, PAIRWISE, F32R>(cv, B, v, obs2, X, err);
+  // limit_e is a bound on the ERROR (mean of 2 v squares) -> bound on their sum, with room for the rounding of
+  // the two summation orders (~2 v ulp) and of the division
+  solve_and_score<true, PAIRWISE, F32R>(cv, B, v, obs2, X, err, limit_e * (double)(2 * v) * (1.0 + 0x1p-40));
   return v;
 }
 

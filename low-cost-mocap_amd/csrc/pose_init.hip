@@ -647,6 +647,7 @@ extern "C" int mocap_initial_poses(mocap_ctx* ctx, int C, int64_t N, const doubl
     ta.obs = d_obs;
     ta.xyz = d_xyz;
     ta.err = nullptr;
+    ta.xyz_in = nullptr;
     HIP_TRY(ctx, launch_triangulate(ta, ctx->stream));
     xyz.resize((size_t)n * 12);
     HIP_TRY(ctx, hipMemcpyAsync(xyz.data(), d_xyz, b_xyz, hipMemcpyDeviceToHost, ctx->stream));

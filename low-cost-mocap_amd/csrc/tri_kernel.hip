@@ -27,7 +27,22 @@ __global__ __launch_bounds__(256) void tri_kernel(TriArgs a) {
     double X[3] = {qnan, qnan, qnan}, e = qnan;
     // explicit captures arrive as object ndarrays in the reference (index.py:232): errors.mean()
     // sums left to right there, so PAIRWISE = false
-    const int v = triangulate_and_score<UNIFORM_K, false, F32R>(cv, obs, obs, X, e);
+    int v;
+    if (a.xyz_in) {
+      // calculate_reprojection_error of a given point (helpers.py:214-241): the views decide whether there is an
+      // entry at all (helpers.py:222-223); a NaN coordinate (the reference's None) yields NaN
+      v = 0;
+      for (int c = 0; c < C; c++) {
+        double x, y;
+        v += obs(c, x, y) ? 1 : 0;
+      }
+      X[0] = a.xyz_in[(size_t)n * 3 + 0];
+      X[1] = a.xyz_in[(size_t)n * 3 + 1];
+      X[2] = a.xyz_in[(size_t)n * 3 + 2];
+      if (v >= 2) score_point<UNIFORM_K, false, F32R>(cv, v, obs, X, e, __builtin_huge_val());
+    } else {
+      v = triangulate_and_score<UNIFORM_K, false, F32R>(cv, obs, obs, X, e);
+    }
     if (v < 2) {
       X[0] = X[1] = X[2] = qnan;  // the reference yields [None, None, None] (helpers.py:300-301)
       e = qnan;                   // and skips the error entry (helpers.py:207-208)

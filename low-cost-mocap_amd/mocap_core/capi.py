@@ -59,6 +59,8 @@ SIGNATURES = {
     "mocap_ba_residuals": (_i32, [_vp, _i32, _vp, _i64, _vp, _vp]),
     "mocap_ba_normal_eq": (_i32, [_vp, _vp, _i64, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "mocap_ba_trust_region_step": (_i32, [_vp, _i32, _i64, _vp, _vp, _dbl, _vp, _i32, _vp, _vp]),
+    "mocap_reproject": (_i32, [_vp, _i64, _vp, _vp, _vp]),
+    "mocap_set_ba_progress": (_i32, [_vp, _vp, _vp]),
     "mocap_ba_profile": (_i32, [_vp, _vp, _i64, _vp, _i32, _i32, _i32, _vp]),
     "mocap_ba_solve": (_i32, [_vp, _vp, _i64, _vp, _dbl, _dbl, _dbl, _i32, _i32, _i32, _vp]),
 }
@@ -169,6 +171,15 @@ class MocapCore:
         err = np.empty(N)
         self._check(self.lib.mocap_triangulate(self._h, N, _p(obs), _p(xyz), _p(err)))
         return xyz, err
+
+    def reproject(self, obs, xyz):
+        """Reprojection error of given points (calculate_reprojection_errors, helpers.py:203-241); NaN = < 2 views."""
+        obs = np.ascontiguousarray(obs, dtype=np.float64).reshape(-1, self.C, 2)
+        xyz = np.ascontiguousarray(xyz, dtype=np.float64).reshape(-1, 3)
+        assert xyz.shape[0] == obs.shape[0]
+        err = np.empty(obs.shape[0])
+        self._check(self.lib.mocap_reproject(self._h, obs.shape[0], _p(obs), _p(xyz), _p(err)))
+        return err
 
     def match_triangulate(self, blobs, counts, gate_px=5.0, K_max=None, G_cap=1 << 20):
         blobs = np.ascontiguousarray(blobs, dtype=np.float32)
@@ -358,6 +369,17 @@ class MocapCore:
         self._check(self.lib.mocap_ba_trust_region_step(self._h, n, int(m), _p(JtJ), _p(Jtr), float(Delta),
                                                         ctypes.addressof(a), int(method), _p(step), _p(info)))
         return step, a.value, {"method": int(info[0]), "live": int(info[1])}
+
+    _BA_CB = ctypes.CFUNCTYPE(None, ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.c_void_p)
+
+    def set_ba_progress(self, fn):
+        """fn(x: ndarray) is called once per accepted step of ba_solve (None = off)."""
+        if fn is None:
+            self._ba_cb = None
+            self._check(self.lib.mocap_set_ba_progress(self._h, None, None))
+            return
+        self._ba_cb = self._BA_CB(lambda px, n, _u: fn(np.ctypeslib.as_array(px, shape=(n,)).copy()))   # keep a reference
+        self._check(self.lib.mocap_set_ba_progress(self._h, ctypes.cast(self._ba_cb, ctypes.c_void_p), None))
 
     def ba_profile(self, x, obs, f32_residuals=True, use_cauchy=True, reps=100):
         x = np.ascontiguousarray(x, dtype=np.float64)

@@ -129,16 +129,19 @@ def triangulate_point(image_points, camera_poses):
 
 def calculate_reprojection_errors(image_points, object_points, camera_poses):
     """helpers.py:203-211: entries with fewer than two views are skipped (the result may be shorter).
-
-    NOTE: like the reference's only callers (helpers.py:272,416; index.py:275) the object points are
-    expected to be the triangulation of `image_points` under `camera_poses`; the core recomputes them."""
+    The errors are those of the object points PASSED IN (mocap_reproject), as the function's contract says; the
+    reference's three call sites happen to pass the triangulation of the same observations."""
     C = len(camera_poses)
     with _state["lock"]:
         core = _upload_cameras(camera_poses)
         obs = _obs_array(image_points, C)
         if obs.shape[0] == 0:
             return np.array([])
-        _, err = core.triangulate(obs)
+        op = np.asarray(object_points, dtype=object).reshape(obs.shape[0], 3)
+        xyz = np.full(op.shape, np.nan)
+        ok = np.vectorize(lambda v: v is not None)(op).all(axis=1)
+        xyz[ok] = op[ok].astype(np.float64)
+        err = core.reproject(obs, xyz)
     return err[~np.isnan(err)]
 
 
@@ -314,20 +317,30 @@ def bundle_adjustment(image_points, camera_poses, socketio, return_info=False):
 
     mode "resident" (default): the whole trust-region loop runs in the core (mocap_ba_solve).
     mode "scipy": the reference's optimizer call verbatim, only the residual evaluations are GPU.
-    `socketio.emit("camera-pose", ...)` is sent with the final poses (the reference streams one per
-    residual evaluation, helpers.py:274)."""
+    `socketio.emit("camera-pose", ...)`: the reference streams one per residual evaluation (helpers.py:274; the UI
+    animates the cameras while calibrating, App.tsx:255).  Mode "scipy" does exactly that; mode "resident" has no
+    per-evaluation host round trip and emits once per accepted step (1 / (n + 2) as often), then the final poses."""
     C = len(camera_poses)
     x0 = _ba_x0(camera_poses)
     with _state["lock"]:
         core = _upload_cameras(camera_poses)
         obs = _obs_array(image_points, C)
+        def emit(params):
+            if socketio is not None:
+                socketio.emit("camera-pose", {"camera_poses": camera_pose_to_serializable(_params_to_camera_poses(params))})
+
         if _state["ba_mode"] == "resident":
-            x, info = core.ba_solve(x0, obs, ftol=1e-2, f32_residuals=True, use_cauchy=True)
+            core.set_ba_progress(emit if socketio is not None else None)
+            try:
+                x, info = core.ba_solve(x0, obs, ftol=1e-2, f32_residuals=True, use_cauchy=True)
+            finally:
+                core.set_ba_progress(None)
         else:
             from scipy import optimize
 
             def residual_function(params):
                 r = core.ba_residuals(params, obs)[0]
+                emit(params)                                    # helpers.py:274
                 return r[~np.isnan(r)].astype(np.float32)       # helpers.py:273
 
             res = optimize.least_squares(residual_function, x0, verbose=0, loss="cauchy", ftol=1e-2)

@@ -1,0 +1,153 @@
+"""GPU: the drop-in boundary's contracts beyond the numbers -- arguments honoured as the reference's functions
+define them, the context shared by several threads (Flask-SocketIO handlers and the MJPEG generator run
+unlocked against the same Cameras state), per-thread error text, progress events."""
+import threading
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def test_reprojection_errors_of_given_object_points(core):
+    """calculate_reprojection_errors(image_points, object_points, camera_poses) (helpers.py:203-241) scores the
+    points it is HANDED, not a re-triangulation: moved points get the oracle's errors for the moved points; the
+    triangulated points reproduce mocap_triangulate's own error output bit for bit; the helpers mirror drops
+    entries with fewer than two views."""
+    from mocap_core import helpers, synth
+    from oracle import mocap_oracle as mo
+    g = load_golden("dlt_c8")
+    K, R, t = g["K"], g["R"], g["t"]
+    obs = g["obs"]
+    core.set_cameras(K, R, t)
+    xyz, err = core.triangulate(obs)
+    again = core.reproject(obs, xyz)
+    assert np.array_equal(np.isnan(err), np.isnan(again))
+    assert np.array_equal(err[~np.isnan(err)], again[~np.isnan(err)])
+    rng = np.random.default_rng(3)
+    moved = np.where(np.isnan(xyz), 0.0, xyz) + rng.normal(0, 0.02, xyz.shape)
+    got = core.reproject(obs, moved)
+    want = mo.reprojection_errors(obs, moved, [k for k in K], R, t)
+    seen = (~np.isnan(obs[..., 0])).sum(axis=1) >= 2
+    assert np.array_equal(~np.isnan(got), seen)
+    w = np.array([np.nan if e is None else e for e in want], dtype=np.float64)
+    np.testing.assert_allclose(got[seen], w[seen], rtol=1e-9)
+    assert (np.abs(got[seen] - err[seen]) > 1e-3 * err[seen]).mean() > 0.9       # really the moved points' errors
+    # the reference-shaped mirror
+    helpers.set_core(core)
+    helpers.set_camera_params([{"intrinsic_matrix": k.tolist()} for k in K])
+    poses = [{"R": R[i], "t": t[i]} for i in range(len(K))]
+    e2 = helpers.calculate_reprojection_errors(synth.obs_to_reference_array(obs), moved.tolist(), poses)
+    assert e2.shape == (int(seen.sum()),)
+    assert np.array_equal(e2, got[seen])
+
+
+def test_context_shared_by_two_threads(core):
+    """One thread keeps asking for a frame's points (the MJPEG generator's find_point_correspondance... call,
+    helpers.py:94) while another keeps replacing the camera set and the to-world matrix (the socket handlers,
+    helpers.py:171-175, :100).  Every answer must be exactly one of the single-threaded answers: calls are
+    serialised per context and tables are swapped whole."""
+    from mocap_core import capi, synth
+    own = capi.MocapCore(0)
+    rig_a = synth.ring_rig(4)
+    rig_b = synth.ring_rig(4, radius=2.5)
+    blobs, counts, _ = synth.make_blob_stream(rig_a, 4, 4, seed=90)
+    W = np.array(synth.APP_TSX_TO_WORLD, dtype=np.float64)
+    answers = []
+    for rig in (rig_a, rig_b):
+        for world in (None, W):
+            own.set_cameras(rig["K"], rig["R"], rig["t"])
+            own.set_world_transform(world)
+            r = own.match_triangulate(blobs, counts, K_max=16)
+            answers.append((r["n_out"].copy(), r["corr"].copy(), r["xyz"].copy()))
+    stop = threading.Event()
+    errors = []
+
+    def flipper():
+        i = 0
+        try:
+            while not stop.is_set():
+                rig = rig_a if i & 1 else rig_b
+                own.set_cameras(rig["K"], rig["R"], rig["t"])
+                own.set_world_transform(W if i & 2 else None)
+                i += 1
+        except Exception as e:  # pragma: no cover
+            errors.append(e)
+
+    th = threading.Thread(target=flipper)
+    th.start()
+    seen = set()
+    try:
+        for _ in range(400):
+            r = own.match_triangulate(blobs, counts, K_max=16)
+            hit = [k for k, (n, c, x) in enumerate(answers)
+                   if np.array_equal(n, r["n_out"]) and np.array_equal(c, r["corr"]) and np.array_equal(x, r["xyz"], equal_nan=True)]
+            assert hit, "an answer that belongs to no single camera set / transform"
+            seen.add(hit[0])
+    finally:
+        stop.set()
+        th.join()
+        own.close()
+    assert not errors
+    assert len(seen) >= 2          # the flips really interleaved with the frame calls
+
+
+def test_error_text_belongs_to_the_calling_thread(core):
+    """mocap_last_error copies the message into a buffer of the calling thread: a second thread failing
+    differently cannot rewrite the text the first one is about to read."""
+    from mocap_core import capi
+    lib = capi.load_library()
+    fresh = capi.MocapCore(0)
+    rc = lib.mocap_triangulate(fresh._h, 1, None, None, None)              # no cameras yet
+    assert rc != 0
+    first = lib.mocap_last_error(fresh._h)
+    seen = {}
+
+    def other():
+        rc2 = lib.mocap_find_blobs(fresh._h, 1, None, 4, None, None, None, None, None)   # no lens model yet
+        seen["rc"] = rc2
+        seen["text"] = lib.mocap_last_error(fresh._h)
+
+    th = threading.Thread(target=other)
+    th.start()
+    th.join()
+    assert seen["rc"] != 0 and seen["text"] != first                       # the context now holds the other message
+    assert b"mocap_set_cameras" in first                                    # this thread's copy is what it was
+    fresh.close()
+
+
+def test_bundle_adjustment_streams_camera_poses(core):
+    """helpers.py:274: the reference emits "camera-pose" on every residual evaluation.  Mode "scipy" does the same
+    (one emit per evaluation of the reference's optimizer), mode "resident" one per accepted step + the final one."""
+    from mocap_core import helpers, synth
+    helpers.set_core(core)
+    rig = synth.ring_rig(4)
+    rng = np.random.default_rng(70)
+    obs, _ = synth.make_ba_observations(rig, 120, seed=70)
+    init = synth.perturb_rig(rig, rng)
+    helpers.set_camera_params([{"intrinsic_matrix": k.tolist()} for k in rig["K"]])
+    poses0 = [{"R": init["R"][i], "t": init["t"][i].reshape(3, 1)} for i in range(4)]
+
+    class Sock:
+        def __init__(self):
+            self.n = 0
+            self.last = None
+
+        def emit(self, name, payload):
+            assert name == "camera-pose" and len(payload["camera_poses"]) == 4
+            self.n += 1
+            self.last = payload
+    counts = {}
+    for mode in ("resident", "scipy"):
+        helpers.set_bundle_adjustment_mode(mode)
+        s = Sock()
+        out, info = helpers.bundle_adjustment(synth.obs_to_reference_array(obs), poses0, s, return_info=True)
+        counts[mode] = (s.n, info)
+        np.testing.assert_allclose(np.array(s.last["camera_poses"][1]["R"]), np.asarray(out[1]["R"]), atol=0)
+    helpers.set_bundle_adjustment_mode("resident")
+    n_res, info_res = counts["resident"]
+    assert n_res == int(info_res["njev"]) - 1 + 1                           # accepted steps + the final emit
+    n_sp, info_sp = counts["scipy"]
+    assert n_sp == info_sp["nfev"] + info_sp["njev"] * 22 + 1               # every evaluation (n = 22 FD probes per Jacobian)
