@@ -446,27 +446,24 @@ def main():
                                    d_xyz[lo:].data_ptr(), d_err[lo:].data_ptr(), d_corr[lo:].data_ptr(),
                                    d_nout[lo:].data_ptr(), d_status[lo:].data_ptr(), d_ncand[lo:].data_ptr())
 
-    # N > 1: the four output arrays are gathered as they are (no packing pass: measured at ~10 % of a step).
-    # MOCAP_BENCH_FORCE_SUB=s cuts a step's batch into s sub-batches with their own gathers, which would hide
-    # all but 1/s of the LAST step's exchange -- measured on one GPU the smaller launches cost more (s = 2: +3.9 %,
-    # 4: +11.7 %, the candidate counts are heavy-tailed) than that tail is worth, so the default is one batch;
-    # the variable also exercises the N > 1 loop on a single GPU.
-    SUB = int(os.environ.get("MOCAP_BENCH_FORCE_SUB", 0)) or 1
-    multi = world > 1 or SUB > 1
-    bounds = [(F * i // SUB, F * (i + 1) // SUB) for i in range(SUB)]
+    # N > 1: the one exchange of the path: final tracks -> rank 0.  Only the valid points travel:
+    # mocap_compact_tracks_dev packs them into 32 + 2C-byte records behind the frame kernel (1.1 KB instead of the
+    # 2.3 KB of K_max-padded arrays per 8 x 16 frame), the record count lands in pinned host memory, and the
+    # transfer of step i is posted -- on its own stream -- once step i + 1's kernels are queued, so it hides behind
+    # them; only the last step's exchange is exposed.  MOCAP_BENCH_EXCHANGE=1 runs the same code path on one GPU.
+    multi = world > 1 or bool(int(os.environ.get("MOCAP_BENCH_EXCHANGE", "0")))
+    comp = mdist.TrackCompactor(core, F, K_MAX, C, dev) if multi else None
+    comm = torch.cuda.Stream(dev) if multi else None
+    frames_per_rank = [F] * world          # weak scaling: every rank owns F frames
+    exchanged = {"records": 0, "bytes": 0}
 
-    def step():
-        """One pass over the batch, then the one exchange of the path: final tracks -> rank 0.  The
-        gathers are queued asynchronously (RCCL's own stream) so they overlap the following kernels;
-        every handle is completed inside the timed region."""
-        if not multi:
-            hot_path()
-            return []
-        hs = []
-        for lo, hi in bounds:
-            hot_path(lo, hi)
-            hs += mdist.gather_tracks_async((d_nout[lo:hi], d_xyz[lo:hi], d_err[lo:hi], d_corr[lo:hi]), dst=0)
-        return hs
+    def post_exchange(i):
+        n = comp.count(i)                  # waits for step i's compaction only
+        exchanged["records"] += n
+        exchanged["bytes"] += n * comp.stride + 4 * F
+        with torch.cuda.stream(comm):
+            comm.wait_event(comp.events[i])
+            return mdist.gather_compact_async(comp.n_out[i], comp.records[i], n, frames_per_rank, dst=0)
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -474,29 +471,34 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        for h in step():
+    def run(n_steps, events=None):
+        prev, pending = None, []
+        for i in range(n_steps):
+            if events:
+                events[i][0].record(stream)
+            hot_path()
+            if multi:
+                cur = comp.compact(d_nout, d_xyz, d_err, d_corr, stream)
+            if events:
+                events[i][1].record(stream)
+            if multi:
+                if prev is not None:
+                    pending.append(post_exchange(prev))
+                    while len(pending) > 2:        # at most two exchanges in flight (bounds the staging memory)
+                        pending.pop(0).result()
+                prev = cur
+        if multi and prev is not None:
+            pending.append(post_exchange(prev))
+        for h in pending:
             h.result()
+
+    run(args.warmup)
     fence()
+    exchanged["records"] = exchanged["bytes"] = 0
     # kernel time with HIP events on the stream the kernel is launched on (torch's current stream)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    pending = []
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        if not multi:
-            ev[i][0].record(stream)
-            hot_path()
-            ev[i][1].record(stream)
-            continue
-        ev[i][0].record(stream)
-        for lo, hi in bounds:
-            hot_path(lo, hi)
-            pending += mdist.gather_tracks_async((d_nout[lo:hi], d_xyz[lo:hi], d_err[lo:hi], d_corr[lo:hi]), dst=0)
-            while len(pending) > 2 * SUB * 4:   # at most two steps' exchanges in flight (bounds the staging memory)
-                pending.pop(0).result()
-        ev[i][1].record(stream)
-    for h in pending:
-        h.result()
+    run(args.steps, ev)
     fence()
     elapsed = time.perf_counter() - t0
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
@@ -533,7 +535,11 @@ def main():
                        "frames_per_gpu": F, "cams": C, "markers": M, "K_max": K_MAX, "gate_px": gate,
                        "parallelism": f"frame-shard x{world}", "frames_per_s": F * world * args.steps / t_max,
                        "markers_per_frame": total_markers / (F * world),
-                       "candidates_per_frame": float(n_cand.mean()), "overflow_frames": int(allv[:, 2].sum())},
+                       "candidates_per_frame": float(n_cand.mean()), "overflow_frames": int(allv[:, 2].sum()),
+                       "exchange": ({"format": "compact records (32 + 2C bytes per valid point) + n_out per frame, count-first "
+                                               "point-to-point gather on rank 0",
+                                     "bytes_per_rank_per_step": exchanged["bytes"] / max(args.steps, 1),
+                                     "padded_format_bytes_per_step": F * (4 + K_MAX * (32 + 2 * C))} if multi else None)},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": measured_traffic(F) if default_wl else None,
                          "traffic_source": "profiles/r01_hbm_traffic.json (rocprofv3 PMC, per frame x frames)",

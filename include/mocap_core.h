@@ -229,6 +229,20 @@ int mocap_initial_poses(mocap_ctx* ctx, int C, int64_t N, const double* obs, con
 int mocap_find_fundamental(mocap_ctx* ctx, int64_t n, const float* p1, const float* p2, double threshold,
                            double confidence, int max_iters, double* F, uint8_t* mask, int32_t* info);
 
+/* ---------------------------------------------------------------- exchange payload (multi-GPU gather)
+ * The frame path's outputs are fixed-capacity ([F][K_max] slots).  For the one exchange of a frame-sharded run
+ * (final tracks -> the gathering rank over RCCL/xGMI) only the valid slots need to travel:
+ * mocap_compact_tracks_dev packs them, in frame order, into records of mocap_track_record_bytes(C) bytes
+ *     { xyz f64[3] | err f64 | corr i16[C] | zero pad to a multiple of 8 }
+ * and writes the exclusive prefix sum of n_out: offsets[f] = first record of frame f, offsets[F] = number of
+ * records (also to *d_total when given -- e.g. pinned host memory, so the host learns the payload size without
+ * a separate copy).  Records beyond `capacity` are dropped (offsets still count them).  All pointers are DEVICE
+ * pointers (d_total: device-accessible); enqueued on the context's stream. */
+int mocap_track_record_bytes(int C);
+int mocap_compact_tracks_dev(mocap_ctx* ctx, int64_t n_frames, int K_max, const int32_t* d_n_out,
+                             const double* d_xyz, const double* d_err, const int16_t* d_corr,
+                             int64_t* d_offsets, void* d_records, int64_t capacity, int64_t* d_total);
+
 /* ---------------------------------------------------------------- bundle adjustment
  * Parameter vector as the reference (helpers.py:278-285):
  *   x = [f0, (f_i, rotvec_i[3], t_i[3]) for i = 1..C-1],  n = 1 + 7 (C-1); camera 0 = (I, 0).

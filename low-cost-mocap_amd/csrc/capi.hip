@@ -98,6 +98,7 @@ extern "C" void mocap_destroy(mocap_ctx* ctx) {
   ctx->tables.release();
   for (auto& b : ctx->scratch) b.release();
   ctx->ba_fused.release();
+  ctx->compact_ws.release();
   ctx->frame_ws.release();
   if (ctx->live_pin) (void)hipHostFree(ctx->live_pin);
   if (ctx->live_event) (void)hipEventDestroy(ctx->live_event);
@@ -636,6 +637,39 @@ static int locate_dev_locked(mocap_ctx* ctx, int64_t n_frames, int K_max, const 
   a.obj_lead = d_lead;
   a.n_obj = d_n_obj;
   HIP_TRY(ctx, launch_locate_objects(a, ctx->stream));
+  return MOCAP_OK;
+}
+
+extern "C" int mocap_track_record_bytes(int C) { return C < 1 ? 0 : (32 + 2 * C + 7) / 8 * 8; }
+
+extern "C" int mocap_compact_tracks_dev(mocap_ctx* ctx, int64_t n_frames, int K_max, const int32_t* d_n_out,
+                                        const double* d_xyz, const double* d_err, const int16_t* d_corr,
+                                        int64_t* d_offsets, void* d_records, int64_t capacity, int64_t* d_total) {
+  if (!ctx) return MOCAP_E_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (!ctx->C) return ctx->fail(MOCAP_E_NOCAMS, "mocap_set_cameras has not been called");
+  if (n_frames < 0 || K_max < 1 || capacity < 0) return ctx->fail(MOCAP_E_ARG, "mocap_compact_tracks: bad size argument");
+  if (n_frames == 0) return MOCAP_OK;
+  if (!d_n_out || !d_xyz || !d_err || !d_corr || !d_offsets || (!d_records && capacity > 0))
+    return ctx->fail(MOCAP_E_ARG, "mocap_compact_tracks: null buffer");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const size_t n_blocks = (size_t)((n_frames + 1023) / 1024);
+  if (ctx->compact_ws.reserve(sizeof(int64_t) * n_blocks)) return ctx->fail(MOCAP_E_HIP, "hipMalloc(scan workspace) failed");
+  CompactArgs a;
+  a.n_frames = n_frames;
+  a.K_max = K_max;
+  a.C = ctx->C;
+  a.stride = mocap_track_record_bytes(ctx->C);
+  a.n_out = d_n_out;
+  a.xyz = d_xyz;
+  a.err = d_err;
+  a.corr = d_corr;
+  a.offsets = d_offsets;
+  a.block_sums = (int64_t*)ctx->compact_ws.ptr;
+  a.records = (unsigned char*)d_records;
+  a.capacity = capacity;
+  a.total = d_total;
+  HIP_TRY(ctx, launch_compact_tracks(a, ctx->stream));
   return MOCAP_OK;
 }
 

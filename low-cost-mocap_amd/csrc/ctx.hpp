@@ -53,6 +53,7 @@ struct mocap_ctx {
   DevBuf img_map, img_rot, img_mask, img_stage, img_tiles, img_lens, img_sq, img_act, img_box, img_zero;
   int blob_skip_dark = 1;     // exact early-out for tiles whose source bytes span a range <= 2 (mocap_set_blob_options)
   int64_t img_sq_images = 0;  // squared frames the workspace holds (zero frame already set)
+  DevBuf compact_ws;        // block totals of the track-compaction scan
   DevBuf frame_ws;          // wide-frame workspace: [workgroup][hit lists | group columns | ...]
   DevBuf scratch[4];        // [0] host-API staging, [1..3] bundle adjustment workspace
 

@@ -75,6 +75,22 @@ struct LocateArgs {
 };
 hipError_t launch_locate_objects(const LocateArgs& a, hipStream_t stream);
 
+// compaction of a frame batch's valid points into fixed-stride records (the payload of the multi-GPU exchange)
+struct CompactArgs {
+  int64_t n_frames;
+  int K_max, C, stride;     // stride = mocap_track_record_bytes(C)
+  const int32_t* n_out;     // [F]
+  const double* xyz;        // [F][K_max][3]
+  const double* err;        // [F][K_max]
+  const int16_t* corr;      // [F][K_max][C]
+  int64_t* offsets;         // [F + 1] out: first record of every frame, total at [F]
+  int64_t* block_sums;      // [ceil(F / 1024)] scratch
+  unsigned char* records;   // [capacity][stride] out
+  int64_t capacity;
+  int64_t* total;           // null, or [1] out (e.g. pinned host memory)
+};
+hipError_t launch_compact_tracks(const CompactArgs& a, hipStream_t stream);
+
 // blob extraction, the step before the frame path (reference helpers.py:68-82, 143-163), csrc/blob_kernels.hip
 constexpr int BLOB_ST_POINT_OVERFLOW_ = 1;  // more centroids than M_max: the first M_max are kept
 constexpr int BLOB_ST_CAP_OVERFLOW_ = 2;    // more border pairs / contours than the workgroup's tables hold

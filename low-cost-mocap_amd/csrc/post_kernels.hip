@@ -84,4 +84,106 @@ hipError_t launch_locate_objects(const LocateArgs& a, hipStream_t stream) {
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------- track compaction for the exchange step
+// The frame kernel writes fixed-capacity outputs ([F][K_max] slots, n_out of them valid): fine for consumers on
+// the same GPU, twice the bytes the valid points need when a frame shard's results travel to the gathering rank
+// (RCCL over xGMI).  compact = exclusive prefix sum over n_out (per-block scan, scan of the block
+// totals, add) + one lane per (frame, slot) copying the valid slots into fixed-stride
+// records  { xyz 3 x f64 | err f64 | corr C x i16 | pad to 8 }  in frame order.
+constexpr int kScanBlock = 1024;
+
+__global__ __launch_bounds__(kScanBlock) void compact_scan_blocks_kernel(CompactArgs a) {
+  __shared__ int64_t sh[kScanBlock / 64];
+  const int64_t f = (int64_t)blockIdx.x * kScanBlock + threadIdx.x;
+  int64_t v = 0;
+  if (f < a.n_frames) {
+    const int n = a.n_out[f];
+    v = n < 0 ? 0 : (n > a.K_max ? a.K_max : n);
+  }
+  // inclusive scan inside the wave, then across the block's 16 waves
+  int64_t x = v;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int o = 1; o < 64; o <<= 1) {
+    const int64_t y = __shfl_up(x, o);
+    if (lane >= o) x += y;
+  }
+  if (lane == 63) sh[wave] = x;
+  __syncthreads();
+  int64_t base = 0;
+  for (int w = 0; w < wave; w++) base += sh[w];
+  if (f < a.n_frames) a.offsets[f] = base + x - v;  // exclusive, relative to the block
+  if (threadIdx.x == kScanBlock - 1) a.block_sums[blockIdx.x] = base + x;
+}
+
+__global__ __launch_bounds__(kScanBlock) void compact_scan_totals_kernel(CompactArgs a, int n_blocks) {
+  // one workgroup: exclusive scan of the block totals in place (n_blocks is a few hundred at most per pass)
+  __shared__ int64_t sh[kScanBlock / 64];
+  __shared__ int64_t carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int b0 = 0; b0 < n_blocks; b0 += kScanBlock) {
+    const int b = b0 + threadIdx.x;
+    const int64_t v = b < n_blocks ? a.block_sums[b] : 0;
+    int64_t x = v;
+    for (int o = 1; o < 64; o <<= 1) {
+      const int64_t y = __shfl_up(x, o);
+      if (lane >= o) x += y;
+    }
+    if (lane == 63) sh[wave] = x;
+    __syncthreads();
+    int64_t base = carry;
+    for (int w = 0; w < wave; w++) base += sh[w];
+    if (b < n_blocks) a.block_sums[b] = base + x - v;
+    __syncthreads();
+    if (threadIdx.x == kScanBlock - 1) carry = base + x;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    a.offsets[a.n_frames] = carry;  // total number of records
+    if (a.total) *a.total = carry;
+  }
+}
+
+__global__ __launch_bounds__(256) void compact_add_block_offsets_kernel(CompactArgs a) {
+  const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (f < a.n_frames) a.offsets[f] += a.block_sums[f / kScanBlock];
+}
+
+__global__ __launch_bounds__(256) void compact_scatter_kernel(CompactArgs a) {
+  // one lane per (frame, slot); a lane writes its whole record
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t f = idx / a.K_max;
+  const int k = (int)(idx - f * a.K_max);
+  if (f >= a.n_frames) return;
+  int n = a.n_out[f];
+  n = n < 0 ? 0 : (n > a.K_max ? a.K_max : n);
+  const int64_t off = a.offsets[f];
+  if (k >= n) return;
+  const int64_t rec = off + k;
+  if (rec >= a.capacity) return;
+  unsigned char* dst = a.records + (size_t)rec * a.stride;
+  const size_t o = (size_t)f * a.K_max + k;
+  double* d = (double*)dst;
+  d[0] = a.xyz[o * 3 + 0];
+  d[1] = a.xyz[o * 3 + 1];
+  d[2] = a.xyz[o * 3 + 2];
+  d[3] = a.err[o];
+  int16_t* c = (int16_t*)(dst + 32);
+  const int16_t* src = a.corr + o * a.C;
+  for (int j = 0; j < a.C; j++) c[j] = src[j];
+  for (int j = a.C; j < (a.stride - 32) / 2; j++) c[j] = 0;
+}
+
+hipError_t launch_compact_tracks(const CompactArgs& a, hipStream_t stream) {
+  if (a.n_frames <= 0) return hipSuccess;
+  const int n_blocks = (int)((a.n_frames + kScanBlock - 1) / kScanBlock);
+  hipLaunchKernelGGL(compact_scan_blocks_kernel, dim3(n_blocks), dim3(kScanBlock), 0, stream, a);
+  hipLaunchKernelGGL(compact_scan_totals_kernel, dim3(1), dim3(kScanBlock), 0, stream, a, n_blocks);
+  hipLaunchKernelGGL(compact_add_block_offsets_kernel, dim3((unsigned)((a.n_frames + 255) / 256)), dim3(256), 0, stream, a);
+  const int64_t lanes = a.n_frames * a.K_max;
+  hipLaunchKernelGGL(compact_scatter_kernel, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, stream, a);
+  return hipGetLastError();
+}
+
 }  // namespace mocap

@@ -59,6 +59,8 @@ SIGNATURES = {
     "mocap_ba_residuals": (_i32, [_vp, _i32, _vp, _i64, _vp, _vp]),
     "mocap_ba_normal_eq": (_i32, [_vp, _vp, _i64, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "mocap_ba_trust_region_step": (_i32, [_vp, _i32, _i64, _vp, _vp, _dbl, _vp, _i32, _vp, _vp]),
+    "mocap_track_record_bytes": (_i32, [_i32]),
+    "mocap_compact_tracks_dev": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "mocap_reproject": (_i32, [_vp, _i64, _vp, _vp, _vp]),
     "mocap_set_ba_progress": (_i32, [_vp, _vp, _vp]),
     "mocap_ba_profile": (_i32, [_vp, _vp, _i64, _vp, _i32, _i32, _i32, _vp]),
@@ -300,6 +302,12 @@ class MocapCore:
         self._check(self.lib.mocap_match_triangulate_dev(
             self._h, int(n_frames), int(M_max), _vp(d_blobs), _vp(d_counts), float(gate_px), int(K_max),
             int(G_cap), _vp(d_xyz), _vp(d_err), _vp(d_corr), _vp(d_n_out), _vp(d_status), _vp(d_n_cand or 0)))
+
+    def compact_tracks_dev(self, n_frames, K_max, d_n_out, d_xyz, d_err, d_corr, d_offsets, d_records, capacity, d_total=0):
+        """Valid points of a frame batch -> fixed-stride records + exclusive prefix of n_out (device pointers)."""
+        self._check(self.lib.mocap_compact_tracks_dev(self._h, int(n_frames), int(K_max), _vp(d_n_out), _vp(d_xyz), _vp(d_err),
+                                                      _vp(d_corr), _vp(d_offsets), _vp(d_records or 0), int(capacity),
+                                                      _vp(d_total or 0)))
 
     def triangulate_dev(self, N, d_obs, d_xyz, d_err):
         self._check(self.lib.mocap_triangulate_dev(self._h, int(N), _vp(d_obs), _vp(d_xyz), _vp(d_err or 0)))

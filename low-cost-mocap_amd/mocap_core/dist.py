@@ -7,11 +7,15 @@ exchange is the final gather of fixed-stride track records to rank 0 -- one coll
 one packed byte tensor (RCCL over xGMI on the GPU box: 7 point-to-point links into the root;
 gloo in the CPU tests).
 
-Record layout per frame (bytes, little endian), K = K_max:
-    n_out  int32   [1]  (+4 pad)
-    xyz    float64 [K][3]
-    err    float64 [K]
-    corr   int16   [K][C]   (padded to 8 bytes)
+Two payload formats:
+  * fixed capacity (pack_records / gather_tracks_async): every frame ships K_max slots --
+        n_out int32 [1] (+4 pad) | xyz float64 [K][3] | err float64 [K] | corr int16 [K][C] (padded to 8 bytes)
+    2.3 KB per 8 x 16 frame at K_max = 48, of which 23 slots are valid on average;
+  * compact (compact_tracks / gather_compact_async, what bench.py uses at N > 1): only the valid points travel,
+    as records of track_record_bytes(C) = 32 + 2 C bytes (padded to 8) in frame order, plus n_out int32 per frame:
+    1.1 KB per frame.  The records are produced on the device by mocap_compact_tracks_dev (prefix sum over n_out
+    + scatter); shard sizes differ, so the exchange is count-first: an all-gather of one int64 per rank, then
+    point-to-point transfers of exactly the valid bytes into the root (7 xGMI links, no ring).
 """
 import os
 
@@ -149,3 +153,132 @@ def gather_tracks_async(tensors, dst=0):
         flat = t.contiguous().reshape(t.shape[0], -1)
         out.append(gather_records_async(flat.view(torch.uint8), dst=dst))
     return out
+
+
+# ----------------------------------------------------------------------------- compact exchange
+def track_record_bytes(C):
+    """= mocap_track_record_bytes(C): xyz 24 | err 8 | corr 2 C | pad to a multiple of 8."""
+    return (32 + 2 * int(C) + 7) // 8 * 8
+
+
+def compact_tracks_reference(n_out, xyz, err, corr):
+    """Host restatement of mocap_compact_tracks_dev for tests and CPU-only runs (gloo): numpy arrays in,
+    (records uint8 [P][stride], offsets int64 [F + 1]) out."""
+    n_out = np.asarray(n_out)
+    F, K = err.shape
+    C = corr.shape[2]
+    stride = track_record_bytes(C)
+    n = np.clip(n_out, 0, K).astype(np.int64)
+    offsets = np.zeros(F + 1, dtype=np.int64)
+    np.cumsum(n, out=offsets[1:])
+    valid = np.arange(K)[None, :] < n[:, None]
+    P = int(offsets[-1])
+    rec = np.zeros((P, stride), dtype=np.uint8)
+    rec[:, 0:24] = np.ascontiguousarray(xyz[valid]).view(np.uint8).reshape(P, 24)
+    rec[:, 24:32] = np.ascontiguousarray(err[valid]).view(np.uint8).reshape(P, 8)
+    rec[:, 32:32 + 2 * C] = np.ascontiguousarray(corr[valid]).view(np.uint8).reshape(P, 2 * C)
+    return rec, offsets
+
+
+def unpack_compact(n_out, records, C, K_max, fill=np.nan):
+    """Inverse of the compaction on the gathering side: n_out [F], records uint8 [P][stride] -> the dense arrays of
+    the fixed-capacity layout (unused slots = fill / -1)."""
+    n_out = np.asarray(n_out).astype(np.int64)
+    F = n_out.shape[0]
+    rec = np.ascontiguousarray(np.asarray(records)).reshape(-1, track_record_bytes(C))
+    n = np.clip(n_out, 0, K_max)
+    valid = np.arange(K_max)[None, :] < n[:, None]
+    assert int(n.sum()) == rec.shape[0], (int(n.sum()), rec.shape)
+    xyz = np.full((F, K_max, 3), fill)
+    err = np.full((F, K_max), fill)
+    corr = np.full((F, K_max, C), -1, dtype=np.int16)
+    xyz[valid] = rec[:, 0:24].copy().view(np.float64).reshape(-1, 3)
+    err[valid] = rec[:, 24:32].copy().view(np.float64).reshape(-1)
+    corr[valid] = rec[:, 32:32 + 2 * C].copy().view(np.int16).reshape(-1, C)
+    return {"n_out": n_out.astype(np.int32), "xyz": xyz, "err": err, "corr": corr}
+
+
+class TrackCompactor:
+    """Device buffers + launch of mocap_compact_tracks_dev for one shard (reused from step to step).
+    compact() enqueues on the core's stream and returns immediately; count() is the number of records of the LAST
+    compact() and waits for it (the kernel drops the count into pinned host memory)."""
+
+    def __init__(self, core, F, K_max, C, device, n_buffers=2):
+        import torch
+        self.core, self.F, self.K, self.C = core, int(F), int(K_max), int(C)
+        self.stride = track_record_bytes(C)
+        self.records = [torch.empty((self.F * self.K, self.stride), dtype=torch.uint8, device=device) for _ in range(n_buffers)]
+        self.offsets = [torch.empty(self.F + 1, dtype=torch.int64, device=device) for _ in range(n_buffers)]
+        self.n_out = [torch.empty(self.F, dtype=torch.int32, device=device) for _ in range(n_buffers)]
+        self.totals = [torch.zeros(1, dtype=torch.int64).pin_memory() for _ in range(n_buffers)]
+        self.events = [torch.cuda.Event() for _ in range(n_buffers)]
+        self._i = -1
+
+    def compact(self, n_out, xyz, err, corr, stream):
+        self._i = (self._i + 1) % len(self.records)
+        i = self._i
+        self.core.compact_tracks_dev(self.F, self.K, n_out.data_ptr(), xyz.data_ptr(), err.data_ptr(), corr.data_ptr(),
+                                     self.offsets[i].data_ptr(), self.records[i].data_ptr(), self.F * self.K,
+                                     self.totals[i].data_ptr())
+        self.n_out[i].copy_(n_out, non_blocking=True)     # the next step's kernel rewrites n_out while this one travels
+        self.events[i].record(stream)
+        return i
+
+    def count(self, i):
+        self.events[i].synchronize()
+        return int(self.totals[i][0])
+
+
+class PendingCompactGather:
+    """In-flight compact exchange.  result() on `dst`: (n_out int32 [sum F_r] tensor, records uint8 [sum P_r][stride]
+    tensor) in rank order; None elsewhere."""
+
+    def __init__(self, works, n_parts, r_parts, is_dst):
+        self._works, self._n, self._r, self._is_dst = works, n_parts, r_parts, is_dst
+
+    def result(self):
+        import torch
+        for w in self._works:
+            w.wait()
+        self._works = []
+        if not self._is_dst:
+            return None
+        return torch.cat(self._n), torch.cat(self._r)
+
+
+def gather_compact_async(n_out, records, n_records, frames_per_rank, dst=0):
+    """The one exchange of the path in its compact form.  n_out: this shard's int32 [F_r]; records: uint8
+    [>= n_records][stride] (only the first n_records rows travel); frames_per_rank: F_r of every rank (static,
+    from shard_bounds).  Count-first: an all-gather of one int64 per rank tells the root how many records each
+    shard holds, then every rank sends exactly its valid bytes point to point."""
+    import torch
+    import torch.distributed as dist
+    rec = records[:n_records]
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return PendingCompactGather([], [n_out], [rec], True)
+    world, rank = dist.get_world_size(), dist.get_rank()
+    mine = torch.tensor([int(n_records)], dtype=torch.int64, device=n_out.device)
+    counts = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(counts, mine)
+    counts = [int(c.item()) for c in counts]
+    stride = records.shape[1]
+    ops, n_parts, r_parts = [], [], []
+    if rank == dst:
+        for r in range(world):
+            if r == dst:
+                n_parts.append(n_out)
+                r_parts.append(rec)
+                continue
+            nb = torch.empty(int(frames_per_rank[r]), dtype=torch.int32, device=n_out.device)
+            rb = torch.empty((counts[r], stride), dtype=torch.uint8, device=n_out.device)
+            n_parts.append(nb)
+            r_parts.append(rb)
+            ops.append(dist.P2POp(dist.irecv, nb.view(torch.uint8), r))
+            if counts[r]:
+                ops.append(dist.P2POp(dist.irecv, rb, r))
+    else:
+        ops.append(dist.P2POp(dist.isend, n_out.contiguous().view(torch.uint8), dst))
+        if n_records:
+            ops.append(dist.P2POp(dist.isend, rec.contiguous(), dst))
+    works = dist.batch_isend_irecv(ops) if ops else []
+    return PendingCompactGather(list(works), n_parts, r_parts, rank == dst)

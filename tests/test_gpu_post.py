@@ -113,3 +113,93 @@ def test_rccl_gather_api_world1():
         dist.barrier()
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("F,K,C", [(1, 4, 2), (700, 16, 4), (1024, 8, 3), (5000, 48, 8)])
+def test_compaction_kernel_matches_reference(core, F, K, C):
+    """mocap_compact_tracks_dev (exclusive prefix sum over n_out + scatter into 32 + 2C-byte records) against its
+    host restatement mocap_core.dist.compact_tracks_reference: offsets, total, every record byte.  Sizes cross the
+    1 024-frame scan block, include empty frames, frames at full capacity and out-of-range counts (clamped)."""
+    import torch
+    from mocap_core import dist as mdist, synth
+    rig = synth.ring_rig(C)
+    core.set_cameras(rig["K"], rig["R"], rig["t"])
+    rng = np.random.default_rng(F)
+    n_out = rng.integers(0, K + 1, F).astype(np.int32)
+    n_out[rng.random(F) < 0.2] = 0
+    if F > 10:
+        n_out[3], n_out[7] = K + 5, -2          # defensive clamps: [0, K]
+    xyz, err = rng.normal(size=(F, K, 3)), rng.random((F, K))
+    corr = rng.integers(-1, 16, (F, K, C)).astype(np.int16)
+    dev = torch.device("cuda", 0)
+    d = [torch.from_numpy(a).to(dev) for a in (n_out, xyz, err, corr)]
+    stride = mdist.track_record_bytes(C)
+    d_off = torch.full((F + 1,), -1, dtype=torch.int64, device=dev)
+    d_rec = torch.full((F * K, stride), 0xAB, dtype=torch.uint8, device=dev)
+    total = torch.zeros(1, dtype=torch.int64).pin_memory()
+    torch.cuda.synchronize()
+    core.compact_tracks_dev(F, K, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), d_off.data_ptr(),
+                            d_rec.data_ptr(), F * K, total.data_ptr())
+    core.synchronize()
+    rec_ref, off_ref = mdist.compact_tracks_reference(n_out, xyz, err, corr)
+    assert int(total[0]) == int(off_ref[-1])
+    assert np.array_equal(d_off.cpu().numpy(), off_ref)
+    assert np.array_equal(d_rec.cpu().numpy()[:rec_ref.shape[0]], rec_ref)
+    assert (d_rec.cpu().numpy()[rec_ref.shape[0]:] == 0xAB).all()         # nothing written past the last record
+    back = mdist.unpack_compact(n_out, d_rec.cpu().numpy()[:rec_ref.shape[0]], C, K)
+    valid = np.arange(K)[None, :] < np.clip(n_out, 0, K)[:, None]
+    assert np.array_equal(back["xyz"][valid], xyz[valid]) and np.array_equal(back["corr"][valid], corr[valid])
+
+
+def test_compact_exchange_through_rccl_world1(core):
+    """TrackCompactor + gather_compact_async through the real RCCL backend on the frame kernel's own outputs (world
+    size 1 is all a 1-GPU box offers; the N > 1 protocol is the gloo world-2 test in test_host_cpu.py)."""
+    import os
+    import socket
+    import torch
+    import torch.distributed as dist
+    from mocap_core import dist as mdist, synth
+    C, M, F, K = 4, 4, 300, 16
+    rig = synth.ring_rig(C)
+    blobs, counts, _ = synth.make_blob_stream(rig, F, M, seed=12)
+    core.set_cameras(rig["K"], rig["R"], rig["t"])
+    ref = core.match_triangulate(blobs, counts, K_max=K)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        stream = torch.cuda.current_stream(dev)
+        core.set_stream(stream.cuda_stream)
+        d_blobs, d_counts = torch.from_numpy(blobs).to(dev), torch.from_numpy(counts).to(dev)
+        d_xyz = torch.empty((F, K, 3), dtype=torch.float64, device=dev)
+        d_err = torch.empty((F, K), dtype=torch.float64, device=dev)
+        d_corr = torch.empty((F, K, C), dtype=torch.int16, device=dev)
+        d_n = torch.zeros(F, dtype=torch.int32, device=dev)
+        d_st = torch.zeros(F, dtype=torch.int32, device=dev)
+        comp = mdist.TrackCompactor(core, F, K, C, dev)
+        for _ in range(3):                       # buffers rotate
+            core.match_triangulate_dev(F, M, d_blobs.data_ptr(), d_counts.data_ptr(), 5.0, K, 1 << 20, d_xyz.data_ptr(),
+                                       d_err.data_ptr(), d_corr.data_ptr(), d_n.data_ptr(), d_st.data_ptr())
+            i = comp.compact(d_n, d_xyz, d_err, d_corr, stream)
+            n = comp.count(i)
+            assert n == int(ref["n_out"].sum())
+            n_all, r_all = mdist.gather_compact_async(comp.n_out[i], comp.records[i], n, [F], dst=0).result()
+            got = mdist.unpack_compact(n_all.cpu().numpy(), r_all.cpu().numpy(), C, K)
+            valid = np.arange(K)[None, :] < ref["n_out"][:, None]
+            assert np.array_equal(got["n_out"], ref["n_out"])
+            for key in ("xyz", "err", "corr"):
+                assert np.array_equal(got[key][valid], ref[key][valid])
+        # the collective calls RCCL itself must accept at N > 1: one int64 all-gather + batched isend / irecv
+        mine = torch.tensor([n], dtype=torch.int64, device=dev)
+        outl = [torch.zeros_like(mine)]
+        dist.all_gather(outl, mine)
+        assert int(outl[0].item()) == n
+        dist.barrier()
+    finally:
+        core.set_stream(0)
+        dist.destroy_process_group()

@@ -119,39 +119,62 @@ def _worker(rank, world, port, out_path):
     from mocap_core import dist as mdist, synth
     from oracle import c_oracle
     mdist.init_process_group(backend="gloo")
-    C, M, F, K = 4, 4, 64, 16
+    C, M, F, K = 4, 4, 65, 16                 # 65 frames over 2 ranks: uneven shards (33 + 32)
     rig = synth.ring_rig(C)
     blobs, counts, _ = synth.make_blob_stream(rig, F, M, seed=9)
     lo, hi = mdist.shard_bounds(F, rank, world)
+    frames_per_rank = [b - a for a, b in (mdist.shard_bounds(F, r, world) for r in range(world))]
     # the per-rank compute is the GPU core in production; here (no GPU) the oracle stands in for it
     res = c_oracle.COracle(rig["K"], rig["R"], rig["t"]).match_triangulate(blobs[lo:hi], counts[lo:hi], K_max=K)
-    rec = mdist.pack_records(torch.from_numpy(res["n_out"]), torch.from_numpy(res["xyz"]),
-                             torch.from_numpy(res["err"]), torch.from_numpy(res["corr"]))
+    # ---- compact exchange (what bench.py runs at N > 1): valid records only, count-first point-to-point gather.
+    # mocap_compact_tracks_dev produces the records on the GPU; its host restatement stands in here (the GPU test
+    # test_compaction_kernel_matches_reference pins the two against each other).
+    rec_np, offsets = mdist.compact_tracks_reference(res["n_out"], res["xyz"], res["err"], res["corr"])
+    cap = torch.zeros((res["err"].size, mdist.track_record_bytes(C)), dtype=torch.uint8)   # capacity F_r * K
+    cap[:rec_np.shape[0]] = torch.from_numpy(rec_np)
+    n_t = torch.from_numpy(res["n_out"].astype(np.int32))
+    handles = [mdist.gather_compact_async(n_t, cap, int(offsets[-1]), frames_per_rank, dst=0) for _ in range(2)]
+    compact = [h.result() for h in handles]
+    # ---- fixed-capacity formats (kept for callers that want them): packed records, per-array gathers
+    if hi - lo == max(frames_per_rank):
+        pad = 0
+    else:
+        pad = max(frames_per_rank) - (hi - lo)      # gather needs equal shapes: pad the short shard with empty frames
+    padded = {k: np.concatenate([v, np.zeros((pad,) + v.shape[1:], dtype=v.dtype)]) for k, v in res.items()
+              if k in ("n_out", "xyz", "err", "corr")}
+    rec = mdist.pack_records(torch.from_numpy(padded["n_out"]), torch.from_numpy(padded["xyz"]),
+                             torch.from_numpy(padded["err"]), torch.from_numpy(padded["corr"]))
     allrec = mdist.gather_records(rec, dst=0)
-    # the pipelined form bench.py uses: several exchanges in flight, completed later, same bytes
-    handles = [mdist.gather_records_async(rec.clone(), dst=0) for _ in range(3)]
-    later = [h.result() for h in handles]
-    # the form without the packing pass (bench.py at N > 1): one asynchronous gather per output array
-    arrays = (torch.from_numpy(res["n_out"]), torch.from_numpy(res["xyz"]), torch.from_numpy(res["err"]),
-              torch.from_numpy(res["corr"]))
+    later = [h.result() for h in [mdist.gather_records_async(rec.clone(), dst=0) for _ in range(2)]]
+    arrays = tuple(torch.from_numpy(padded[k]) for k in ("n_out", "xyz", "err", "corr"))
     parts = [h.result() for h in mdist.gather_tracks_async(arrays, dst=0)]
     if rank == 0:
-        got = mdist.unpack_records(allrec, C, K)
-        np.savez(out_path, **got)
+        n_all, r_all = compact[0]
+        assert all(torch.equal(n_all, c[0]) and torch.equal(r_all, c[1]) for c in compact)
+        assert n_all.shape[0] == F
+        got = mdist.unpack_compact(n_all.numpy(), r_all.numpy(), C, K)
+        np.savez(out_path, **got, payload_bytes=r_all.numel() + 4 * F, padded_bytes=allrec.numel())
+        # the fixed-capacity paths carry the same numbers (modulo the padding frames of the short shard)
+        keep = np.concatenate([np.arange(max(frames_per_rank) * r, max(frames_per_rank) * r + frames_per_rank[r])
+                               for r in range(world)])
+        fixed = mdist.unpack_records(allrec, C, K)
         assert all(torch.equal(x, allrec) for x in later)
+        valid = np.arange(K)[None, :] < got["n_out"][:, None]
+        assert np.array_equal(fixed["n_out"][keep], got["n_out"])
+        for key in ("xyz", "err", "corr"):
+            assert np.array_equal(fixed[key][keep][valid], got[key][valid])
         nF = allrec.shape[0]
-        assert np.array_equal(parts[0].numpy().view(np.int32).reshape(nF), got["n_out"])
-        assert np.array_equal(parts[1].numpy().view(np.float64).reshape(nF, K, 3), got["xyz"], equal_nan=True)
-        assert np.array_equal(parts[2].numpy().view(np.float64).reshape(nF, K), got["err"], equal_nan=True)
-        assert np.array_equal(parts[3].numpy().view(np.int16).reshape(nF, K, C), got["corr"])
+        assert np.array_equal(parts[0].numpy().view(np.int32).reshape(nF), fixed["n_out"])
+        assert np.array_equal(parts[3].numpy().view(np.int16).reshape(nF, K, C), fixed["corr"])
     else:
-        assert allrec is None and all(x is None for x in later) and all(x is None for x in parts)
+        assert all(c is None for c in compact) and allrec is None and all(x is None for x in later + parts)
     dist.barrier()
     dist.destroy_process_group()
 
 
 def test_frame_sharding_gloo_world2(tmp_path):
-    """N-rank output == 1-rank output, bit for bit, through the single gather."""
+    """N-rank output == 1-rank output, bit for bit, through the single exchange -- compact format (valid records
+    only), uneven shards (65 frames over 2 ranks)."""
     import torch.multiprocessing as mp
     from mocap_core import synth
     from oracle import c_oracle
@@ -159,12 +182,32 @@ def test_frame_sharding_gloo_world2(tmp_path):
     mp.start_processes(_worker, args=(2, _free_port(), out), nprocs=2, join=True, start_method="spawn")
     got = dict(np.load(out))
     rig = synth.ring_rig(4)
-    blobs, counts, _ = synth.make_blob_stream(rig, 64, 4, seed=9)
+    blobs, counts, _ = synth.make_blob_stream(rig, 65, 4, seed=9)
     ref = c_oracle.COracle(rig["K"], rig["R"], rig["t"]).match_triangulate(blobs, counts, K_max=16)
     assert np.array_equal(got["n_out"], ref["n_out"])
     valid = np.arange(16)[None, :] < ref["n_out"][:, None]
     for key in ("xyz", "err", "corr"):
         assert np.array_equal(got[key][valid], ref[key][valid])
+    assert got["payload_bytes"] < 0.6 * got["padded_bytes"]       # what the compaction is for
+
+
+def test_compact_records_roundtrip():
+    from mocap_core import dist as mdist
+    rng = np.random.default_rng(1)
+    F, K, C = 9, 7, 3
+    n_out = rng.integers(0, K + 1, F).astype(np.int32)
+    n_out[2] = 0
+    xyz, err = rng.normal(size=(F, K, 3)), rng.normal(size=(F, K))
+    corr = rng.integers(-1, 9, (F, K, C)).astype(np.int16)
+    rec, off = mdist.compact_tracks_reference(n_out, xyz, err, corr)
+    assert rec.shape == (int(n_out.sum()), mdist.track_record_bytes(C)) and off[-1] == n_out.sum()
+    assert np.array_equal(np.diff(off), n_out)
+    back = mdist.unpack_compact(n_out, rec, C, K)
+    valid = np.arange(K)[None, :] < n_out[:, None]
+    assert np.array_equal(back["n_out"], n_out)
+    for k, v in (("xyz", xyz), ("err", err), ("corr", corr)):
+        assert np.array_equal(back[k][valid], v[valid])
+    assert np.isnan(back["xyz"][~valid]).all() and (back["corr"][~valid] == -1).all()
 
 
 def test_record_pack_roundtrip():
