@@ -560,7 +560,7 @@ def main():
             # parity gate next to the number: a prefix of the very batch that was timed, vs the oracle
             from oracle import c_oracle
             nchk = 300
-            nchk = nchk if default_wl else min(F, 300 if C * M <= 64 else 4)
+            nchk = nchk if default_wl else min(F, 300 if C * M <= 64 else 64)
             ref = c_oracle.COracle(rig["K"], rig["R"], rig["t"]).match_triangulate(blobs[:nchk], counts[:nchk],
                                                                                    gate_px=gate, K_max=K_MAX)
             vv = valid[:nchk]
