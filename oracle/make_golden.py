@@ -348,6 +348,9 @@ def main():
         return main_pose()
     if "--ba-only" in sys.argv:
         return main_ba()
+    if "--with-cv2" in sys.argv:       # pin the OpenCV restatements against a REAL cv2, where one exists
+        from oracle import make_cv2_golden
+        return make_cv2_golden.main()
     main_blobs()
     main_pose()
     # BASELINE.json configs[0..2] shapes
