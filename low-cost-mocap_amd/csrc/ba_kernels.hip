@@ -525,7 +525,8 @@ __global__ __launch_bounds__(kFusedThreads) void ba_fused_kernel(BaFusedArgs a) 
   __syncthreads();
   if (a.debug_stop == 5) return;
   // ---- phase 3: partial Gram of the 64 rows, upper-triangle tiles round-robin over the waves
-  const int nt = NP / 16, ntiles = nt * (nt + 1) / 2;
+  const int nt = NP / 16;
+  const int tri_n = (n + 1) * (n + 2) / 2;  // packed upper triangle of G's leading block
   {
     int u = 0;
     for (int ti = 0; ti < nt; ti++)
@@ -537,9 +538,14 @@ __global__ __launch_bounds__(kFusedThreads) void ba_fused_kernel(BaFusedArgs a) 
 #pragma unroll 4
         for (int s4 = 0; s4 < 16; s4++)
           acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[(size_t)s4 * 4 * LD], pb[(size_t)s4 * 4 * LD], acc, 0, 0, 0);
-        double* out = a.partial + ((size_t)chunk * ntiles + u) * 256;
+        // only the upper triangle of the leading (n+1) x (n+1) block travels, packed row-major: a workgroup reads
+        // fresh cross-XCD lines at ~65 GB/s (guide: handoff-payload), so the last owner's sum is bandwidth-bound
+        double* out = a.partial + (size_t)chunk * tri_n;
 #pragma unroll
-        for (int r = 0; r < 4; r++) st_agent(&out[r * 64 + lane], acc[r]);
+        for (int r = 0; r < 4; r++) {
+          const int row = ti * 16 + (lane >> 4) + 4 * r, col = tj * 16 + (lane & 15);
+          if (row <= col && col <= n) st_agent(&out[row * (n + 1) - row * (row - 1) / 2 + (col - row)], acc[r]);
+        }
       }
   }
   if (a.debug_stop == 6) return;
@@ -552,48 +558,33 @@ __global__ __launch_bounds__(kFusedThreads) void ba_fused_kernel(BaFusedArgs a) 
   if (!sh_last) return;
   if (tid == 0) __hip_atomic_store(&a.counters[a.chunks], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (a.debug_stop == 7) return;
-  // ---- phase 4: G = sum of the chunks' partials in chunk order -> pinned host memory (upper triangle of
-  // the leading (n+1) x (n+1) block; the host mirrors it)
+  // ---- phase 4: G = sum of the chunks' partials in chunk order -> pinned host memory (packed upper triangle of
+  // the leading (n+1) x (n+1) block; the host unpacks and mirrors it)
   {
-    const int reg = (tid >> 6) & 3, slot = tid >> 8;  // 256 threads per tile, kFusedThreads / 256 tiles at a time
-    constexpr int kSlots = kFusedThreads / 256;
-    const size_t cs = (size_t)ntiles * 256;
     const double* __restrict__ part = a.partial;
     double* __restrict__ gout = a.out;
-    for (int u0 = slot; u0 < ntiles; u0 += 2 * kSlots) {  // two tiles x sixteen chunks = 32 loads in flight per thread
-      double sum[2] = {0.0, 0.0};
-      for (int k0 = 0; k0 < a.chunks; k0 += 16) {
-        double v[2][16];
+    constexpr int EPT = 4;  // packed elements per thread and round: 4 x 16 chunks = 64 loads in flight
+    for (int e0 = tid; e0 < tri_n; e0 += EPT * kFusedThreads) {
+      double sum[EPT];
 #pragma unroll
-        for (int t = 0; t < 2; t++)
+      for (int t = 0; t < EPT; t++) sum[t] = 0.0;
+      for (int k0 = 0; k0 < a.chunks; k0 += 16) {
+        double v[EPT][16];
+#pragma unroll
+        for (int t = 0; t < EPT; t++)
 #pragma unroll
           for (int q = 0; q < 16; q++)
-            v[t][q] = (u0 + t * kSlots < ntiles && k0 + q < a.chunks)
-                          ? ld_agent(&part[(size_t)(k0 + q) * cs + (size_t)(u0 + t * kSlots) * 256 + reg * 64 + lane]) : 0.0;
+            v[t][q] = (e0 + t * kFusedThreads < tri_n && k0 + q < a.chunks)
+                          ? ld_agent(&part[(size_t)(k0 + q) * tri_n + e0 + t * kFusedThreads]) : 0.0;
 #pragma unroll
-        for (int t = 0; t < 2; t++)
+        for (int t = 0; t < EPT; t++)
 #pragma unroll
           for (int q = 0; q < 16; q++)
             if (k0 + q < a.chunks) sum[t] += v[t][q];  // chunk order
       }
-      if (a.debug_stop == 8) {
-        if (sum[0] + sum[1] == 1.2345e-300) gout[0] = 0.0;
-        continue;
-      }
 #pragma unroll
-      for (int t = 0; t < 2; t++) {
-        const int u = u0 + t * kSlots;
-        if (u >= ntiles) break;
-        // tile index -> (ti, tj) of the upper triangle, row-major
-        int ti = 0, rem = u;
-        while (rem >= nt - ti) {
-          rem -= nt - ti;
-          ti++;
-        }
-        const int tj = ti + rem;
-        const int row = ti * 16 + (lane >> 4) + 4 * reg, col = tj * 16 + (lane & 15);
-        if (row <= col && col <= n) gout[(size_t)row * NP + col] = sum[t];
-      }
+      for (int t = 0; t < EPT; t++)
+        if (e0 + t * kFusedThreads < tri_n) gout[e0 + t * kFusedThreads] = sum[t];  // packed; the host unpacks
     }
     // cost: chunk sums added by 64 lanes with stride 64, then a fixed tree
     if (wave == 0) {
@@ -612,7 +603,6 @@ __global__ __launch_bounds__(kFusedThreads) void ba_fused_kernel(BaFusedArgs a) 
       }
     }
   }
-  if (a.debug_stop == 9) return;
   // every wave waits for its own stores (workgroup-scope release), one thread publishes to the host
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __syncthreads();

@@ -328,9 +328,8 @@ int ba_setup(mocap_ctx* ctx, BaWork& w, int64_t N, const double* obs, int Pmax, 
   if (w.fused) {
     w.chunks = (int)((N + 63) / 64);
     w.groups = ba_fused_groups(C);
-    const int nt = w.NP / 16, ntiles = nt * (nt + 1) / 2;
     const int owners = ba_fused_owners(w.chunks);
-    const size_t nd_fp = al((size_t)owners * ntiles * 256), nd_fc = al((size_t)owners * 2),
+    const size_t nd_fp = al((size_t)owners * ((size_t)(w.n + 1) * (w.n + 2) / 2)), nd_fc = al((size_t)owners * 2),
                  nd_cnt = al((size_t)(owners + 1) / 2 + 1), nd_fJ = want_jaug ? al((size_t)N * w.NP) : 0;
     if (ctx->ba_fused.reserve((nd_fp + nd_fc + nd_cnt + nd_fJ) * sizeof(double)))
       return ctx->fail(MOCAP_E_HIP, "hipMalloc(BA fused workspace) failed");
@@ -479,7 +478,7 @@ int ba_linearize_fused(mocap_ctx* ctx, BaWork& w, const double* x, int f32, int 
   G.assign(nG, 0.0);
   for (int i = 0; i <= n; i++)
     for (int j = i; j <= n; j++) {
-      const double v = w.h_fout[(size_t)i * NP + j];
+      const double v = w.h_fout[i * (n + 1) - i * (i - 1) / 2 + (j - i)];  // packed upper triangle, row-major
       G[(size_t)i * NP + j] = v;
       G[(size_t)j * NP + i] = v;
     }

@@ -202,11 +202,11 @@ struct BaFusedArgs {
   const double* K4;      // [j][4]
   const double* obs;     // [N][C][2]
   double* r;             // [n+1][N] residuals
-  double* partial;       // [chunks][tiles][256] upper-triangle Gram tiles per chunk
+  double* partial;       // [chunks][(n+1)(n+2)/2] packed upper triangle of each chunk's Gram matrix
   double* cost_part;     // [chunks][2] (sum of loss values, all-finite flag)
   int32_t* counters;     // [chunks + 1], zero on entry and on exit
   double* Jaug_out;      // null, or [N][NP]: the rows of Jaug by point index (tests)
-  double* out;           // pinned host memory [NP*NP + 3]: upper triangle of G | cost | finite | stamp
+  double* out;           // pinned host memory [NP*NP + 3]: packed upper triangle of G ... | cost | finite | stamp (last 3)
 };
 size_t ba_fused_lds_bytes(int C, int NP, bool uniformK);
 bool ba_fused_eligible(int C, int n, int NP, bool uniformK);
