@@ -86,7 +86,8 @@ extern "C" int mocap_create(int device_id, mocap_ctx** out) {
   if ((t = getenv("MOCAP_HEAVY_THRESHOLD"))) c->heavy_threshold = atoi(t);  // 0 disables splitting
   if ((t = getenv("MOCAP_SLICE_SIZE"))) c->slice_size = atoi(t);
   if ((t = getenv("MOCAP_FORCE_WIDE"))) c->force_wide = atoi(t) ? 1 : 0;
-  if ((t = getenv("MOCAP_PRUNE"))) c->prune = atoi(t) ? 1 : 0;  // 0: every group is reprojected in full (A/B)
+  if ((t = getenv("MOCAP_PRUNE"))) c->prune = atoi(t) ? 1 : 0;
+  if ((t = getenv("MOCAP_FRAME_LAUNCHES"))) c->frame_launches = atoi(t) == 3 ? 3 : 1;  // 3: main / slice / merge launches (A/B)  // 0: every group is reprojected in full (A/B)
   *out = c;
   return MOCAP_OK;
 }
@@ -502,6 +503,14 @@ static int match_dev_locked(mocap_ctx* ctx, int64_t n_frames, int M_max, const f
   q.part_x = (double*)w;
   HIP_TRY(ctx, hipMemsetAsync(q.counters, 0, b_cnt, ctx->stream));
   if (q.heavy_threshold) HIP_TRY(ctx, hipMemsetAsync(q.slice_heavy, 0xFF, b_slice, ctx->stream));
+  if (ctx->frame_launches != 3) {
+    // one launch: frames, then slices of the heavy frames, merged by the workgroup that finishes a frame's last slice.
+    // Few frames (live calls): still enough workgroups for a heavy frame's slices to run side by side.
+    int64_t g1 = n_frames + (q.heavy_threshold ? 64 : 0);
+    if (g1 > full_grid) g1 = full_grid;
+    HIP_TRY(ctx, launch_frame_kernel(a, MODE_ALL, T, (int)g1, ctx->stream));
+    return MOCAP_OK;
+  }
   HIP_TRY(ctx, launch_frame_kernel(a, MODE_MAIN, T, (int)grid, ctx->stream));
   if (q.heavy_threshold) {
     HIP_TRY(ctx, launch_frame_kernel(a, MODE_SLICE, T, (int)(full_grid < q.W_cap ? full_grid : q.W_cap), ctx->stream));

@@ -23,6 +23,7 @@ struct mocap_ctx {
   int slice_size = 0;       // 0 = automatic (MOCAP_SLICE_SIZE)
   int hit_cap = 16;         // wide frames: hits kept per (root, camera) (mocap_set_frame_limits)
   int force_wide = 0;       // route every frame batch through the wide (HBM workspace) variant
+  int frame_launches = 1;   // 1: one persistent launch per batch (MODE_ALL); 3: main / slice / merge launches
   int prune = 1;            // stop a candidate group's reprojection once it cannot beat its root's best (exact)
   hipStream_t own_stream = nullptr, stream = nullptr;
   std::mutex mu;            // one context = one serialised caller (include/mocap_core.h)

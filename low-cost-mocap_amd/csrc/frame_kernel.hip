@@ -32,6 +32,11 @@
 //               by construction) and evaluate only their slice, writing per-root partial winners;
 //   MODE_MERGE  one workgroup per heavy frame redoes A-C and picks, per root, the first minimum
 //               over the slices in slice order -> same result as the single-workgroup evaluation.
+// MODE_ALL (the default) is the same schedule in ONE launch: a workgroup pulls frames while there are any, then
+// takes slice tickets; a ticket whose slice has not been published yet waits for it (producers never wait, so
+// this cannot deadlock) until every frame has been matched; the workgroup that finishes the LAST slice of a heavy
+// frame merges the slices with the frame state it already holds in LDS (no third pass over phases A-C, no third
+// launch).  The three-launch form stays selectable (MOCAP_FRAME_LAUNCHES=3) for A/B runs; results are identical.
 #include "mocap_device.hpp"
 #include "kernels.hpp"
 
@@ -60,6 +65,15 @@ __device__ __forceinline__ void divmod_small(uint32_t rem, uint32_t n, uint32_t&
   }
   r = (uint32_t)rr;
 }
+
+// queue words shared between workgroups inside one launch (MODE_ALL): agent-scope relaxed accesses (sc1)
+__device__ __forceinline__ int q_load(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void q_store(int32_t* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int q_add(int32_t* p, int v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <class Tp>
+__device__ __forceinline__ Tp q_ld(const Tp* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <class Tp>
+__device__ __forceinline__ void q_st(Tp* p, Tp v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // per-root epipolar line record in LDS: a, b, c, sqrt(a^2+b^2), its reciprocal, pad
 constexpr int kLineStride = 6;
@@ -141,7 +155,7 @@ size_t frame_lds_bytes(int C, int M, int R, int T, int H, bool wide, bool table)
 size_t frame_ws_bytes(int C, int M, int R, int T, int H, bool wide, bool table) { return FrameLayout(C, M, R, T, H, wide, table && !wide).ws_total; }
 
 // misc[] slots
-enum { MI_NROOTS = 0, MI_STATUS = 1, MI_NOUT = 2, MI_G = 3, MI_ITEM = 4, MI_DEFER = 5 };
+enum { MI_NROOTS = 0, MI_STATUS = 1, MI_NOUT = 2, MI_G = 3, MI_ITEM = 4, MI_DEFER = 5, MI_KIND = 6 };
 
 template <int T, bool UNIFORM_K, bool F32R, bool WIDE>
 struct FrameState {
@@ -753,6 +767,146 @@ __global__ __launch_bounds__(T, MOCAP_FRAME_WAVES_PER_EU) void frame_kernel(Fram
   const int R = p.K_max;
 
   int chunk_next = 0, chunk_end = 0;  // lane 0 only: frames of the chunk it pulled last
+  if constexpr (MODE == MODE_ALL) {
+    bool frames_left = true;  // lane 0 only
+    while (true) {
+      // ---------------------------------------------------------- pull a frame, else a slice ticket
+      if (tid == 0) {
+        int item = -1, kind = 0;
+        if (frames_left) {
+          if (chunk_next >= chunk_end) {
+            chunk_next = q_add(&q.counters[QC_NEXT_FRAME], q.frame_chunk);
+            chunk_end = chunk_next + q.frame_chunk;
+          }
+          item = chunk_next++;
+          if (item >= p.n_frames) {
+            item = -1;
+            frames_left = false;
+          } else {
+            kind = 1;
+          }
+        }
+        if (!kind && q.heavy_threshold) {
+          const int s = q_add(&q.counters[QC_NEXT_SLICE], 1);
+          while (s < q.W_cap) {
+            if (q_load(&q.slice_heavy[s]) >= 0) {
+              kind = 2;
+              item = s;
+              break;
+            }
+            // a producer publishes its slices BEFORE it counts its frame as done: once every frame is done, an
+            // unpublished ticket will never be published (and neither will any later one)
+            if (q_load(&q.counters[QC_FRAMES_DONE]) >= (int)p.n_frames) {
+              if (q_load(&q.slice_heavy[s]) >= 0) {
+                kind = 2;
+                item = s;
+              }
+              break;
+            }
+            __builtin_amdgcn_s_sleep(8);
+          }
+        }
+        st.misc[MI_ITEM] = item;
+        st.misc[MI_KIND] = kind;
+      }
+      __syncthreads();
+      const int item = st.misc[MI_ITEM], kind = st.misc[MI_KIND];
+      __syncthreads();  // every lane has read the slots before lane 0 can overwrite them
+      if (!kind) break;
+      if (kind == 1) {
+        const int64_t frame = item;
+        st.match(frame);
+        const uint32_t G = (uint32_t)st.misc[MI_G];
+        if (tid == 0) {
+          int defer = 0;
+          if (q.heavy_threshold && G > q.heavy_threshold) {
+            uint32_t S = (G + q.slice_size - 1) / q.slice_size;
+            if (S > 64) S = 64;
+            const int h = q_add(&q.counters[QC_N_HEAVY], 1);
+            if (h < q.H_cap) {
+              const int base = q_add(&q.counters[QC_N_SLICES], (int)S);
+              if (base + (int)S <= q.W_cap) {
+                q_store(&q.heavy[4 * h + 0], (int32_t)frame);
+                q_store(&q.heavy[4 * h + 1], base);
+                q_store(&q.heavy[4 * h + 2], (int32_t)S);
+                q_store(&q.heavy[4 * h + 3], 0);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the entry is in memory before its tickets become valid
+                for (uint32_t s = 0; s < S; s++) q_store(&q.slice_heavy[base + s], h);
+                defer = 1;
+              }
+            }
+          }
+          st.misc[MI_DEFER] = defer;
+        }
+        __syncthreads();
+        st.write_frame_header(frame);  // n_out / status / n_cand are known after the match, whoever evaluates
+        if (!st.misc[MI_DEFER] && G) {
+          st.evaluate(0, G);
+          const int nroots = st.misc[MI_NROOTS];
+          for (int r = tid; r < nroots; r += T) {
+            if (st.outslot[r] < 0) continue;
+            double e, X[3];
+            uint32_t gl;
+            if (st.root_winner(r, 0, G, e, gl, X)) st.write_point(frame, r, e, gl, X);
+          }
+        }
+        __syncthreads();
+        if (tid == 0) {
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          q_add(&q.counters[QC_FRAMES_DONE], 1);
+        }
+      } else {
+        const int h = q_load(&q.slice_heavy[item]);
+        const int64_t frame = q_load(&q.heavy[4 * h + 0]);
+        const int base = q_load(&q.heavy[4 * h + 1]), S = q_load(&q.heavy[4 * h + 2]);
+        const int sl = item - base;
+        st.match(frame);
+        const uint64_t G = (uint32_t)st.misc[MI_G];
+        const uint32_t g_lo = (uint32_t)(G * (uint64_t)sl / S), g_hi = (uint32_t)(G * (uint64_t)(sl + 1) / S);
+        if (g_hi > g_lo) st.evaluate(g_lo, g_hi);
+        const int nroots = st.misc[MI_NROOTS];
+        for (int r = tid; r < nroots; r += T) {
+          const int k = st.outslot[r];
+          if (k < 0) continue;
+          double e = __longlong_as_double(0x7ff0000000000000ll), X[3] = {0, 0, 0};  // +inf: no candidate here
+          uint32_t gl = 0;
+          if (g_hi > g_lo) st.root_winner(r, g_lo, g_hi, e, gl, X);
+          const size_t o = (size_t)item * R + k;
+          q_st(&q.part_e[o], e);
+          q_st(&q.part_g[o], gl);
+          q_st(&q.part_x[3 * o + 0], X[0]);
+          q_st(&q.part_x[3 * o + 1], X[1]);
+          q_st(&q.part_x[3 * o + 2], X[2]);
+        }
+        // the workgroup that finishes a heavy frame's LAST slice merges them: it already holds the frame's roots, hit
+        // lists and output slots in LDS
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // every wave's partials have left the CU
+        __syncthreads();
+        if (tid == 0) st.misc[MI_DEFER] = q_add(&q.heavy[4 * h + 3], 1) == S - 1;
+        __syncthreads();
+        if (st.misc[MI_DEFER]) {
+          for (int r = tid; r < nroots; r += T) {
+            const int k = st.outslot[r];
+            if (k < 0) continue;
+            size_t ob = (size_t)base * R + k;
+            double eb = q_ld(&q.part_e[ob]);
+            for (int s = 1; s < S; s++) {
+              const size_t o = (size_t)(base + s) * R + k;
+              const double e = q_ld(&q.part_e[o]);
+              if (e < eb) {  // strict <: the earliest slice wins ties, slices ascend in candidate index
+                eb = e;
+                ob = o;
+              }
+            }
+            const double X[3] = {q_ld(&q.part_x[3 * ob + 0]), q_ld(&q.part_x[3 * ob + 1]), q_ld(&q.part_x[3 * ob + 2])};
+            st.write_point(frame, r, eb, q_ld(&q.part_g[ob]), X);
+          }
+        }
+        __syncthreads();
+      }
+    }
+    return;
+  }
   while (true) {
     // ------------------------------------------------------------ pull a work item
     if (tid == 0) {
@@ -902,7 +1056,8 @@ static hipError_t launch_T(const FrameArgs& a, int mode, int grid, size_t lds, h
   switch (mode) {
     case MODE_MAIN: return launch_TM<T, WIDE, MODE_MAIN>(a, grid, lds, stream);
     case MODE_SLICE: return launch_TM<T, WIDE, MODE_SLICE>(a, grid, lds, stream);
-    default: return launch_TM<T, WIDE, MODE_MERGE>(a, grid, lds, stream);
+    case MODE_MERGE: return launch_TM<T, WIDE, MODE_MERGE>(a, grid, lds, stream);
+    default: return launch_TM<T, WIDE, MODE_ALL>(a, grid, lds, stream);
   }
 }
 

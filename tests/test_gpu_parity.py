@@ -227,6 +227,32 @@ def test_scheduling_knobs_do_not_change_results(core):
                 assert np.array_equal(res[key], base[key]), (threads, thr, sl, key)
             for key in ("xyz", "err", "corr"):
                 assert np.array_equal(res[key][valid], base[key][valid]), (threads, thr, sl, key)
+        # the three-launch schedule (main / slice / merge passes) against the single persistent launch (default):
+        # another context, created under MOCAP_FRAME_LAUNCHES=3; also the live-call shape (one frame per call)
+        import os
+        from mocap_core import capi
+        os.environ["MOCAP_FRAME_LAUNCHES"] = "3"
+        try:
+            three = capi.MocapCore(0)
+        finally:
+            del os.environ["MOCAP_FRAME_LAUNCHES"]
+        three.set_cameras(rig["K"], rig["R"], rig["t"])
+        for thr, sl in [(-1, 0), (2048, 512)]:
+            three.set_tuning(0, thr, sl)
+            res = three.match_triangulate(blobs, counts, K_max=48)
+            for key in ("n_out", "status", "n_cand"):
+                assert np.array_equal(res[key], base[key]), ("three launches", thr, sl, key)
+            for key in ("xyz", "err", "corr"):
+                assert np.array_equal(res[key][valid], base[key][valid]), ("three launches", thr, sl, key)
+        three.close()
+        core.set_tuning(0, -1, 0)
+        heavy = np.argsort(base["n_cand"])[-3:]              # single-frame calls on the heaviest frames: sliced live path
+        for f in list(heavy) + [0, 1]:
+            one = core.match_triangulate(blobs[f:f + 1], counts[f:f + 1], K_max=48)
+            k = int(base["n_out"][f])
+            assert int(one["n_out"][0]) == k and int(one["n_cand"][0]) == int(base["n_cand"][f])
+            for key in ("xyz", "err", "corr"):
+                assert np.array_equal(one[key][0, :k], base[key][f, :k]), ("single frame", f, key)
     finally:
         core.set_tuning(0, -1, 0)
 
