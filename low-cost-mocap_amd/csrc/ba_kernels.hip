@@ -425,28 +425,38 @@ __global__ __launch_bounds__(kFusedThreads) void ba_fused_kernel(BaFusedArgs a) 
     double* dm = a.dev_mail;  // [0] stamp, [2..] x
     const bool lead = chunk == 0 && grp == 0;
     if (lead) {
-      if (tid == 0) {
+      // the mailbox is a run of 64-byte lines {tag, 7 doubles of x}; the host writes a line's data, then its tag
+      // (x86 store order), and a line is read whole: a line whose tag equals the stamp carries its new data, so the
+      // poll that sees the command has also read x -- no second trip over PCIe
+      const int lines = (n + 6) / 7;
+      if (wave == 0) {
         const unsigned long long t0 = wall_clock64();
         int go = 0;
         while (true) {
-          const double sq = __hip_atomic_load(&a.mailbox[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-          if (sq == a.stamp) {
+          double v = 0.0;
+          if (lane < 8 * lines) v = __hip_atomic_load(&a.mailbox[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          double v2 = 0.0;  // lines 8.. (n > 56)
+          if (lane + 64 < 8 * lines) v2 = __hip_atomic_load(&a.mailbox[lane + 64], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          const bool is_tag = (lane & 7) == 0;
+          const bool bad1 = is_tag && lane < 8 * lines && v != a.stamp, bad2 = is_tag && lane + 64 < 8 * lines && v2 != a.stamp;
+          const bool quit = is_tag && lane == 0 && v < 0.0;
+          if (!__ballot(bad1 || bad2)) {
+            if (!is_tag) {
+              const int k1 = (lane >> 3) * 7 + (lane & 7) - 1, k2 = ((lane + 64) >> 3) * 7 + (lane & 7) - 1;
+              if (lane < 8 * lines && k1 < n) xs[k1] = v;
+              if (lane + 64 < 8 * lines && k2 < n) xs[k2] = v2;
+            }
             go = 1;
             break;
           }
-          if (sq < 0.0 || wall_clock64() - t0 > 200000000ull) break;
+          if (__ballot(quit) || wall_clock64() - t0 > 200000000ull) break;
           __builtin_amdgcn_s_sleep(2);
         }
-        sh_last = go;
+        if (lane == 0) sh_last = go;
       }
       __syncthreads();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // system scope: x was written before the stamp
       if (sh_last)
-        for (int k = tid; k < n; k += kFusedThreads) {
-          const double v = __hip_atomic_load(&a.mailbox[2 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-          xs[k] = v;
-          st_agent(&dm[2 + k], v);
-        }
+        for (int k = tid; k < n; k += kFusedThreads) st_agent(&dm[2 + k], xs[k]);
       drain_stores();
       __syncthreads();
       if (tid == 0) st_agent(&dm[0], sh_last ? a.stamp : -a.stamp);  // -stamp: this launch is abandoned

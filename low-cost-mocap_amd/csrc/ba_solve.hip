@@ -343,8 +343,8 @@ int ba_setup(mocap_ctx* ctx, BaWork& w, int64_t N, const double* obs, int Pmax, 
     w.d_fmail = q;     q += nd_mail;
     w.d_fJaug = want_jaug ? q : nullptr;
     HIP_TRY(ctx, hipMemsetAsync(w.d_fcounters, 0, (nd_cnt + nd_mail) * sizeof(double), ctx->stream));  // the kernel leaves the counters at zero
-    nd_fout = al((size_t)w.NP * w.NP + 3) + al(2 + 128);
-    w.prearm = !getenv("MOCAP_BA_NO_PREARM");
+    nd_fout = al((size_t)w.NP * w.NP + 3) + al(8 * 19);  // + mailbox: 19 lines of {tag, 7 doubles} (n <= 127)
+    w.prearm = !getenv("MOCAP_BA_NO_PREARM") && w.n <= 112;  // the mailbox poll reads 16 lines of 7 parameters in one go
   }
   const size_t pin_bytes = sizeof(double) * (nd_x + nd_G + nd_cost + nd_fout);
   if (pin_bytes > ctx->ba_pin_cap) {
@@ -503,9 +503,13 @@ int ba_linearize_fused(mocap_ctx* ctx, BaWork& w, const double* x, int f32, int 
       w.armed = true;
     }
     stamp = w.armed_stamp;
-    memcpy(w.h_mail + 2, x, sizeof(double) * w.n);
-    __atomic_thread_fence(__ATOMIC_RELEASE);
-    *(volatile double*)w.h_mail = stamp;
+    // mailbox = 64-byte lines {tag, 7 doubles of x}: data first, then the tag of the line
+    for (int l = 0; l * 7 < w.n; l++) {
+      volatile double* line = w.h_mail + 8 * l;
+      for (int j = 0; j < 7 && l * 7 + j < w.n; j++) line[1 + j] = x[l * 7 + j];
+      __atomic_thread_fence(__ATOMIC_RELEASE);
+      line[0] = stamp;
+    }
     w.armed = false;
     rc = ba_fused_launch(ctx, w, nullptr, f32, cauchy, rel_step, w.armed_stamp);
     if (rc) return rc;

@@ -473,7 +473,7 @@ static int match_dev_locked(mocap_ctx* ctx, int64_t n_frames, int M_max, const f
   // work queues: heavy-frame list + slice partials (scheduling note in frame_kernel.hip)
   const bool batch = n_frames >= 2 * full_grid;
   FrameQueues& q = a.q;
-  q.heavy_threshold = ctx->heavy_threshold >= 0 ? (uint32_t)ctx->heavy_threshold : (batch ? 16384u : 16u * T);  // live calls: swept, p50 0.129 -> 0.117 ms vs 2T, same p99
+  q.heavy_threshold = ctx->heavy_threshold >= 0 ? (uint32_t)ctx->heavy_threshold : (batch ? 32768u : 16u * T);  // batch: swept under the single-launch schedule (16 k: 13.45, 24-32 k: 13.32, 48 k: 13.50, 64 k: 13.72 ms per 100 k frames); live calls: swept, p50 0.129 -> 0.117 ms vs 2T, same p99
   q.slice_size = ctx->slice_size > 0 ? (uint32_t)ctx->slice_size : (batch ? 8192u : 4u * T);
   // small frames: amortise the queue atomic over a chunk (keeps >= 64 chunks per workgroup for balance);
   // frames with real work keep the finest granularity, their candidate counts are heavy-tailed

@@ -840,7 +840,11 @@ __global__ __launch_bounds__(T, MOCAP_FRAME_WAVES_PER_EU) void frame_kernel(Fram
         }
         __syncthreads();
         st.write_frame_header(frame);  // n_out / status / n_cand are known after the match, whoever evaluates
+#ifdef MOCAP_DEBUG_NO_EVAL  // timing experiments only: phases A-C without candidate evaluation
+        if (false) {
+#else
         if (!st.misc[MI_DEFER] && G) {
+#endif
           st.evaluate(0, G);
           const int nroots = st.misc[MI_NROOTS];
           for (int r = tid; r < nroots; r += T) {
@@ -863,14 +867,18 @@ __global__ __launch_bounds__(T, MOCAP_FRAME_WAVES_PER_EU) void frame_kernel(Fram
         st.match(frame);
         const uint64_t G = (uint32_t)st.misc[MI_G];
         const uint32_t g_lo = (uint32_t)(G * (uint64_t)sl / S), g_hi = (uint32_t)(G * (uint64_t)(sl + 1) / S);
+#ifndef MOCAP_DEBUG_NO_EVAL
         if (g_hi > g_lo) st.evaluate(g_lo, g_hi);
+#endif
         const int nroots = st.misc[MI_NROOTS];
         for (int r = tid; r < nroots; r += T) {
           const int k = st.outslot[r];
           if (k < 0) continue;
           double e = __longlong_as_double(0x7ff0000000000000ll), X[3] = {0, 0, 0};  // +inf: no candidate here
           uint32_t gl = 0;
+#ifndef MOCAP_DEBUG_NO_EVAL
           if (g_hi > g_lo) st.root_winner(r, g_lo, g_hi, e, gl, X);
+#endif
           const size_t o = (size_t)item * R + k;
           q_st(&q.part_e[o], e);
           q_st(&q.part_g[o], gl);

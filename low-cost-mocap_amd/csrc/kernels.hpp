@@ -197,8 +197,8 @@ struct BaFusedArgs {
   int64_t N;
   double rel_step;
   double stamp;          // written to out[NP*NP + 2] when G and the cost are in place
-  // null: the base point is `x` below.  Else pinned host memory {stamp, -, x[n]}: the kernel was launched AHEAD of
-  // the host's decision and waits here until mailbox[0] == stamp (a negative value = abandon), then reads x from it
+  // null: the base point is `x` below.  Else pinned host memory, 64-byte lines {tag, 7 doubles of x}: the kernel was
+  // launched AHEAD of the host's decision and waits until every line's tag == stamp (tag of line 0 negative = abandon)
   const double* mailbox;
   double* dev_mail;      // device memory [2 + 128]: the lead workgroup republishes the mailbox here for the others
   double x[128];         // base point by value (n <= 127): kernel arguments, no PCIe read
