@@ -21,6 +21,7 @@ class CholSecular {
  private:
   bool factor(double a);
   void solve_inplace(double* b) const;
+  void forward_inplace(double* b) const;
   int na_ = 0, ld_ = 0;
   std::vector<double> store_;  // aligned carve-out: B | L | invd | g | q | w
   double *B_ = nullptr, *L_ = nullptr, *invd_ = nullptr, *g_ = nullptr, *q_ = nullptr, *w_ = nullptr;
