@@ -57,12 +57,12 @@ def algorithmic_bytes(counts, n_out, C, M):
 
 
 def measured_traffic(frames):
-    """HBM bytes per launch from the committed PMC pass (profiles/r01_hbm_traffic.json: rocprofv3
+    """HBM bytes per launch from the committed PMC pass (profiles/r02_hbm_traffic.json: rocprofv3
     FETCH_SIZE x2 [gfx950 correction] + WRITE_SIZE per frame, measured on this kernel at 20 k frames),
     scaled to this launch's frame count.  PMC counters cannot be read inside the timed run, so this
     is the profile's figure, not a live one; None if the summary is absent."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")) as f:
             t = json.load(f)
         return float(t["hbm_bytes_per_frame"]) * frames
     except Exception:
@@ -542,8 +542,8 @@ def main():
                                      "padded_format_bytes_per_step": F * (4 + K_MAX * (32 + 2 * C))} if multi else None)},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": measured_traffic(F) if default_wl else None,
-                         "traffic_source": "profiles/r01_hbm_traffic.json (rocprofv3 PMC, per frame x frames)",
-                         "kernel": "mocap::frame_kernel (MODE 0+1+2 launches of one pass, HIP events)",
+                         "traffic_source": "profiles/r02_hbm_traffic.json (rocprofv3 PMC, per frame x frames)",
+                         "kernel": "mocap::frame_kernel<.., MODE_ALL> (one persistent launch per pass, HIP events)",
                          "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": abytes,
                          "note": "path is FP64-VALU bound (~1e3 flop/byte), see roofline_fp64"},
