@@ -407,7 +407,10 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
-    rank, local_rank, world = mdist.init_process_group()
+    rank, local_rank, world = mdist.init_process_group(backend=os.environ.get("MOCAP_DIST_BACKEND") or None)
+    # MOCAP_DIST_BACKEND=gloo: a functional dry run of the N > 1 control flow on a box with fewer GPUs than ranks
+    # (ranks share devices; RCCL itself refuses two ranks on one device) -- never a measurement
+    local_rank = local_rank % torch.cuda.device_count()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     torch.cuda.set_device(local_rank)

@@ -52,6 +52,8 @@ def init_process_group(backend=None):
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
             kw["device_id"] = torch.device("cuda", local_rank)
+        elif torch.cuda.is_available():
+            torch.cuda.set_device(local_rank % torch.cuda.device_count())
         dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, local_rank, world
 
