@@ -413,9 +413,11 @@ __global__ __launch_bounds__(kFusedThreads) void ba_fused_kernel(BaFusedArgs a) 
   const int C = a.C, n = a.n, NP = a.NP;
   const int64_t N = a.N;
   const int nsets = 1 + 6 * (C - 1);  // live parameter sets
+  const double qnan = __longlong_as_double(0x7ff8000000000000ll);
   const size_t nPq = UNIFORM_K ? (size_t)12 * C : (size_t)12 * C * C;
   const size_t set_stride = (size_t)12 * C + nPq;  // [RT C*12 | Pq]
   double* tabs = lds;                               // [kFusedWaves][set_stride]
+  double* obs_s = lds + kFusedWaves * set_stride;   // [C][2][64] the chunk's observations, shared by the waves
   if (a.mailbox) {
     // Launched ahead: the previous linearisation's result is still being turned into the next trial point by the
     // host (trust-region subproblem, ~9 us).  Being resident and polling hides the launch latency and the launch
@@ -486,7 +488,14 @@ __global__ __launch_bounds__(kFusedThreads) void ba_fused_kernel(BaFusedArgs a) 
   __syncthreads();
   if (a.debug_stop && chunk == 0 && grp == 0 && tid == 0) *(volatile double*)(a.out + (size_t)NP * NP + 2) = a.stamp;
   if (a.debug_stop == 1) return;
-  // ---- phase 0: cameras of this group's parameter sets
+  // ---- phase 0: the chunk's observations -> LDS, transposed (every wave of the workgroup triangulates the same 64
+  // points; read per lane from HBM they are 16 dependent, uncoalesced loads per point: ~3 us of the residual phase)
+  for (int e = tid; e < 64 * C * 2; e += kFusedThreads) {
+    const int pt = e / (2 * C), rem = e - pt * 2 * C;
+    const int64_t idx = (int64_t)chunk * 64 + pt;
+    obs_s[rem * 64 + pt] = idx < N ? a.obs[(size_t)idx * C * 2 + rem] : qnan;
+  }
+  // cameras of this group's parameter sets
   for (int t = tid; t < kFusedWaves * C; t += kFusedThreads) {
     const int w = t / C, cam = t - w * C, slot = kFusedWaves * grp + w;
     if (slot >= nsets) continue;
@@ -501,7 +510,6 @@ __global__ __launch_bounds__(kFusedThreads) void ba_fused_kernel(BaFusedArgs a) 
   __syncthreads();
   if (a.debug_stop == 2) return;
   // ---- phase 1: residual of (set p, point idx) = re-triangulation + mean squared reprojection error
-  const double qnan = __longlong_as_double(0x7ff8000000000000ll);
   {
     const int slot = kFusedWaves * grp + wave;
     const int p = ba_live_set(slot);
@@ -514,10 +522,10 @@ __global__ __launch_bounds__(kFusedThreads) void ba_fused_kernel(BaFusedArgs a) 
       cv.RT = (ltab_t)(tabs + (size_t)wave * set_stride);
       cv.Pq = (ltab_t)(tabs + (size_t)wave * set_stride + 12 * C);
       cv.K4 = a.K4;
-      const double* o = a.obs + (size_t)idx * C * 2;
+      const double* o = obs_s + lane;
       auto obs = [&](int c, double& x, double& y) -> bool {
-        x = o[2 * c];
-        y = o[2 * c + 1];
+        x = o[(2 * c) * 64];
+        y = o[(2 * c + 1) * 64];
         return !(isnan(x) || isnan(y));
       };
       double X[3], e = qnan;
@@ -683,7 +691,8 @@ __global__ __launch_bounds__(kFusedThreads) void ba_fused_kernel(BaFusedArgs a) 
 
 size_t ba_fused_lds_bytes(int C, int NP, bool uniformK) {
   const size_t set_stride = (size_t)12 * C + (uniformK ? (size_t)12 * C : (size_t)12 * C * C);
-  const size_t tabs = kFusedWaves * set_stride * sizeof(double), jaug = (size_t)64 * (NP + 1) * sizeof(double);
+  const size_t tabs = (kFusedWaves * set_stride + (size_t)64 * C * 2) * sizeof(double),
+               jaug = (size_t)64 * (NP + 1) * sizeof(double);
   return tabs > jaug ? tabs : jaug;
 }
 
