@@ -813,25 +813,35 @@ __global__ __launch_bounds__(T, MOCAP_FRAME_WAVES_PER_EU) void frame_kernel(Fram
       const int item = st.misc[MI_ITEM], kind = st.misc[MI_KIND];
       __syncthreads();  // every lane has read the slots before lane 0 can overwrite them
       if (!kind) break;
+      // one code path for both kinds of item (a single inlined copy of match() and evaluate(): frame and slice
+      // workgroups share the CU's instruction cache)
+      int64_t frame = item;
+      int h = -1, base = 0, S = 1, sl = 0;
+      if (kind == 2) {
+        h = q_load(&q.slice_heavy[item]);
+        frame = q_load(&q.heavy[4 * h + 0]);
+        base = q_load(&q.heavy[4 * h + 1]);
+        S = q_load(&q.heavy[4 * h + 2]);
+        sl = item - base;
+      }
+      st.match(frame);
+      const uint32_t G = (uint32_t)st.misc[MI_G];
       if (kind == 1) {
-        const int64_t frame = item;
-        st.match(frame);
-        const uint32_t G = (uint32_t)st.misc[MI_G];
         if (tid == 0) {
           int defer = 0;
           if (q.heavy_threshold && G > q.heavy_threshold) {
-            uint32_t S = (G + q.slice_size - 1) / q.slice_size;
-            if (S > 64) S = 64;
-            const int h = q_add(&q.counters[QC_N_HEAVY], 1);
-            if (h < q.H_cap) {
-              const int base = q_add(&q.counters[QC_N_SLICES], (int)S);
-              if (base + (int)S <= q.W_cap) {
-                q_store(&q.heavy[4 * h + 0], (int32_t)frame);
-                q_store(&q.heavy[4 * h + 1], base);
-                q_store(&q.heavy[4 * h + 2], (int32_t)S);
-                q_store(&q.heavy[4 * h + 3], 0);
+            uint32_t Sn = (G + q.slice_size - 1) / q.slice_size;
+            if (Sn > 64) Sn = 64;
+            const int hn = q_add(&q.counters[QC_N_HEAVY], 1);
+            if (hn < q.H_cap) {
+              const int bn = q_add(&q.counters[QC_N_SLICES], (int)Sn);
+              if (bn + (int)Sn <= q.W_cap) {
+                q_store(&q.heavy[4 * hn + 0], (int32_t)frame);
+                q_store(&q.heavy[4 * hn + 1], bn);
+                q_store(&q.heavy[4 * hn + 2], (int32_t)Sn);
+                q_store(&q.heavy[4 * hn + 3], 0);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the entry is in memory before its tickets become valid
-                for (uint32_t s = 0; s < S; s++) q_store(&q.slice_heavy[base + s], h);
+                for (uint32_t s = 0; s < Sn; s++) q_store(&q.slice_heavy[bn + s], hn);
                 defer = 1;
               }
             }
@@ -840,45 +850,32 @@ __global__ __launch_bounds__(T, MOCAP_FRAME_WAVES_PER_EU) void frame_kernel(Fram
         }
         __syncthreads();
         st.write_frame_header(frame);  // n_out / status / n_cand are known after the match, whoever evaluates
-#ifdef MOCAP_DEBUG_NO_EVAL  // timing experiments only: phases A-C without candidate evaluation
-        if (false) {
-#else
-        if (!st.misc[MI_DEFER] && G) {
-#endif
-          st.evaluate(0, G);
-          const int nroots = st.misc[MI_NROOTS];
-          for (int r = tid; r < nroots; r += T) {
-            if (st.outslot[r] < 0) continue;
-            double e, X[3];
-            uint32_t gl;
-            if (st.root_winner(r, 0, G, e, gl, X)) st.write_point(frame, r, e, gl, X);
-          }
-        }
-        __syncthreads();
-        if (tid == 0) {
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-          q_add(&q.counters[QC_FRAMES_DONE], 1);
-        }
+      }
+      // candidate range of this item: the whole frame, nothing (deferred to its slices), or one slice
+      uint32_t g_lo = 0, g_hi = G;
+      if (kind == 1) {
+        if (st.misc[MI_DEFER]) g_hi = 0;
       } else {
-        const int h = q_load(&q.slice_heavy[item]);
-        const int64_t frame = q_load(&q.heavy[4 * h + 0]);
-        const int base = q_load(&q.heavy[4 * h + 1]), S = q_load(&q.heavy[4 * h + 2]);
-        const int sl = item - base;
-        st.match(frame);
-        const uint64_t G = (uint32_t)st.misc[MI_G];
-        const uint32_t g_lo = (uint32_t)(G * (uint64_t)sl / S), g_hi = (uint32_t)(G * (uint64_t)(sl + 1) / S);
-#ifndef MOCAP_DEBUG_NO_EVAL
-        if (g_hi > g_lo) st.evaluate(g_lo, g_hi);
+        g_lo = (uint32_t)((uint64_t)G * (uint64_t)sl / S);
+        g_hi = (uint32_t)((uint64_t)G * (uint64_t)(sl + 1) / S);
+      }
+#ifndef MOCAP_DEBUG_NO_EVAL  // timing experiments only: phases A-C without candidate evaluation
+      if (g_hi > g_lo) st.evaluate(g_lo, g_hi);
 #endif
-        const int nroots = st.misc[MI_NROOTS];
-        for (int r = tid; r < nroots; r += T) {
-          const int k = st.outslot[r];
-          if (k < 0) continue;
-          double e = __longlong_as_double(0x7ff0000000000000ll), X[3] = {0, 0, 0};  // +inf: no candidate here
-          uint32_t gl = 0;
+      const int nroots = st.misc[MI_NROOTS];
+      bool merge = false;
+      for (int r = tid; r < nroots; r += T) {
+        const int k = st.outslot[r];
+        if (k < 0) continue;
+        double e = __longlong_as_double(0x7ff0000000000000ll), X[3] = {0, 0, 0};  // +inf: no candidate here
+        uint32_t gl = 0;
+        bool won = false;
 #ifndef MOCAP_DEBUG_NO_EVAL
-          if (g_hi > g_lo) st.root_winner(r, g_lo, g_hi, e, gl, X);
+        if (g_hi > g_lo) won = st.root_winner(r, g_lo, g_hi, e, gl, X);
 #endif
+        if (kind == 1) {
+          if (won) st.write_point(frame, r, e, gl, X);
+        } else {
           const size_t o = (size_t)item * R + k;
           q_st(&q.part_e[o], e);
           q_st(&q.part_g[o], gl);
@@ -886,13 +883,22 @@ __global__ __launch_bounds__(T, MOCAP_FRAME_WAVES_PER_EU) void frame_kernel(Fram
           q_st(&q.part_x[3 * o + 1], X[1]);
           q_st(&q.part_x[3 * o + 2], X[2]);
         }
+      }
+      if (kind == 1) {
+        __syncthreads();
+        if (tid == 0) {
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          q_add(&q.counters[QC_FRAMES_DONE], 1);
+        }
+      } else {
         // the workgroup that finishes a heavy frame's LAST slice merges them: it already holds the frame's roots, hit
         // lists and output slots in LDS
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // every wave's partials have left the CU
         __syncthreads();
         if (tid == 0) st.misc[MI_DEFER] = q_add(&q.heavy[4 * h + 3], 1) == S - 1;
         __syncthreads();
-        if (st.misc[MI_DEFER]) {
+        merge = st.misc[MI_DEFER] != 0;
+        if (merge) {
           for (int r = tid; r < nroots; r += T) {
             const int k = st.outslot[r];
             if (k < 0) continue;
