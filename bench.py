@@ -86,9 +86,11 @@ def executed_fp64(candidates, kernel_ms):
         return None
 
 
-def cpu_baseline(rig, blobs, counts, budget_s=15.0):
+def cpu_baseline(rig, blobs, counts, budget_s=15.0, gpu=None):
     """The oracle's C restatement of the reference path ("port"), single thread, on a bounded
-    prefix of the SAME frames.  Reported baseline only -- never the thing measured or shipped."""
+    prefix of the SAME frames.  Reported baseline only -- never the thing measured or shipped.
+    gpu: the timed run's outputs (numpy: n_out, corr, xyz); the all-cores run's oracle results are then also
+    compared with them frame by frame -> `wide_parity` (tens of thousands of frames instead of the 300-frame gate)."""
     from oracle import c_oracle
     co = c_oracle.COracle(rig["K"], rig["R"], rig["t"])
     co.match_triangulate(blobs[:20], counts[:20])          # warm
@@ -117,12 +119,27 @@ def cpu_baseline(rig, blobs, counts, budget_s=15.0):
         def work(i):
             if not hasattr(local, "co"):
                 local.co = c_oracle.COracle(rig["K"], rig["R"], rig["t"])
-            r = local.co.match_triangulate(blobs[i * chunk:(i + 1) * chunk], counts[i * chunk:(i + 1) * chunk])
-            return int(r["n_out"].sum())
+            lo, hi = i * chunk, (i + 1) * chunk
+            r = local.co.match_triangulate(blobs[lo:hi], counts[lo:hi])
+            bad, dev = 0, 0.0
+            if gpu is not None:          # checker role: the GPU's answer for the very same frames
+                kk = gpu["corr"].shape[1]
+                vv = np.arange(kk)[None, :] < r["n_out"][:, None]
+                same = np.array_equal(r["n_out"], gpu["n_out"][lo:hi]) and np.array_equal(r["corr"][:, :kk][vv], gpu["corr"][lo:hi][vv])
+                bad = 0 if same else 1
+                if same and vv.any():
+                    ref = r["xyz"][:, :kk][vv]
+                    dev = float(np.abs(gpu["xyz"][lo:hi][vv] - ref).max() / np.abs(ref).max())
+            return int(r["n_out"].sum()), bad, dev
         t2 = time.perf_counter()
         with ThreadPoolExecutor(nthreads) as ex:
-            tot = sum(ex.map(work, range(n_chunks)))
+            res = list(ex.map(work, range(n_chunks)))
         dt2 = time.perf_counter() - t2
+        tot = sum(r[0] for r in res)
+        if gpu is not None:
+            out["wide_parity"] = {"frames_checked": n_chunks * chunk, "chunks_with_any_index_difference": sum(r[1] for r in res),
+                                  "corr_bit_exact": not any(r[1] for r in res), "xyz_max_rel": max(r[2] for r in res),
+                                  "against": "oracle/c (the all-cores baseline run's own results)"}
         out["all_cores"] = {"value": tot / dt2, "unit": "markers/s", "cores": nthreads,
                             "sample": f"first {n_chunks * chunk} frames of the bench batch in chunks of {chunk}, "
                                       f"{nthreads} threads, {dt2:.1f}s"}
@@ -335,6 +352,38 @@ def ba_cpu_baseline(rig, init, obs, x0, budget_nfev=150):
     return out
 
 
+def ba_parity(core):
+    """Reference-mode bundle adjustment on the solver goldens (tests/golden/ba_*: the reference's own poses and
+    OptimizeResult statistics, plus its reproducibility under a 1e-15 nudge of the start vector): pose deltas of
+    mode "scipy" (reference optimizer, GPU residuals) and mode "resident" (mocap_ba_solve)."""
+    from mocap_core import helpers
+    out = {}
+    gdir = os.path.join(ROOT, "tests", "golden")
+    for name in ("ba_c3_n24", "ba_c4_n60_solved", "ba_c8_n100_solved"):
+        path = os.path.join(gdir, name + ".npz")
+        if not os.path.exists(path):
+            continue
+        g = np.load(path)
+        C = g["K"].shape[0]
+        helpers.set_core(core)
+        helpers.set_camera_params([{"intrinsic_matrix": k.tolist()} for k in g["K"]])
+        poses0 = [{"R": g["R_init"][i].copy(), "t": g["t_init"][i].copy()} for i in range(C)]
+        row = {"reference": {"nfev": int(g["ba_stats"][0]), "njev": int(g["ba_stats"][1]),
+                             "self_dR_max": float(g["self_dR"].max()), "self_dt_rel_max": float(g["self_dt"].max())}}
+        for mode in ("scipy", "resident"):
+            helpers.set_bundle_adjustment_mode(mode)
+            try:
+                poses, info = helpers.bundle_adjustment(synth.obs_to_reference_array(g["obs"]), poses0, None, return_info=True)
+            finally:
+                helpers.set_bundle_adjustment_mode("resident")
+            R = np.array([np.asarray(p["R"], dtype=np.float64) for p in poses])
+            t = np.array([np.asarray(p["t"], dtype=np.float64).reshape(3) for p in poses])
+            row[mode] = {"nfev": int(info["nfev"]), "njev": int(info["njev"]), "dR_max": float(np.abs(R - g["R_ba"]).max()),
+                         "dt_rel_max": float(np.abs(t - g["t_ba"]).max() / np.abs(g["t_ba"]).max())}
+        out[name] = row
+    return out
+
+
 def ba_bench(core, iters=200, cpu=True):
     """Secondary metric: LM iterations/sec, 8 cams x 1000 points, reference settings
     (cauchy loss, float32 residual cast, 2-point Jacobian incl. the dead focal columns)."""
@@ -381,7 +430,7 @@ def ba_bench(core, iters=200, cpu=True):
                         "PCIe hand-over, host subproblem).  MFMA issue counters: profiles/r02_ba_pmc_mfma.csv"}
     out_cpu = ba_cpu_baseline(rig, init, obs, x0) if cpu else None
     return {"metric": "BA iters/sec (8 cams, 1k pts)", "value": info["iterations"] / dt, "roofline": roofline,
-            "cpu_baseline": out_cpu,
+            "cpu_baseline": out_cpu, "parity": ba_parity(core),
             "iterations": info["iterations"], "nfev": info["nfev"], "ms_per_iter": 1e3 * dt / max(info["iterations"], 1),
             "runs_ms": [round(1e3 * r[0], 2) for r in runs], "statistic": "median of 5 solves",
             "params": int(x0.size), "points": int(info["m"]),
@@ -575,7 +624,9 @@ def main():
                 "xyz_max_rel": float(np.abs(xyz[vv] - ref["xyz"][vv]).max() / np.abs(ref["xyz"][vv]).max()),
             }
             if not args.no_cpu_baseline and default_wl:
-                line["cpu_baseline"] = cpu_baseline(rig, blobs, counts)
+                line["cpu_baseline"] = cpu_baseline(rig, blobs, counts, gpu={"n_out": n_out, "corr": corr, "xyz": d_xyz.cpu().numpy()})
+                if "wide_parity" in line["cpu_baseline"]:
+                    line["parity"]["wide"] = line["cpu_baseline"].pop("wide_parity")
                 line["config"]["host_cores"] = os.cpu_count()
             if default_wl and not args.no_latency:
                 core.set_stream(0)
