@@ -270,7 +270,7 @@ def blob_stage_bench(core, dev, stream, steps=5, frames=1024, distinct=16):
                          "unit": "GB/s", "frac": (in_bytes + out_bytes) / ms_b / 1e6 / HBM_PEAK_GBS,
                          "algorithmic_bytes_per_image": 240 * 320 * 3 + 8,
                          "note": "integer-VALU bound (9x9 + 5x5 filters on 3 channels: ~180 ops/pixel); "
-                                 "profiles/r01_blob_*"},
+                                 "profiles/r01_blob_* (instruction mix), profiles/r02_blob_pmc_traffic.csv (HBM traffic)"},
             "frame_set_latency_ms": {"p50": float(lat[len(lat) // 2]), "max": float(lat[-1]),
                                      "path": "1 frame set (8 images on the device) -> blobs -> 3-D points, "
                                              "5 kernel launches + sync, wall clock incl. Python/ctypes"},

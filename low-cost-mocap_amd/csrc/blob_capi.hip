@@ -90,18 +90,12 @@ int find_blobs_dev_locked(mocap_ctx* ctx, int64_t n_frames, const uint8_t* d_ima
   if (n_frames < 0 || M_max < 1) return ctx->fail(MOCAP_E_ARG, "mocap_find_blobs: bad size argument");
   if (n_frames == 0) return MOCAP_OK;
   if (!d_images || !d_blobs || !d_counts || !d_status) return ctx->fail(MOCAP_E_ARG, "mocap_find_blobs: null buffer");
-  // frame sets are processed in chunks: the squared-frame workspace of one chunk (~340 KB per image) stays
-  // in the 256 MB Infinity Cache between the pre-pass that writes it and the mask kernel that reads it
+  // frame sets are processed in chunks: a chunk's raw frames (230 KB per image at 240 x 320) are read by the
+  // activity pass and then by the mask kernel's gather while they are still in the 256 MB Infinity Cache
   const int C = ctx->img_C, S = ctx->img_S;
   const int64_t chunk_frames = (2048 / C) > 0 ? 2048 / C : 1;
   const int64_t chunk_images = chunk_frames * C;
-  const size_t sq_img = (size_t)(S + 2) * (S + 2 * kSquarePad) * 3;
   const int64_t want = n_frames * C < chunk_images ? n_frames * C : chunk_images;
-  if (ctx->img_sq_images < want) {
-    if (ctx->img_sq.reserve(sq_img * want)) return ctx->fail(MOCAP_E_HIP, "hipMalloc(squared frames, %zu B) failed", sq_img * want);
-    HIP_TRY(ctx, hipMemsetAsync(ctx->img_sq.ptr, 0, ctx->img_sq.cap, ctx->stream));  // the zero frame, once
-    ctx->img_sq_images = (int64_t)(ctx->img_sq.cap / sq_img);
-  }
   const int bands = (ctx->img_rows + 16 + kSquareRows - 1) / kSquareRows, segs = ctx->img_cols * 3 / 16;
   if (ctx->img_act.reserve((size_t)want * bands * segs * 2)) return ctx->fail(MOCAP_E_HIP, "hipMalloc(activity map) failed");
   const size_t words = (size_t)(S + 63) / 64;
@@ -120,8 +114,10 @@ int find_blobs_dev_locked(mocap_ctx* ctx, int64_t n_frames, const uint8_t* d_ima
     a.M_max = M_max;
     a.raw = d_images + i0 * ctx->img_rows * ctx->img_cols * 3;
     a.rot = (const int32_t*)ctx->img_rot.ptr;
-    a.squared = (uint8_t*)ctx->img_sq.ptr;
     a.gather = (const uint32_t*)ctx->img_tiles.ptr;
+    a.fix_rec = (const uint32_t*)ctx->img_fix.ptr;
+    a.fix_off = (const int32_t*)ctx->img_fixidx.ptr;
+    a.fix_cnt = a.fix_off + ctx->img_n_lt;
     a.cam_lens = (const int32_t*)ctx->img_lens.ptr;
     a.activity = (uint8_t*)ctx->img_act.ptr;
     a.tile_box = (const int16_t*)ctx->img_box.ptr;
@@ -133,7 +129,7 @@ int find_blobs_dev_locked(mocap_ctx* ctx, int64_t n_frames, const uint8_t* d_ima
     a.counts = d_counts + i0;
     a.status = d_status + i0;
     a.n_contours = d_n_contours ? d_n_contours + i0 : nullptr;
-    HIP_TRY(ctx, launch_blob_square(a, ctx->stream));
+    if (a.skip_dark && !a.processed) HIP_TRY(ctx, launch_blob_activity(a, ctx->stream));  // the map's only reader
     HIP_TRY(ctx, launch_blob_mask(a, ctx->stream));
   }
   // contours of the whole batch at once (one workgroup per image, reads only the 1-bit masks)
@@ -204,79 +200,147 @@ extern "C" int mocap_set_image_params(mocap_ctx* ctx, int C, int rows, int cols,
     else
       build_undistort_map(K + 9 * c, dist + 5 * c, S, map.data() + (size_t)c * S * S);
   }
-  // gather tables of the mask kernel: per distinct lens and 64 x 64 tile, for each pixel of the tile's
-  // 76 x 76 region (reflect-101 of cv::GaussianBlur / cv::filter2D applied here, once) the byte offset of
-  // the top-left bilinear tap inside a zero-framed squared frame, and the 1/32-px fractions
+  // gather tables of the mask kernel: per distinct (lens, rotation) and 64 x 64 tile, for each pixel of the tile's
+  // 76 x 76 region (reflect-101 of cv::GaussianBlur / cv::filter2D applied here, once) where its four bilinear taps
+  // sit IN THE RAW FRAME.  np.rot90 and make_square (helpers.py:71-72, 507-523) are a change of coordinates plus a
+  // per-row scale: squared pixel (Y, X) = raw pixel (r, X) [rot 0] or (rows-1-r, cols-1-X) [rot 180], r = Y - ay
+  // clamped to the frame, times scale/8 (8 inside the frame, 7..0 on the 8 feathered rows above and below, nothing
+  // beyond).  Interior pixels (all four taps inside the frame) become a plain offset + fractions; for a rotated camera
+  // the pair starts at the memory-first pixel and the fractions are swapped (32 - f; f = 0 keeps its pixel first).
   const int tiles = (S + kBlobTile - 1) / kBlobTile;
-  const int WP = S + 2 * kSquarePad, RW = kBlobTile + 2 * kBlobHalo;
+  const int RW = kBlobTile + 2 * kBlobHalo;
+  const int row_bytes = cols * 3;
+  const int64_t image_bytes = (int64_t)rows * row_bytes;
   std::vector<int32_t> lens(C, 0);
-  std::vector<int> lens_cam;  // first camera of each distinct lens
+  std::vector<int> lens_cam;  // first camera of each distinct (lens, rotation)
   for (int c = 0; c < C; c++) {
     int same = -1;
     for (size_t l = 0; l < lens_cam.size() && same < 0; l++)
-      if (!memcmp(map.data() + (size_t)lens_cam[l] * S * S, map.data() + (size_t)c * S * S, sizeof(uint32_t) * S * S)) same = (int)l;
+      if (rot[lens_cam[l]] == rot[c] &&
+          !memcmp(map.data() + (size_t)lens_cam[l] * S * S, map.data() + (size_t)c * S * S, sizeof(uint32_t) * S * S)) same = (int)l;
     if (same < 0) {
       same = (int)lens_cam.size();
       lens_cam.push_back(c);
     }
     lens[c] = same;
   }
-  std::vector<uint32_t> gather(lens_cam.size() * tiles * tiles * (size_t)kBlobGather, 0u);
+  const size_t n_lt = lens_cam.size() * tiles * tiles;
+  constexpr uint32_t kSentinel = 0x3fffffu;
+  std::vector<uint32_t> gather(n_lt * (size_t)kBlobGather, kSentinel);
+  std::vector<uint32_t> fix;            // 5 words per record
+  std::vector<int32_t> fixidx(2 * n_lt, 0);  // [n_lt] first record, [n_lt] count
+  std::vector<int16_t> box(n_lt * 4);
+  std::vector<uint8_t> zero(n_lt, 0);
   auto refl = [S](int i) {
     i = i < 0 ? -i : i;
     i = i >= S ? 2 * (S - 1) - i : i;
     return i < 0 ? 0 : (i >= S ? S - 1 : i);
   };
-  for (size_t l = 0; l < lens_cam.size(); l++)
+  struct Tap {
+    bool in_area;  // inside the rows the squared frame fills (frame + feather) and its columns: takes part in the activity box
+    int scale;     // 0 = zero pixel
+    int64_t off;   // raw byte offset of the pixel
+    int r_raw, c_raw;
+  };
+  for (size_t l = 0; l < lens_cam.size(); l++) {
+    const int rotc = rot[lens_cam[l]];
+    auto tap_of = [&](int Y, int X) {
+      Tap t{false, 0, 0, 0, 0};
+      if (X < 0 || X >= S || Y < ay - 8 || Y >= ay + rows + 8) return t;
+      t.in_area = true;
+      int r = Y - ay, sc = 8;
+      if (r < 0) {
+        sc = 8 + r;
+        r = 0;
+      } else if (r >= rows) {
+        sc = 7 - (r - rows);
+        r = rows - 1;
+      }
+      t.scale = sc;
+      t.r_raw = rotc ? rows - 1 - r : r;
+      t.c_raw = rotc ? cols - 1 - X : X;
+      t.off = ((int64_t)t.r_raw * cols + t.c_raw) * 3;
+      return t;
+    };
     for (int t = 0; t < tiles * tiles; t++) {
+      const size_t lt = l * tiles * tiles + t;
       const int ty0 = (t / tiles) * kBlobTile, tx0 = (t % tiles) * kBlobTile;
-      uint32_t* g = gather.data() + (l * tiles * tiles + t) * (size_t)kBlobGather;
+      uint32_t* g = gather.data() + lt * (size_t)kBlobGather;
+      fixidx[lt] = (int32_t)(fix.size() / 5);
+      int b0 = 1 << 20, b1 = -1, s0 = 1 << 20, s1 = -1;
+      bool z = false;
       for (int vy = 0; vy < RW; vy++)
         for (int vx = 0; vx < RW; vx++) {
           const uint32_t m = map[((size_t)lens_cam[l] * S + refl(ty0 - kBlobHalo + vy)) * S + refl(tx0 - kBlobHalo + vx)];
           const int sxp = (m >> 10) & 2047;
-          uint32_t e = 0;  // every tap outside: offset 0 = the zero frame, fractions 0
-          if (sxp != 2047) {
-            const int sx = sxp - 1, sy = (int)(m >> 21) - 1;  // -1 .. S-1: row/column -1 and S are the zero frame
-            e = (uint32_t)(((sy + 1) * WP + sx + kSquarePad) * 3) | (m & 31u) << 22 | ((m >> 5) & 31u) << 27;
-          }
-          g[vy * RW + vx] = e;
-        }
-    }
-  // source bounding box of every tile in units of the pre-pass's activity map (16-row bands x 16-byte segments)
-  std::vector<int16_t> box(lens_cam.size() * tiles * tiles * 4);
-  std::vector<uint8_t> zero(lens_cam.size() * tiles * tiles, 0);
-  for (size_t l = 0; l < lens_cam.size(); l++)
-    for (int t = 0; t < tiles * tiles; t++) {
-      const uint32_t* g = gather.data() + (l * tiles * tiles + t) * (size_t)kBlobGather;
-      int b0 = 1 << 20, b1 = -1, s0 = 1 << 20, s1 = -1;
-      bool z = false;
-      for (int i = 0; i < RW * RW; i++) {
-        const int off = (int)(g[i] & 0x3fffffu) / 3;   // pixel index inside the zero-framed layout
-        const int Y0 = off / WP - 1, X0 = off % WP - kSquarePad;
-        for (int tap = 0; tap < 4; tap++) {
-          const int Y = Y0 + (tap >> 1), X = X0 + (tap & 1);
-          if (Y < ay - 8 || Y >= ay + rows + 8 || X < 0 || X >= S) {
+          const int idx = vy * RW + vx;
+          if (sxp == 2047) {  // every tap outside the squared frame (cv::remap BORDER_CONSTANT 0)
             z = true;
-            continue;
+            continue;       // g[idx] stays the sentinel = zero pixel
           }
-          const int b = (Y - (ay - 8)) / kSquareRows, sa = 3 * X / 16, sb = (3 * X + 2) / 16;
-          b0 = b < b0 ? b : b0;
-          b1 = b > b1 ? b : b1;
-          s0 = sa < s0 ? sa : s0;
-          s1 = sb > s1 ? sb : s1;
+          const int sx = sxp - 1, sy = (int)(m >> 21) - 1;  // -1 .. S-1
+          const uint32_t fx = m & 31u, fy = (m >> 5) & 31u;
+          const Tap tp[4] = {tap_of(sy, sx), tap_of(sy, sx + 1), tap_of(sy + 1, sx), tap_of(sy + 1, sx + 1)};
+          // activity box of the tile, in the squared frame's bands and segments
+          for (int k = 0; k < 4; k++) {
+            const int Y = sy + (k >> 1), X = sx + (k & 1);
+            if (!tp[k].in_area) {
+              z = true;
+              continue;
+            }
+            const int bnd = (Y - (ay - 8)) / kSquareRows, sa = 3 * X / 16, sb = (3 * X + 2) / 16;
+            b0 = bnd < b0 ? bnd : b0;
+            b1 = bnd > b1 ? bnd : b1;
+            s0 = sa < s0 ? sa : s0;
+            s1 = sb > s1 ? sb : s1;
+          }
+          const bool all_zero = !tp[0].scale && !tp[1].scale && !tp[2].scale && !tp[3].scale;
+          if (all_zero) continue;  // sentinel
+          bool plain = tp[0].scale == 8 && tp[1].scale == 8 && tp[2].scale == 8 && tp[3].scale == 8 &&
+                       tp[2].r_raw - tp[0].r_raw == (rotc ? -1 : 1);  // two different frame rows (not a clamped pair)
+          uint32_t e = 0;
+          if (plain) {
+            // memory-first pixel of the pair and memory-upper row of the two
+            uint32_t fxe = fx, fye = fy;
+            int r_top = tp[0].r_raw, c_first = tp[0].c_raw;
+            if (rotc) {
+              if (fx) {
+                c_first = tp[1].c_raw;  // = cols - 2 - sx: the pair's second pixel comes first in memory
+                fxe = 32u - fx;
+              }
+              if (fy) {
+                r_top = tp[2].r_raw;    // = rows - 2 - r
+                fye = 32u - fy;
+              }
+            }
+            const int64_t off = ((int64_t)r_top * cols + c_first) * 3;
+            // both 8-byte loads (this row and the next one in memory) must stay inside the image
+            if (off + row_bytes + 8 > image_bytes || off >= (int64_t)kSentinel) plain = false;
+            else e = (uint32_t)off | fxe << 22 | fye << 27;
+          }
+          if (plain) {
+            g[idx] = e;
+          } else {
+            fix.push_back((uint32_t)idx | fx << 16 | fy << 24);
+            for (int k = 0; k < 4; k++) fix.push_back(tp[k].scale ? ((uint32_t)tp[k].off | (uint32_t)tp[k].scale << 22) : 0u);
+          }
         }
-      }
-      int16_t* o = box.data() + (l * tiles * tiles + t) * 4;
-      if (b1 < 0) {  // every tap in the zero area: one (any) activity cell, the zero flag decides
-        b0 = b1 = s0 = s1 = 0;
-      }
+      fixidx[n_lt + lt] = (int32_t)(fix.size() / 5) - fixidx[lt];
+      int16_t* o = box.data() + lt * 4;
+      if (b1 < 0) b0 = b1 = s0 = s1 = 0;  // every tap in the zero area: one (any) activity cell, the zero flag decides
       o[0] = (int16_t)b0;
       o[1] = (int16_t)b1;
       o[2] = (int16_t)s0;
       o[3] = (int16_t)s1;
-      zero[l * tiles * tiles + t] = z ? 1 : 0;
+      zero[lt] = z ? 1 : 0;
     }
+  }
+  if (fix.empty()) fix.assign(5, 0u);
+  if (ctx->img_fix.reserve(fix.size() * sizeof(uint32_t)) || ctx->img_fixidx.reserve(fixidx.size() * sizeof(int32_t)))
+    return ctx->fail(MOCAP_E_HIP, "hipMalloc(gather fix-up lists) failed");
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->img_fix.ptr, fix.data(), fix.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->img_fixidx.ptr, fixidx.data(), fixidx.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+  ctx->img_n_lt = (int)n_lt;
   if (ctx->img_map.reserve(map.size() * sizeof(uint32_t)) || ctx->img_rot.reserve(C * sizeof(int32_t)) ||
       ctx->img_tiles.reserve(gather.size() * sizeof(uint32_t)) || ctx->img_lens.reserve(C * sizeof(int32_t)) ||
       ctx->img_box.reserve(box.size() * sizeof(int16_t)) || ctx->img_zero.reserve(zero.size()))
@@ -288,9 +352,6 @@ extern "C" int mocap_set_image_params(mocap_ctx* ctx, int C, int rows, int cols,
   HIP_TRY(ctx, hipMemcpyAsync(ctx->img_map.ptr, map.data(), map.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(ctx->img_rot.ptr, rot.data(), C * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  // another frame geometry: the rows the pre-pass leaves untouched (zero frame, empty rows) are different ones,
-  // so the workspace must be cleared again before its next use
-  if (ctx->img_S != S || ctx->img_rows != rows) ctx->img_sq_images = 0;
   ctx->img_C = C;
   ctx->img_rows = rows;
   ctx->img_cols = cols;

@@ -16,11 +16,11 @@
 //   grey       = (B*9798 + G*19235 + R*3735 + 16384) >> 15 on the channel-swapped frame, mask = grey > 51
 //
 // Three kernels:
-//   blob_square_kernel    pre-pass: rot90 + make_square into a zero-framed layout, so that the gather below
-//                         has one path (no border / feather / rotation logic per tap); records the min / max
-//                         byte per (16-row band, 16-byte segment) for the exact dark-tile early-out.
+//   blob_activity_kernel  (only with the dark-tile early-out) min / max byte per (16-row band, 16-byte segment) of
+//                         the squared frame, read-only: nothing but the small map is written.
 //   blob_mask_kernel      one workgroup per 64 x 64 output tile: the whole chain for the tile runs out of
-//                         LDS (table-driven bilinear gather of the 76 x 76 x 3 region -> row pass (dot4) ->
+//                         LDS (table-driven bilinear gather of the 76 x 76 x 3 region STRAIGHT FROM THE RAW
+//                         FRAME -- rot90 / make_square live in the table and a short fix-up list -> row pass (dot4) ->
 //                         column pass (dot2) -> 5x5 (signed dot4) -> grey), 1 bit per pixel out.
 //   blob_contour_kernel   one workgroup per image: border following WITHOUT the sequential raster scan of
 //                         Suzuki-Abe.  Every border (outer or hole) is a cycle of the Moore-tracing step
@@ -64,23 +64,20 @@ __device__ __forceinline__ uint32_t udot2(uint32_t a, uint32_t b, uint32_t c) {
   return __builtin_amdgcn_udot2(__builtin_bit_cast(v2u16, a), __builtin_bit_cast(v2u16, b), c, false);
 }
 
-// ---- pre-pass: np.rot90 (k = 0 or 2) + make_square (helpers.py:507-523) into the zero-framed layout the
-// gather tables address.  One workgroup per image; only the frame rows and the 2 x 8 feathered rows are
-// written (edge row * (7 - i) / 8, truncated), the zero frame and the empty rows are set once at allocation.
-__global__ __launch_bounds__(kBlobThreads) void blob_square_kernel(BlobArgs a) {
+// ---- activity pass (only when the dark-tile early-out is on): per 16-row band of the squared frame
+// (np.rot90 + make_square, helpers.py:507-523: the frame rows and the 2 x 8 feathered rows, edge row * (7 - i) / 8
+// truncated) and per 16-byte segment of a squared row, the min / max of the bytes the squared frame WOULD hold there.
+// Nothing but the map is written: the mask kernel gathers from the raw frame itself.
+__global__ __launch_bounds__(kBlobThreads) void blob_activity_kernel(BlobArgs a) {
   const int first = a.ay - 8, n_rows = a.rows + 16;  // squared rows [first, first + n_rows)
   const int groups = (n_rows + kSquareRows - 1) / kSquareRows;
   const int64_t img = blockIdx.x / groups;
   const int grp = blockIdx.x % groups;
   const int cam = (int)((a.img_base + img) % a.C);
   const int rot = a.rot[cam];
-  const int S = a.S, WP = S + 2 * kSquarePad;
   const uint8_t* raw = a.raw + (size_t)img * a.rows * a.cols * 3;
-  uint8_t* sq = a.squared + (size_t)img * (S + 2) * WP * 3;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int row_bytes = a.cols * 3;
-  // activity of this band: per 16-byte segment the min / max byte over the band's rows (what the frame rows
-  // hold AFTER feather scaling, i.e. exactly the bytes the mask kernel will gather)
   // A lane owns segments lane, lane + 64, ... of a row (rows up to kActSlots * 1024 bytes: the host rejects
   // wider frames), one accumulator pair per segment.
   __shared__ uint32_t act[4][kActSlots * 64];
@@ -90,87 +87,69 @@ __global__ __launch_bounds__(kBlobThreads) void blob_square_kernel(BlobArgs a) {
     mn[j] = 0x00ff00ffu;
     mx[j] = 0u;
   }
+  if (rot == 0) {
 #pragma unroll
-  for (int k = 0; k < kSquareRows / 4; k++) {
-    const int Y = first + grp * kSquareRows + wave * (kSquareRows / 4) + k;
-    if (Y >= first + n_rows) break;
-    int r = Y - a.ay, scale = 8;
-    if (r < 0) {
-      scale = 8 + r;  // r = -1 -> 7/8 ... r = -8 -> 0
-      r = 0;
-    } else if (r >= a.rows) {
-      scale = 7 - (r - a.rows);
-      r = a.rows - 1;
-    }
-    uint8_t* dst = sq + ((size_t)(Y + 1) * WP + kSquarePad) * 3;
-    if (rot == 0) {
-      // 16 bytes per lane: rows start 16-byte aligned in both layouts (cols % 16 == 0 checked by the host)
+    for (int k = 0; k < kSquareRows / 4; k++) {
+      const int Y = first + grp * kSquareRows + wave * (kSquareRows / 4) + k;
+      if (Y >= first + n_rows) break;
+      int r = Y - a.ay, scale = 8;
+      if (r < 0) {
+        scale = 8 + r;  // r = -1 -> 7/8 ... r = -8 -> 0
+        r = 0;
+      } else if (r >= a.rows) {
+        scale = 7 - (r - a.rows);
+        r = a.rows - 1;
+      }
+      // 16 bytes per lane: rows start 16-byte aligned (cols % 16 == 0 checked by the host)
       const uint8_t* src = raw + (size_t)r * row_bytes;
 #pragma unroll
       for (int j = 0; j < kActSlots; j++) {
         const int i = (j * 64 + lane) * 16;
         if (i >= row_bytes) break;
         uint4 v = *(const uint4*)(src + i);
-        if (scale != 8) {
-          uint32_t* w = (uint32_t*)&v;
+        const uint32_t* w = (const uint32_t*)&v;
 #pragma unroll
-          for (int q = 0; q < 4; q++) {
-            const uint32_t e = ((w[q] & 0x00ff00ffu) * (uint32_t)scale) >> 3 & 0x00ff00ffu;
-            const uint32_t o = (((w[q] >> 8) & 0x00ff00ffu) * (uint32_t)scale) >> 3 & 0x00ff00ffu;
-            w[q] = e | o << 8;
+        for (int q = 0; q < 4; q++) {
+          uint32_t e = w[q] & 0x00ff00ffu, o = (w[q] >> 8) & 0x00ff00ffu;
+          if (scale != 8) {
+            e = (e * (uint32_t)scale) >> 3 & 0x00ff00ffu;
+            o = (o * (uint32_t)scale) >> 3 & 0x00ff00ffu;
           }
-        }
-        *(uint4*)(dst + i) = v;
-        {
-          const uint32_t* w = (const uint32_t*)&v;
-#pragma unroll
-          for (int q = 0; q < 4; q++) {
-            const uint32_t e = w[q] & 0x00ff00ffu, o = (w[q] >> 8) & 0x00ff00ffu;
-            mn[j] = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(v2u16, mn[j]), __builtin_elementwise_min(__builtin_bit_cast(v2u16, e), __builtin_bit_cast(v2u16, o))));
-            mx[j] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(v2u16, mx[j]), __builtin_elementwise_max(__builtin_bit_cast(v2u16, e), __builtin_bit_cast(v2u16, o))));
-          }
+          mn[j] = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(v2u16, mn[j]), __builtin_elementwise_min(__builtin_bit_cast(v2u16, e), __builtin_bit_cast(v2u16, o))));
+          mx[j] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(v2u16, mx[j]), __builtin_elementwise_max(__builtin_bit_cast(v2u16, e), __builtin_bit_cast(v2u16, o))));
         }
       }
-    } else {  // rot90 k = 2: rows and columns reversed
-      const uint8_t* src = raw + (size_t)(a.rows - 1 - r) * row_bytes;
-      for (int x = lane; x < a.cols; x += 64) {
-        const uint8_t* p = src + (size_t)(a.cols - 1 - x) * 3;
-        dst[3 * x] = (uint8_t)((p[0] * scale) >> 3);
-        dst[3 * x + 1] = (uint8_t)((p[1] * scale) >> 3);
-        dst[3 * x + 2] = (uint8_t)((p[2] * scale) >> 3);
-      }
+    }
+  } else {
 #pragma unroll
-      for (int j = 0; j < kActSlots; j++) {  // rotated cameras: no activity summary -> "full range", their tiles are never skipped
-        mn[j] = 0u;
-        mx[j] = 0x00ff00ffu;
-      }
+    for (int j = 0; j < kActSlots; j++) {  // rotated cameras: no activity summary -> "full range", their tiles are never skipped
+      mn[j] = 0u;
+      mx[j] = 0x00ff00ffu;
     }
   }
-  if (a.activity) {
 #pragma unroll
-    for (int j = 0; j < kActSlots; j++) {
-      const uint32_t lo = min(mn[j] & 0xffffu, mn[j] >> 16), hi = max(mx[j] & 0xffffu, mx[j] >> 16);
-      act[wave][j * 64 + lane] = lo | hi << 8;
+  for (int j = 0; j < kActSlots; j++) {
+    const uint32_t lo = min(mn[j] & 0xffffu, mn[j] >> 16), hi = max(mx[j] & 0xffffu, mx[j] >> 16);
+    act[wave][j * 64 + lane] = lo | hi << 8;
+  }
+  __syncthreads();
+  const int segs = row_bytes / 16;
+  for (int sg = threadIdx.x; sg < segs; sg += kBlobThreads) {
+    uint32_t l = 255u, h = 0u;
+    for (int w2 = 0; w2 < 4; w2++) {
+      l = min(l, act[w2][sg] & 0xffu);
+      h = max(h, act[w2][sg] >> 8);
     }
-    __syncthreads();
-    const int segs = row_bytes / 16;
-    for (int s = threadIdx.x; s < segs; s += kBlobThreads) {
-      uint32_t l = 255u, h = 0u;
-      for (int w2 = 0; w2 < 4; w2++) {
-        l = min(l, act[w2][s] & 0xffu);
-        h = max(h, act[w2][s] >> 8);
-      }
-      uint8_t* o = a.activity + (((size_t)img * groups + grp) * segs + s) * 2;
-      o[0] = (uint8_t)l;
-      o[1] = (uint8_t)h;
-    }
+    uint8_t* o = a.activity + (((size_t)img * groups + grp) * segs + sg) * 2;
+    o[0] = (uint8_t)l;
+    o[1] = (uint8_t)h;
   }
 }
 
-hipError_t launch_blob_square(const BlobArgs& a, hipStream_t stream) {
+hipError_t launch_blob_activity(const BlobArgs& a, hipStream_t stream) {
   if (a.n_images <= 0) return hipSuccess;
   const int groups = (a.rows + 16 + kSquareRows - 1) / kSquareRows;
-  hipLaunchKernelGGL(blob_square_kernel, dim3((unsigned)(a.n_images * groups)), dim3(kBlobThreads), 0, stream, a);
+  hipLaunchKernelGGL(blob_activity_kernel, dim3((unsigned)(a.n_images * groups)), dim3(kBlobThreads), 0, stream, a);
   return hipGetLastError();
 }
 
@@ -185,10 +164,12 @@ __global__ __launch_bounds__(kBlobThreads) void blob_mask_kernel(BlobArgs a) {
   const int tile = blockIdx.x % (tiles * tiles);
   const int ty0 = (tile / tiles) * BT, tx0 = (tile % tiles) * BT;
   const int cam = (int)((a.img_base + img) % a.C);
-  const int WP = S + 2 * kSquarePad;
-  const uint8_t* sq = a.squared + (size_t)img * (S + 2) * WP * 3;
-  const uint32_t* tab = a.gather + ((size_t)a.cam_lens[cam] * tiles * tiles + tile) * kBlobGather;
-  const uint8_t* sq_below = sq + (size_t)WP * 3;  // the row under a tap
+  // the gather reads the RAW frame: rot90 / make_square (feathered rows, zero padding) are folded into the table
+  // (interior taps: plain offsets; the few taps on feathered / zero rows or at the frame's edge: a fix-up list)
+  const uint8_t* sq = a.raw + (size_t)img * a.rows * a.cols * 3;
+  const size_t lt = (size_t)a.cam_lens[cam] * tiles * tiles + tile;
+  const uint32_t* tab = a.gather + lt * kBlobGather;
+  const uint8_t* sq_below = sq + (size_t)a.cols * 3;  // the raw row under a tap
   const int words = (S + 63) / 64;
   unsigned long long* mask = a.mask + (size_t)img * S * words;
 
@@ -198,7 +179,7 @@ __global__ __launch_bounds__(kBlobThreads) void blob_mask_kernel(BlobArgs a) {
   // weights summing to 20, so its output is at most 20 (M - m); grey is a convex combination of the three
   // channels.  M - m <= 2  =>  grey <= 40 < 52: no mask bit can be set.
   if (a.skip_dark && !a.processed) {
-    const int16_t* box = a.tile_box + ((size_t)a.cam_lens[cam] * tiles * tiles + tile) * 4;
+    const int16_t* box = a.tile_box + lt * 4;
     const int b0 = box[0], b1 = box[1], s0 = box[2], s1 = box[3];
     if (b0 >= 0) {
       const int segs = a.cols * 3 / 16, bands = (a.rows + 16 + kSquareRows - 1) / kSquareRows;
@@ -224,7 +205,7 @@ __global__ __launch_bounds__(kBlobThreads) void blob_mask_kernel(BlobArgs a) {
       lo = min(min(red[0][0], red[0][1]), min(red[0][2], red[0][3]));
       hi = max(max(red[1][0], red[1][1]), max(red[1][2], red[1][3]));
       // a box that reaches into the zero rows / zero frame of the squared layout (host flag) also sees 0
-      if (hi <= (a.tile_zero[(size_t)a.cam_lens[cam] * tiles * tiles + tile] ? 0u : lo) + 2u) {
+      if (hi <= (a.tile_zero[lt] ? 0u : lo) + 2u) {
         for (int y = tid; y < BT; y += kBlobThreads)
           if (ty0 + y < S) mask[(size_t)(ty0 + y) * words + tx0 / 64] = 0ull;
         return;
@@ -248,7 +229,8 @@ __global__ __launch_bounds__(kBlobThreads) void blob_mask_kernel(BlobArgs a) {
 #pragma unroll
     for (int k = 0; k < CH; k++)
       if (base / kBlobThreads + k < kIters) {
-        const uint32_t off = mm[k] & 0x3fffffu;  // the same 32-bit lane offset against two uniform row bases
+        uint32_t off = mm[k] & 0x3fffffu;  // the same 32-bit lane offset against two uniform row bases
+        off = off == 0x3fffffu ? 0u : off;  // "zero or fixed up later": any valid address will do
         __builtin_memcpy(&tt[k], sq + off, 8);
         __builtin_memcpy(&bb[k], sq_below + off, 8);
       }
@@ -265,15 +247,44 @@ __global__ __launch_bounds__(kBlobThreads) void blob_mask_kernel(BlobArgs a) {
         const uint32_t t_g = gx * ((tl >> 8) & 0xffu) + fx * (th & 0xffu);
         const uint32_t b_rb = gx * (bl & 0x00ff00ffu) + fx * __builtin_amdgcn_perm(bh, bl, 0x0c050c03u);
         const uint32_t b_g = gx * ((bl >> 8) & 0xffu) + fx * (bh & 0xffu);
-        const uint32_t o_r = (gy * (t_rb & 0xffffu) + fy * (b_rb & 0xffffu) + 512u) >> 10;
-        const uint32_t o_g = (gy * t_g + fy * b_g + 512u) >> 10;
-        const uint32_t o_b = (gy * (t_rb >> 16) + fy * (b_rb >> 16) + 512u) >> 10;
+        const bool zero = (mm[k] & 0x3fffffu) == 0x3fffffu;
+        const uint32_t o_r = zero ? 0u : (gy * (t_rb & 0xffffu) + fy * (b_rb & 0xffffu) + 512u) >> 10;
+        const uint32_t o_g = zero ? 0u : (gy * t_g + fy * b_g + 512u) >> 10;
+        const uint32_t o_b = zero ? 0u : (gy * (t_rb >> 16) + fy * (b_rb >> 16) + 512u) >> 10;
         if (idx < kBlobRegion) {
           U[0][idx] = (uint8_t)o_r;
           U[1][idx] = (uint8_t)o_g;
           U[2][idx] = (uint8_t)o_b;
         }
       }
+  }
+  {
+    // fix-ups: region pixels with a tap on a feathered row (edge row * (7 - i) / 8, truncated per byte), on a zero
+    // row / outside the frame's columns, or too close to the end of the image for the 8-byte loads above.  Each
+    // record names its four taps individually {raw byte offset | scale << 22, scale 0 = zero pixel} and keeps the
+    // map's own fractions, so rotation needs no special case here.
+    const int n_fix = a.fix_cnt[lt];
+    if (n_fix) {
+      __syncthreads();
+      const uint32_t* rec = a.fix_rec + (size_t)a.fix_off[lt] * 5;
+      for (int i = tid; i < n_fix; i += kBlobThreads) {
+        const uint32_t w0 = rec[5 * i];
+        const uint32_t idx = w0 & 0xffffu, fx = (w0 >> 16) & 31u, fy = (w0 >> 24) & 31u, gx = 32u - fx, gy = 32u - fy;
+        uint32_t px[4][3];
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+          const uint32_t d = rec[5 * i + 1 + t], sc = (d >> 22) & 15u;
+          const uint8_t* p = sq + (d & 0x3fffffu);
+#pragma unroll
+          for (int c = 0; c < 3; c++) px[t][c] = sc ? ((uint32_t)p[c] * sc) >> 3 : 0u;
+        }
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+          const uint32_t top = gx * px[0][c] + fx * px[1][c], bot = gx * px[2][c] + fx * px[3][c];
+          U[c][idx] = (uint8_t)((gy * top + fy * bot + 512u) >> 10);
+        }
+      }
+    }
   }
   __syncthreads();
 

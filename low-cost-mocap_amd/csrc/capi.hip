@@ -109,7 +109,8 @@ extern "C" void mocap_destroy(mocap_ctx* ctx) {
   ctx->img_stage.release();
   ctx->img_tiles.release();
   ctx->img_lens.release();
-  ctx->img_sq.release();
+  ctx->img_fix.release();
+  ctx->img_fixidx.release();
   ctx->img_act.release();
   ctx->img_box.release();
   ctx->img_zero.release();

@@ -51,9 +51,9 @@ struct mocap_ctx {
   bool world_on = false;
   // blob extraction (mocap_set_image_params): frame geometry, undistortion maps, mask workspace
   int img_C = 0, img_rows = 0, img_cols = 0, img_S = 0, img_ay = 0;
-  DevBuf img_map, img_rot, img_mask, img_stage, img_tiles, img_lens, img_sq, img_act, img_box, img_zero;
+  DevBuf img_map, img_rot, img_mask, img_stage, img_tiles, img_lens, img_fix, img_fixidx, img_act, img_box, img_zero;
+  int img_n_lt = 0;           // (lens, rotation) x tiles: entries of the fix-up index
   int blob_skip_dark = 1;     // exact early-out for tiles whose source bytes span a range <= 2 (mocap_set_blob_options)
-  int64_t img_sq_images = 0;  // squared frames the workspace holds (zero frame already set)
   DevBuf compact_ws;        // block totals of the track-compaction scan
   DevBuf frame_ws;          // wide-frame workspace: [workgroup][hit lists | group columns | ...]
   DevBuf scratch[4];        // [0] host-API staging, [1..3] bundle adjustment workspace

@@ -98,10 +98,9 @@ constexpr int kBlobTile = 64;  // output tile edge of blob_mask_kernel
 constexpr int kBlobHalo = 6;   // 4 (9x9 Gaussian) + 2 (5x5 filter)
 constexpr int kBlobRegion = (kBlobTile + 2 * kBlobHalo) * (kBlobTile + 2 * kBlobHalo);  // 5776 region pixels per tile
 constexpr int kBlobGather = ((kBlobRegion + 255) / 256) * 256;  // gather-table entries per tile (padded to 256)
-constexpr int kSquareRows = 16;  // squared rows per workgroup of the pre-pass = one band of the activity map
+constexpr int kSquareRows = 16;  // squared rows per workgroup of the activity pass = one band of the activity map
 constexpr int kBlobMaxEdge = 832;  // widest frame: contour tables + padded mask must fit 160 KB of LDS
 constexpr int kBlobActSlots = (kBlobMaxEdge * 3 / 16 + 63) / 64;  // 16-byte row segments per pre-pass lane (3)
-constexpr int kSquarePad = 16;  // zero pixels left and right of a squared-frame row (keeps rows 16-byte aligned)
 struct BlobArgs {
   int64_t n_images;        // images of this launch; camera = (img_base + image) % C
   int64_t img_base;        // index of the launch's first image in the caller's batch
@@ -110,14 +109,17 @@ struct BlobArgs {
   int M_max;
   const uint8_t* raw;      // [n_images][rows][cols][3] RGB
   const int32_t* rot;      // [C] quarter turns (0 or 2)
-  // squared frames (helpers.py:507-523) with a zero frame around them: [n_images][S + 2][S + 2 * kSquarePad][3];
-  // only the frame and feather rows are rewritten per image, everything else stays zero
-  uint8_t* squared;
-  // per (distinct lens, tile): for each pixel of the tile's 76 x 76 region (reflect-101 already applied)
-  // byte offset of the top-left tap in a squared frame | fx << 22 | fy << 27
+  // per (distinct lens and rotation, tile): for each pixel of the tile's 76 x 76 region (reflect-101 already applied)
+  // byte offset of the first tap pair in the RAW frame | fx << 22 | fy << 27 (fractions already swapped for
+  // rotated cameras); offset 0x3fffff = zero pixel, or a pixel the fix-up list overwrites
   const uint32_t* gather;
+  // fix-up list of (lens, tile) lt: fix_cnt[lt] records of 5 words from fix_rec[5 * fix_off[lt]]:
+  // {region index | fx << 16 | fy << 24, tap TL, TR, BL, BR = raw byte offset | scale << 22 (0 = zero pixel)}
+  const uint32_t* fix_rec;
+  const int32_t* fix_off;
+  const int32_t* fix_cnt;
   const int32_t* cam_lens;   // [C] index of the camera's lens table
-  // dark-tile early-out (exact): the pre-pass records min / max of the raw bytes per (16-row band, 16-byte
+  // dark-tile early-out (exact): the activity pass records min / max of the squared frame's bytes per (16-row band, 16-byte
   // segment); a tile whose source bounding box spans a value range <= 2 cannot produce a set mask bit
   uint8_t* activity;         // [n_images][bands][segs][2] (min, max); bands = ceil((rows + 16) / 16), segs = cols * 3 / 16
   const int16_t* tile_box;   // [lens][tiles^2][4]: first band, last band, first segment, last segment; band < 0 = never skip
@@ -130,7 +132,7 @@ struct BlobArgs {
   int32_t* status;         // [n_images]
   int32_t* n_contours;     // [n_images] or null
 };
-hipError_t launch_blob_square(const BlobArgs& a, hipStream_t stream);
+hipError_t launch_blob_activity(const BlobArgs& a, hipStream_t stream);
 hipError_t launch_blob_mask(const BlobArgs& a, hipStream_t stream);
 hipError_t launch_blob_contours(const BlobArgs& a, int P_cap, int N_cap, int only_overflowed, hipStream_t stream);
 size_t blob_contour_lds_bytes(int S, int P_cap, int N_cap);
