@@ -87,7 +87,7 @@ __global__ __launch_bounds__(kBlobThreads) void blob_activity_kernel(BlobArgs a)
     mn[j] = 0x00ff00ffu;
     mx[j] = 0u;
   }
-  if (rot == 0) {
+  {
 #pragma unroll
     for (int k = 0; k < kSquareRows / 4; k++) {
       const int Y = first + grp * kSquareRows + wave * (kSquareRows / 4) + k;
@@ -100,8 +100,9 @@ __global__ __launch_bounds__(kBlobThreads) void blob_activity_kernel(BlobArgs a)
         scale = 7 - (r - a.rows);
         r = a.rows - 1;
       }
-      // 16 bytes per lane: rows start 16-byte aligned (cols % 16 == 0 checked by the host)
-      const uint8_t* src = raw + (size_t)r * row_bytes;
+      // 16 bytes per lane: rows start 16-byte aligned (cols % 16 == 0 checked by the host).  A camera turned by
+      // 180 degrees reads the mirrored row; its segments are mirrored when the map is written below.
+      const uint8_t* src = raw + (size_t)(rot ? a.rows - 1 - r : r) * row_bytes;
 #pragma unroll
       for (int j = 0; j < kActSlots; j++) {
         const int i = (j * 64 + lane) * 16;
@@ -120,12 +121,6 @@ __global__ __launch_bounds__(kBlobThreads) void blob_activity_kernel(BlobArgs a)
         }
       }
     }
-  } else {
-#pragma unroll
-    for (int j = 0; j < kActSlots; j++) {  // rotated cameras: no activity summary -> "full range", their tiles are never skipped
-      mn[j] = 0u;
-      mx[j] = 0x00ff00ffu;
-    }
   }
 #pragma unroll
   for (int j = 0; j < kActSlots; j++) {
@@ -135,11 +130,21 @@ __global__ __launch_bounds__(kBlobThreads) void blob_activity_kernel(BlobArgs a)
   __syncthreads();
   const int segs = row_bytes / 16;
   for (int sg = threadIdx.x; sg < segs; sg += kBlobThreads) {
-    uint32_t l = 255u, h = 0u;
-    for (int w2 = 0; w2 < 4; w2++) {
-      l = min(l, act[w2][sg] & 0xffu);
-      h = max(h, act[w2][sg] >> 8);
+    // segment sg of the SQUARED row = bytes [16 sg, 16 sg + 16) = pixels X0 .. X1; for a rotated camera those are
+    // the raw pixels cols-1-X1 .. cols-1-X0, i.e. a byte range that up to three raw segments cover (a superset of
+    // the bytes is a valid bound: the early-out only ever skips less)
+    int r0 = sg, r1 = sg;
+    if (rot) {
+      const int X0 = 16 * sg / 3, X1 = min((16 * sg + 15) / 3, a.cols - 1);
+      r0 = 3 * (a.cols - 1 - X1) / 16;
+      r1 = (3 * (a.cols - 1 - X0) + 2) / 16;
     }
+    uint32_t l = 255u, h = 0u;
+    for (int rs = r0; rs <= r1; rs++)
+      for (int w2 = 0; w2 < 4; w2++) {
+        l = min(l, act[w2][rs] & 0xffu);
+        h = max(h, act[w2][rs] >> 8);
+      }
     uint8_t* o = a.activity + (((size_t)img * groups + grp) * segs + sg) * 2;
     o[0] = (uint8_t)l;
     o[1] = (uint8_t)h;
