@@ -216,7 +216,7 @@ struct FrameState {
 
   // ---------------------------------------------------------------- phases A-C
   // Leaves roots / hit lists / candidate offsets in LDS; returns with all lanes synchronised.
-  __device__ void match(int64_t frame) {
+  __device__ void match(int64_t frame, int skip = 0 /* timing experiments: 1 = no table build, 2 = no camera loop */) {
     {
       const float2* src = (const float2*)(p.blobs + (size_t)frame * C * M * 2);
       if (WIDE) {
@@ -231,7 +231,7 @@ struct FrameState {
       if (tid == 0) misc[MI_STATUS] = 0;
     }
     __syncthreads();
-    if (TABLE) {
+    if (TABLE && !(skip & 1)) {
       // DLT contribution of every blob, once per frame: a candidate group then ADDS ten doubles per view
       // instead of rebuilding two rows of A and their outer products (the Cartesian product revisits every
       // blob thousands of times)
@@ -266,7 +266,7 @@ struct FrameState {
     while ((1 << gs_shift) < M) gs_shift++;
     const bool fused = !WIDE && gs_shift <= 6;
 
-    for (int i = 1; i < C; i++) {
+    for (int i = 1; i < ((skip & 2) ? 1 : C); i++) {
       const int Mi = cnt[i];
       const float2* pts = bxy + (size_t)i * M;
       // B1 (wave 0, which also owns B5: no workgroup barrier between B5 of camera i-1 and this):
@@ -825,6 +825,12 @@ __global__ __launch_bounds__(T, MOCAP_FRAME_WAVES_PER_EU) void frame_kernel(Fram
         sl = item - base;
       }
       st.match(frame);
+#ifdef MOCAP_DEBUG_DOUBLE_MATCH  // timing experiments only: what phases A-C cost INSIDE the mix: an extra, possibly
+      __syncthreads();             // partial (skip mask = the macro's value) pass before the real one is repeated
+      st.match(frame, MOCAP_DEBUG_DOUBLE_MATCH);
+      __syncthreads();
+      st.match(frame);
+#endif
       const uint32_t G = (uint32_t)st.misc[MI_G];
       if (kind == 1) {
         if (tid == 0) {
