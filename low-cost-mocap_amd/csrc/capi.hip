@@ -490,26 +490,43 @@ static int match_dev_locked(mocap_ctx* ctx, int64_t n_frames, int M_max, const f
   q.W_cap = (int)(H * 8 < 64 ? 64 : H * 8);
   auto al = [](size_t x) { return (x + 255) / 256 * 256; };
   const size_t b_cnt = al(sizeof(int32_t) * QC_COUNT), b_heavy = al(sizeof(int32_t) * 4 * (size_t)q.H_cap),
-               b_slice = al(sizeof(int32_t) * (size_t)q.W_cap), b_pe = al(sizeof(double) * (size_t)q.W_cap * K_max),
+               b_slice = al(sizeof(int32_t) * (size_t)q.W_cap), b_gen = b_slice, b_pe = al(sizeof(double) * (size_t)q.W_cap * K_max),
                b_pg = al(sizeof(uint32_t) * (size_t)q.W_cap * K_max), b_px = al(sizeof(double) * 3 * (size_t)q.W_cap * K_max);
   DevBuf& wq = ctx->scratch[3];
-  if (wq.reserve(b_cnt + b_heavy + b_slice + b_pe + b_pg + b_px))
+  const void* wq_before = wq.ptr;
+  if (wq.reserve(b_cnt + b_heavy + b_slice + b_gen + b_pe + b_pg + b_px))
     return ctx->fail(MOCAP_E_HIP, "hipMalloc(frame work queues) failed");
+  const bool one_launch = ctx->frame_launches != 3;
+  // one-launch schedule: the kernel leaves the counters at zero and slices carry a launch generation, so the queue
+  // needs clearing only when the buffer is new, the layout moved, or the other schedule used it last
+  const bool fresh = wq.ptr != wq_before || ctx->frame_q_cap != q.W_cap || !ctx->frame_q_clean;
   char* w = (char*)wq.ptr;
   q.counters = (int32_t*)w;     w += b_cnt;
   q.slice_heavy = (int32_t*)w;  w += b_slice;
+  q.slice_gen = (int32_t*)w;    w += b_gen;
+  q.gen = ++ctx->frame_gen;
+  if (ctx->frame_gen == 0x7fffffff) {  // generation wrap: start over from a cleared queue
+    ctx->frame_gen = 0;
+    ctx->frame_q_clean = false;
+  }
   q.heavy = (int32_t*)w;        w += b_heavy;
   q.part_e = (double*)w;        w += b_pe;
   q.part_g = (uint32_t*)w;      w += b_pg;
   q.part_x = (double*)w;
-  HIP_TRY(ctx, hipMemsetAsync(q.counters, 0, b_cnt, ctx->stream));
-  if (q.heavy_threshold) HIP_TRY(ctx, hipMemsetAsync(q.slice_heavy, 0xFF, b_slice, ctx->stream));
-  if (ctx->frame_launches != 3) {
+  if (!one_launch || fresh) {
+    HIP_TRY(ctx, hipMemsetAsync(q.counters, 0, b_cnt, ctx->stream));
+    if (q.heavy_threshold) HIP_TRY(ctx, hipMemsetAsync(q.slice_heavy, 0xFF, b_slice, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(q.slice_gen, 0, b_gen, ctx->stream));
+  }
+  ctx->frame_q_cap = q.W_cap;
+  ctx->frame_q_clean = false;  // until the launch below is known to be queued
+  if (one_launch) {
     // one launch: frames, then slices of the heavy frames, merged by the workgroup that finishes a frame's last slice.
     // Few frames (live calls): still enough workgroups for a heavy frame's slices to run side by side.
     int64_t g1 = n_frames + (q.heavy_threshold ? 64 : 0);
     if (g1 > full_grid) g1 = full_grid;
     HIP_TRY(ctx, launch_frame_kernel(a, MODE_ALL, T, (int)g1, ctx->stream));
+    ctx->frame_q_clean = true;
     return MOCAP_OK;
   }
   HIP_TRY(ctx, launch_frame_kernel(a, MODE_MAIN, T, (int)grid, ctx->stream));

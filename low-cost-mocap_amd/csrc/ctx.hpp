@@ -23,6 +23,9 @@ struct mocap_ctx {
   int slice_size = 0;       // 0 = automatic (MOCAP_SLICE_SIZE)
   int hit_cap = 16;         // wide frames: hits kept per (root, camera) (mocap_set_frame_limits)
   int force_wide = 0;       // route every frame batch through the wide (HBM workspace) variant
+  int32_t frame_gen = 0;    // generation of the last frame-path launch (tags the slices it publishes)
+  int frame_q_cap = 0;      // W_cap the work-queue buffer was laid out for
+  bool frame_q_clean = false;  // the queue counters were left at zero by the one-launch schedule
   int frame_launches = 1;   // 1: one persistent launch per batch (MODE_ALL); 3: main / slice / merge launches
   int prune = 1;            // stop a candidate group's reprojection once it cannot beat its root's best (exact)
   hipStream_t own_stream = nullptr, stream = nullptr;

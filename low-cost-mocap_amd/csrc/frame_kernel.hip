@@ -789,7 +789,7 @@ __global__ __launch_bounds__(T, MOCAP_FRAME_WAVES_PER_EU) void frame_kernel(Fram
         if (!kind && q.heavy_threshold) {
           const int s = q_add(&q.counters[QC_NEXT_SLICE], 1);
           while (s < q.W_cap) {
-            if (q_load(&q.slice_heavy[s]) >= 0) {
+            if (q_load(&q.slice_gen[s]) == q.gen) {
               kind = 2;
               item = s;
               break;
@@ -797,7 +797,7 @@ __global__ __launch_bounds__(T, MOCAP_FRAME_WAVES_PER_EU) void frame_kernel(Fram
             // a producer publishes its slices BEFORE it counts its frame as done: once every frame is done, an
             // unpublished ticket will never be published (and neither will any later one)
             if (q_load(&q.counters[QC_FRAMES_DONE]) >= (int)p.n_frames) {
-              if (q_load(&q.slice_heavy[s]) >= 0) {
+              if (q_load(&q.slice_gen[s]) == q.gen) {
                 kind = 2;
                 item = s;
               }
@@ -812,7 +812,12 @@ __global__ __launch_bounds__(T, MOCAP_FRAME_WAVES_PER_EU) void frame_kernel(Fram
       __syncthreads();
       const int item = st.misc[MI_ITEM], kind = st.misc[MI_KIND];
       __syncthreads();  // every lane has read the slots before lane 0 can overwrite them
-      if (!kind) break;
+      if (!kind) {
+        // the last workgroup to leave puts the queue counters back to zero: the next launch needs no memset
+        if (tid == 0 && q_add(&q.counters[QC_EXITED], 1) == (int)gridDim.x - 1)
+          for (int c = 0; c < QC_COUNT; c++) q_store(&q.counters[c], 0);
+        break;
+      }
       // one code path for both kinds of item (a single inlined copy of match() and evaluate(): frame and slice
       // workgroups share the CU's instruction cache)
       int64_t frame = item;
@@ -846,8 +851,9 @@ __global__ __launch_bounds__(T, MOCAP_FRAME_WAVES_PER_EU) void frame_kernel(Fram
                 q_store(&q.heavy[4 * hn + 1], bn);
                 q_store(&q.heavy[4 * hn + 2], (int32_t)Sn);
                 q_store(&q.heavy[4 * hn + 3], 0);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the entry is in memory before its tickets become valid
                 for (uint32_t s = 0; s < Sn; s++) q_store(&q.slice_heavy[bn + s], hn);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the entries are in memory before their tickets become valid
+                for (uint32_t s = 0; s < Sn; s++) q_store(&q.slice_gen[bn + s], q.gen);
                 defer = 1;
               }
             }

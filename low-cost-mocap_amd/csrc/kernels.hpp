@@ -14,11 +14,13 @@ constexpr int MOCAP_ST_HIT_OVERFLOW_ = 4;
 
 // device-side work queues of the frame path (see the scheduling note in frame_kernel.hip)
 constexpr int MODE_MAIN = 0, MODE_SLICE = 1, MODE_MERGE = 2, MODE_ALL = 3;
-enum { QC_NEXT_FRAME = 0, QC_N_HEAVY = 1, QC_N_SLICES = 2, QC_NEXT_SLICE = 3, QC_NEXT_MERGE = 4, QC_FRAMES_DONE = 5, QC_COUNT = 8 };
+enum { QC_NEXT_FRAME = 0, QC_N_HEAVY = 1, QC_N_SLICES = 2, QC_NEXT_SLICE = 3, QC_NEXT_MERGE = 4, QC_FRAMES_DONE = 5, QC_EXITED = 6, QC_COUNT = 8 };
 struct FrameQueues {
   int32_t* counters;     // [QC_COUNT], zeroed before every batch
   int32_t* heavy;        // [H_cap][4]: frame (or -1), first slice id, slice count, slices finished (MODE_ALL)
   int32_t* slice_heavy;  // [W_cap]: heavy-list index of each slice id (-1 = unused)
+  int32_t* slice_gen;    // [W_cap] MODE_ALL: slice id s is published for this launch when slice_gen[s] == gen
+  int32_t gen;           // launch generation (no per-launch memset of the queue: the counters clean themselves)
   double* part_e;        // [W_cap][K_max]     per-slice, per-root partial winners
   uint32_t* part_g;      // [W_cap][K_max]
   double* part_x;        // [W_cap][K_max][3]
