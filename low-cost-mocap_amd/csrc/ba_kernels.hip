@@ -380,6 +380,7 @@ hipError_t launch_ba_gram_cost(const double* Jaug, int64_t m_pad, int NP, double
 // dependent loads of lines another XCD just wrote is ~3 us; a spilled register reloaded inside a loop ~1 us --
 // so: few, fat workgroups, one fence each, as few dependent rounds as possible.  Counters return to zero inside
 // the launch (no memset between launches).
+constexpr int kFusedFan = 16;  // records per node of the reduction tree
 constexpr int kFusedWaves = 8, kFusedThreads = 64 * kFusedWaves;  // one parameter set per wave (A/B at 8 x 1 000: 4 waves 29.9 us, 8 waves 26.2, 16 waves 29.4 per launch)
 
 // Cross-workgroup hand-off inside the launch (MI355X_MICROARCH.md, rows handoff-flag / publish-large): payload
@@ -623,58 +624,77 @@ __global__ __launch_bounds__(kFusedThreads) void ba_fused_kernel(BaFusedArgs a) 
       }
   }
   if (a.debug_stop == 6) return;
-  // ---- who finishes the batch?
-  drain_stores();
-  __syncthreads();
-  if (tid == 0)
-    sh_last = __hip_atomic_fetch_add(&a.counters[a.chunks], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.chunks - 1;
-  __syncthreads();
-  if (!sh_last) return;
-  if (tid == 0) __hip_atomic_store(&a.counters[a.chunks], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (a.debug_stop == 7) return;
-  // ---- phase 4: G = sum of the chunks' partials in chunk order -> pinned host memory (packed upper triangle of
-  // the leading (n+1) x (n+1) block; the host unpacks and mirrors it)
+  // ---- phase 4: tree of "last arriver" reductions, 16 records per node, summed in record order (fixed order ->
+  // bit-reproducible whichever workgroup is last).  1 000 points = 16 chunks = one node: its last arriver writes G
+  // (packed upper triangle of the leading (n+1) x (n+1) block; the host unpacks and mirrors it), the cost and the stamp
+  // into pinned host memory.  16 000 points = 250 chunks = 16 nodes + a root: a single workgroup adding 250 records
+  // would be bandwidth-bound for ~40 us (a workgroup reads fresh cross-XCD lines at ~65 GB/s).
   {
-    const double* __restrict__ part = a.partial;
-    double* __restrict__ gout = a.out;
-    constexpr int EPT = 4;  // packed elements per thread and round: 4 x 16 chunks = 64 loads in flight
-    for (int e0 = tid; e0 < tri_n; e0 += EPT * kFusedThreads) {
-      double sum[EPT];
-#pragma unroll
-      for (int t = 0; t < EPT; t++) sum[t] = 0.0;
-      for (int k0 = 0; k0 < a.chunks; k0 += 16) {
-        double v[EPT][16];
+    int units = a.chunks, my = chunk;
+    size_t rec_base = 0, cnt_base = (size_t)a.chunks;  // records / counters of the current level
+    while (true) {
+      const int nodes = (units + kFusedFan - 1) / kFusedFan, node = my / kFusedFan;
+      const int first = node * kFusedFan, cnt = min(kFusedFan, units - first);
+      drain_stores();
+      __syncthreads();
+      if (tid == 0) {
+        sh_last = __hip_atomic_fetch_add(&a.counters[cnt_base + node], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == cnt - 1;
+        if (sh_last) __hip_atomic_store(&a.counters[cnt_base + node], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __syncthreads();
+      if (!sh_last) return;
+      if (a.debug_stop == 7) return;
+      const bool top = nodes == 1;
+      const double* __restrict__ part = a.partial + (rec_base + first) * tri_n;
+      double* __restrict__ dst = top ? a.out : a.partial + (rec_base + units + node) * tri_n;
+      constexpr int EPT = 4;  // packed elements per thread and round: 4 x 16 records = 64 loads in flight
+      for (int e0 = tid; e0 < tri_n; e0 += EPT * kFusedThreads) {
+        double sum[EPT];
+        double v[EPT][kFusedFan];
 #pragma unroll
         for (int t = 0; t < EPT; t++)
 #pragma unroll
-          for (int q = 0; q < 16; q++)
-            v[t][q] = (e0 + t * kFusedThreads < tri_n && k0 + q < a.chunks)
-                          ? ld_agent(&part[(size_t)(k0 + q) * tri_n + e0 + t * kFusedThreads]) : 0.0;
+          for (int q = 0; q < kFusedFan; q++)
+            v[t][q] = (e0 + t * kFusedThreads < tri_n && q < cnt) ? ld_agent(&part[(size_t)q * tri_n + e0 + t * kFusedThreads]) : 0.0;
+#pragma unroll
+        for (int t = 0; t < EPT; t++) {
+          sum[t] = 0.0;
+#pragma unroll
+          for (int q = 0; q < kFusedFan; q++)
+            if (q < cnt) sum[t] += v[t][q];  // record order
+        }
 #pragma unroll
         for (int t = 0; t < EPT; t++)
-#pragma unroll
-          for (int q = 0; q < 16; q++)
-            if (k0 + q < a.chunks) sum[t] += v[t][q];  // chunk order
+          if (e0 + t * kFusedThreads < tri_n) {
+            if (top)
+              dst[e0 + t * kFusedThreads] = sum[t];  // pinned host memory
+            else
+              st_agent(&dst[e0 + t * kFusedThreads], sum[t]);
+          }
       }
-#pragma unroll
-      for (int t = 0; t < EPT; t++)
-        if (e0 + t * kFusedThreads < tri_n) gout[e0 + t * kFusedThreads] = sum[t];  // packed; the host unpacks
-    }
-    // cost: chunk sums added by 64 lanes with stride 64, then a fixed tree
-    if (wave == 0) {
-      double c = 0.0, fin = 1.0;
-      for (int k = lane; k < a.chunks; k += 64) {
-        c += ld_agent(&a.cost_part[2 * k]);
-        fin = fmin(fin, ld_agent(&a.cost_part[2 * k + 1]));
+      // cost of the node: its records' sums in order, all-finite flag
+      if (wave == 0) {
+        const double* cp = a.cost_part + 2 * (rec_base + first);
+        double c = lane < cnt ? ld_agent(&cp[2 * lane]) : 0.0;
+        double fin = lane < cnt ? ld_agent(&cp[2 * lane + 1]) : 1.0;
+        double acc = 0.0;
+        for (int q = 0; q < cnt; q++) acc += __shfl(c, q);  // in record order
+        for (int o = 8; o > 0; o >>= 1) fin = fmin(fin, __shfl_down(fin, o));
+        if (lane == 0) {
+          if (top) {
+            sh_red[0] = 0.5 * acc;
+            sh_red[1] = fin;
+          } else {
+            st_agent(&a.cost_part[2 * (rec_base + units + node)], acc);
+            st_agent(&a.cost_part[2 * (rec_base + units + node) + 1], fin);
+          }
+        }
       }
-      for (int o = 32; o > 0; o >>= 1) {
-        c += __shfl_down(c, o);
-        fin = fmin(fin, __shfl_down(fin, o));
-      }
-      if (lane == 0) {
-        sh_red[0] = 0.5 * c;
-        sh_red[1] = fin;
-      }
+      if (top) break;
+      rec_base += units;
+      cnt_base += nodes;
+      units = nodes;
+      my = node;
     }
   }
   // every wave waits for its own stores (workgroup-scope release), one thread publishes to the host
@@ -689,6 +709,17 @@ __global__ __launch_bounds__(kFusedThreads) void ba_fused_kernel(BaFusedArgs a) 
   }
 }
 
+// records (Gram partials, cost pairs) and counters of the reduction tree over `chunks` leaves
+size_t ba_fused_records(int chunks) {
+  size_t total = 0;
+  for (int u = chunks; ; u = (u + kFusedFan - 1) / kFusedFan) {
+    total += (size_t)u;
+    if (u <= kFusedFan) break;
+  }
+  return total;
+}
+size_t ba_fused_counters(int chunks) { return ba_fused_records(chunks) + 1; }
+
 size_t ba_fused_lds_bytes(int C, int NP, bool uniformK) {
   const size_t set_stride = (size_t)12 * C + (uniformK ? (size_t)12 * C : (size_t)12 * C * C);
   const size_t tabs = (kFusedWaves * set_stride + (size_t)64 * C * 2) * sizeof(double),
@@ -697,7 +728,6 @@ size_t ba_fused_lds_bytes(int C, int NP, bool uniformK) {
 }
 
 int ba_fused_groups(int C) { return (1 + 6 * (C - 1) + kFusedWaves - 1) / kFusedWaves; }
-int ba_fused_owners(int chunks) { return chunks; }
 
 bool ba_fused_eligible(int C, int n, int NP, bool uniformK) {
   return n <= 127 && ba_fused_lds_bytes(C, NP, uniformK) <= 150 * 1024;

@@ -322,18 +322,17 @@ int ba_setup(mocap_ctx* ctx, BaWork& w, int64_t N, const double* obs, int Pmax, 
   w.d_valid = (int32_t*)ctx->scratch[2].ptr;
   // one launch per linearisation when the rig fits the fused kernel's LDS budget (MOCAP_BA_UNFUSED=1: the chain
   // of five launches it replaces, kept as the fallback for large rigs and for A/B measurements)
-  // Up to 2 048 points: beyond that the chain's kernels fill the GPU and the fused kernel's last workgroup (which
-  // adds one partial per 64 rows) becomes the longer path (measured at 16 000 points: 225 vs 150 us per iteration;
-  // at 1 000 points 62.9 vs 65.0).
-  w.fused = ba_fused_eligible(C, w.n, w.NP, w.uniformK != 0) && !getenv("MOCAP_BA_UNFUSED") &&
-            (N <= 2048 || getenv("MOCAP_BA_FUSED"));
+  // Any point count: the Gram partials are added by a 16-ary tree of last-arriver workgroups, so the serial tail
+  // stays at two short sums (measured per iteration, fused vs chain: 41 vs 58 us at 1 000 points, 97 vs 147 us at
+  // 16 000 points).
+  w.fused = ba_fused_eligible(C, w.n, w.NP, w.uniformK != 0) && !getenv("MOCAP_BA_UNFUSED");
   size_t nd_fout = 0;
   if (w.fused) {
     w.chunks = (int)((N + 63) / 64);
     w.groups = ba_fused_groups(C);
-    const int owners = ba_fused_owners(w.chunks);
-    const size_t nd_fp = al((size_t)owners * ((size_t)(w.n + 1) * (w.n + 2) / 2)), nd_fc = al((size_t)owners * 2),
-                 nd_cnt = al((size_t)(owners + 1) / 2 + 1), nd_fJ = want_jaug ? al((size_t)N * w.NP) : 0, nd_mail = al(2 + 128);
+    const size_t recs = ba_fused_records(w.chunks);
+    const size_t nd_fp = al(recs * ((size_t)(w.n + 1) * (w.n + 2) / 2)), nd_fc = al(recs * 2),
+                 nd_cnt = al(ba_fused_counters(w.chunks) / 2 + 1), nd_fJ = want_jaug ? al((size_t)N * w.NP) : 0, nd_mail = al(2 + 128);
     if (ctx->ba_fused.reserve((nd_fp + nd_fc + nd_cnt + nd_mail + nd_fJ) * sizeof(double)))
       return ctx->fail(MOCAP_E_HIP, "hipMalloc(BA fused workspace) failed");
     double* q = (double*)ctx->ba_fused.ptr;

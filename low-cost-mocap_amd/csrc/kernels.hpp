@@ -210,16 +210,17 @@ struct BaFusedArgs {
   const double* K4;      // [j][4]
   const double* obs;     // [N][C][2]
   double* r;             // [n+1][N] residuals
-  double* partial;       // [chunks][(n+1)(n+2)/2] packed upper triangle of each chunk's Gram matrix
-  double* cost_part;     // [chunks][2] (sum of loss values, all-finite flag)
-  int32_t* counters;     // [chunks + 1], zero on entry and on exit
+  double* partial;       // [ba_fused_records][(n+1)(n+2)/2] packed upper triangle of each chunk's / tree node's Gram matrix
+  double* cost_part;     // [ba_fused_records][2] (sum of loss values, all-finite flag)
+  int32_t* counters;     // [ba_fused_counters], zero on entry and on exit
   double* Jaug_out;      // null, or [N][NP]: the rows of Jaug by point index (tests)
   double* out;           // pinned host memory [NP*NP + 3]: packed upper triangle of G ... | cost | finite | stamp (last 3)
 };
 size_t ba_fused_lds_bytes(int C, int NP, bool uniformK);
 bool ba_fused_eligible(int C, int n, int NP, bool uniformK);
 int ba_fused_groups(int C);    // workgroups per chunk: ceil(live parameter sets / sets per workgroup)
-int ba_fused_owners(int chunks);  // workgroups that write Gram partials (one per chunk)
+size_t ba_fused_records(int chunks);   // records of the reduction tree (one per chunk + the inner nodes)
+size_t ba_fused_counters(int chunks);  // arrival counters: one per chunk, one per tree node
 hipError_t launch_ba_fused(const BaFusedArgs& a, hipStream_t stream);
 
 // cost-only evaluation: sum of rho over valid points of residual row r [N]
