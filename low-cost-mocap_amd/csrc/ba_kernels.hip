@@ -393,7 +393,7 @@ __device__ __forceinline__ void st_agent(double* p, double v) {
 __device__ __forceinline__ double ld_agent(const double* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ void drain_stores() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
+__device__ __forceinline__ void drain_stores() { wait_own_stores(); }
 
 // slot of a live parameter set (0 = base point, 1 + k = k-th live parameter) -> parameter set index p
 __device__ __forceinline__ int ba_live_set(int slot) {
@@ -698,7 +698,7 @@ __global__ __launch_bounds__(kFusedThreads) void ba_fused_kernel(BaFusedArgs a) 
     }
   }
   // every wave waits for its own stores (workgroup-scope release), one thread publishes to the host
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  wait_own_stores();
   __syncthreads();
   if (tid == 0) {
     double* tail = a.out + (size_t)NP * NP;

@@ -87,6 +87,7 @@ extern "C" int mocap_create(int device_id, mocap_ctx** out) {
   if ((t = getenv("MOCAP_SLICE_SIZE"))) c->slice_size = atoi(t);
   if ((t = getenv("MOCAP_FORCE_WIDE"))) c->force_wide = atoi(t) ? 1 : 0;
   if ((t = getenv("MOCAP_PRUNE"))) c->prune = atoi(t) ? 1 : 0;
+  if ((t = getenv("MOCAP_EIGCUT"))) c->eigcut = atoi(t) ? 1 : 0;
   if ((t = getenv("MOCAP_FRAME_LAUNCHES"))) c->frame_launches = atoi(t) == 3 ? 3 : 1;  // 3: main / slice / merge launches (A/B)  // 0: every group is reprojected in full (A/B)
   *out = c;
   return MOCAP_OK;
@@ -294,6 +295,17 @@ extern "C" int mocap_set_cameras(mocap_ctx* ctx, int C, const double* K, const d
   ctx->cv.K4 = ctx->cv.RT + nRT;
   ctx->cv.F = ctx->cv.K4 + nK4;
   ctx->d_K9 = ctx->cv.F + nF;
+  // EigCut (mocap_device.hpp): the bound equates the DLT rows' residual with cv.projectPoints', which holds when every
+  // K is [[fx,0,cx],[0,fy,cy],[0,0,1]] (projectPoints reads fx, fy, cx, cy only); then P[2] = (R[2], t[2])
+  bool plainK = true;
+  double p3 = 0.0;
+  for (int c = 0; c < C; c++) {
+    const double* k = K + 9 * c;
+    plainK = plainK && k[1] == 0.0 && k[3] == 0.0 && k[6] == 0.0 && k[7] == 0.0 && k[8] == 1.0;
+    const double* r = R + 9 * c;
+    p3 = std::fmax(p3, r[6] * r[6] + r[7] * r[7] + r[8] * r[8] + t[3 * c + 2] * t[3 * c + 2]);
+  }
+  ctx->p3max2 = plainK && std::isfinite(p3) ? p3 * (1.0 + 1e-5) : 0.0;
   return MOCAP_OK;
 }
 
@@ -452,9 +464,11 @@ static int match_dev_locked(mocap_ctx* ctx, int64_t n_frames, int M_max, const f
       return ctx->fail(MOCAP_E_LIMIT, "frame state needs %zu B of LDS (C=%d, M_max=%d, K_max=%d): lower K_max",
                        lds, ctx->C, M_max, K_max);
   }
+  if (const char* pad = getenv("MOCAP_DEBUG_LDS_PAD")) lds += (size_t)atoi(pad);  // occupancy experiments only
   a.H = hit_cap;
   a.wide = wide ? 1 : 0;
   a.prune = ctx->prune;
+  a.p3max2 = ctx->prune && ctx->eigcut ? ctx->p3max2 : 0.0;
   a.ws = nullptr;
   a.ws_stride = 0;
   // persistent grid: enough workgroups to fill every CU at the LDS-limited occupancy

@@ -155,7 +155,8 @@ size_t frame_lds_bytes(int C, int M, int R, int T, int H, bool wide, bool table)
 size_t frame_ws_bytes(int C, int M, int R, int T, int H, bool wide, bool table) { return FrameLayout(C, M, R, T, H, wide, table && !wide).ws_total; }
 
 // misc[] slots
-enum { MI_NROOTS = 0, MI_STATUS = 1, MI_NOUT = 2, MI_G = 3, MI_ITEM = 4, MI_DEFER = 5, MI_KIND = 6 };
+enum { MI_NROOTS = 0, MI_STATUS = 1, MI_NOUT = 2, MI_G = 3, MI_ITEM = 4, MI_DEFER = 5, MI_KIND = 6,
+       MI_OMAX = 7 /* bit pattern of the largest |coordinate| among the frame's blobs (float >= 0) */ };
 
 template <int T, bool UNIFORM_K, bool F32R, bool WIDE>
 struct FrameState {
@@ -228,9 +229,23 @@ struct FrameState {
         int n = p.counts[(size_t)frame * C + tid];
         cnt[tid] = n < 0 ? 0 : (n > M ? M : n);
       }
-      if (tid == 0) misc[MI_STATUS] = 0;
+      if (tid == 0) {
+        misc[MI_STATUS] = 0;
+        misc[MI_OMAX] = 0;
+      }
     }
     __syncthreads();
+    if (p.p3max2 > 0.0) {  // EigCut's float32 allowance scales with the largest coordinate (inf: the cut-off never fires)
+      float om = 0.0f;
+      for (int i = tid; i < C * M; i += T) {
+        const int c = i / M, k = i - c * M;
+        if (k < cnt[c]) {
+          const float2 v = bxy[i];
+          om = fmaxf(om, fmaxf(fabsf(v.x), fabsf(v.y)));
+        }
+      }
+      if (om > 0.0f) atomicMax(&misc[MI_OMAX], __float_as_int(om));
+    }
     if (TABLE && !(skip & 1)) {
       // DLT contribution of every blob, once per frame: a candidate group then ADDS ten doubles per view
       // instead of rebuilding two rows of A and their outer products (the Cartesian product revisits every
@@ -631,13 +646,31 @@ struct FrameState {
       // minimum in candidate order -- does not depend on which lane got where first; only the amount of work does.
       const double inf = __builtin_huge_val();
       const bool prune = p.prune != 0;
+      EigCut ec;
+      if (prune && p.p3max2 > 0.0) {
+        const double om = (double)__int_as_float(misc[MI_OMAX]);
+        ec.p3max2 = p.p3max2;
+        ec.o2slack = (1100.0 * 0x1p-46) * (om * om);
+      }
       while (true) {
         double X[3], e;
         const double bound = prune ? __longlong_as_double((long long)rbound[r]) : inf;
         if constexpr (TABLE)
-          triangulate_and_score_tab<true, F32R>(cv, contrib, obs_ix, X, e, bound);
+          triangulate_and_score_tab<true, F32R>(cv, contrib, obs_ix, X, e, bound, ec);
         else
-          triangulate_and_score<UNIFORM_K, true, F32R>(cv, obs, obs, X, e, bound);
+          triangulate_and_score<UNIFORM_K, true, F32R>(cv, obs, obs, X, e, bound, ec);
+#ifdef MOCAP_DEBUG_EIGCHECK  // self-check of the cut-offs: a group that was cut must not beat the bound it was cut against
+        if (!(e < inf)) {
+          double X2[3], e2;
+          if constexpr (TABLE)
+            triangulate_and_score_tab<true, F32R>(cv, contrib, obs_ix, X2, e2);
+          else
+            triangulate_and_score<UNIFORM_K, true, F32R>(cv, obs, obs, X2, e2);
+          if (e2 <= bound)
+            printf("EIGCHECK frame-item tid %d root %d g %u bound %.17g true %.17g omax %g\n", tid, r, g - r_beg, bound, e2,
+                   (double)__int_as_float(misc[MI_OMAX]));
+        }
+#endif
         if (e < best_e) {  // strict <: first minimum within the lane's ascending run (best_e starts at +inf; a
           best_e = e;      // group that was cut short or whose error is not finite never enters)
           best_g = g - r_beg;
@@ -852,7 +885,7 @@ __global__ __launch_bounds__(T, MOCAP_FRAME_WAVES_PER_EU) void frame_kernel(Fram
                 q_store(&q.heavy[4 * hn + 2], (int32_t)Sn);
                 q_store(&q.heavy[4 * hn + 3], 0);
                 for (uint32_t s = 0; s < Sn; s++) q_store(&q.slice_heavy[bn + s], hn);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the entries are in memory before their tickets become valid
+                wait_own_stores();  // the entries are in memory before their tickets become valid
                 for (uint32_t s = 0; s < Sn; s++) q_store(&q.slice_gen[bn + s], q.gen);
                 defer = 1;
               }
@@ -899,13 +932,13 @@ __global__ __launch_bounds__(T, MOCAP_FRAME_WAVES_PER_EU) void frame_kernel(Fram
       if (kind == 1) {
         __syncthreads();
         if (tid == 0) {
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          wait_own_stores();
           q_add(&q.counters[QC_FRAMES_DONE], 1);
         }
       } else {
         // the workgroup that finishes a heavy frame's LAST slice merges them: it already holds the frame's roots, hit
         // lists and output slots in LDS
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // every wave's partials have left the CU
+        wait_own_stores();  // every wave's partials have left the CU
         __syncthreads();
         if (tid == 0) st.misc[MI_DEFER] = q_add(&q.heavy[4 * h + 3], 1) == S - 1;
         __syncthreads();

@@ -53,6 +53,7 @@ struct FrameArgs {
   int H;
   int wide;
   int prune;  // cut the reprojection of a group short once it cannot beat the best of its root (exact, see evaluate())
+  double p3max2;  // EigCut: (1 + 1e-5) * max |P[2]|^2 over the cameras, 0 = eigenvalue cut-off off (see mocap_device.hpp)
 };
 
 constexpr int kWideThreads = 1024;  // workgroup size of the wide-frame variant (one workgroup per CU)

@@ -77,6 +77,12 @@ __host__ __device__ constexpr int sidx(int i, int j) {
 
 // 1/sqrt(d) for finite d > 0 away from the exponent limits (Cholesky pivots clamped from below):
 // raw estimate + one third-order step -> < 1 ulp.  6 instructions instead of 9.
+// The calling wave's global stores have been acknowledged (gfx9 counts stores on vmcnt).  Needed before a flag /
+// counter that tells ANOTHER workgroup (or the host) "my data is there": a workgroup-scope release fence emits no
+// such wait (visibility inside one CU needs none), and an agent-scope one writes the whole L2 back (16 us when every
+// wave does it).  With sc1 (write-through) stores the acknowledgement means the data has left this XCD's L2.
+__device__ __forceinline__ void wait_own_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 __device__ __forceinline__ double rsqrt_pos(double d) {
   const double y = __builtin_amdgcn_rsq(d);
   const double e = fma(-(d * y), y, 1.0);
@@ -184,13 +190,19 @@ __device__ __forceinline__ void smallest_eigvec4_jacobi(double (&a)[10], double 
 //   dominate the candidate set, so shift 0 alone is never enough, and one Laguerre step always
 //   is); max 2.3e-14 relative on X against LAPACK dgesdd.
 constexpr int kInvIters = 5;
-__device__ __forceinline__ void smallest_eigvec4_cholesky(const double (&a)[10], double (&out)[4]) {
+// lamcut / lam_lb: the exact cut-off of candidate selection (EigCut below).  trace((B - lam I)^-1) = s1 >= 1/(lam1 - lam),
+// so every factorisation yields the rigorous lower bound lam1 >= lam + 1/s1.  After the FIRST factorisation (lam = 0)
+// the candidate is dropped when s1 * lamcut < 1 (returns false, `out` untouched); otherwise lam_lb receives the bound
+// of the last factorisation, shrunk by the rounding allowance (Cholesky backward error and the rounding of B itself
+// are O(1e-15 tr); 2e-12 tr is charged).  lamcut = +inf switches the cut off.
+__device__ __forceinline__ bool smallest_eigvec4_cholesky(const double (&a)[10], double (&out)[4], double lamcut,
+                                                          double& lam_lb) {
   const double tr = (a[0] + a[4]) + (a[7] + a[9]);
   // pivots are clamped from below (fmax also swallows NaN): a shift that rounding pushed past lam1
   // yields one tiny pivot, i.e. a huge last row of M -- still the wanted vector -- and s2/s1^2 -> 1,
   // which ends the loop through the ordinary convergence test
   const double floor_piv = tr * 1e-30 + 1e-300;
-  double lam = 0.0, piv3 = 1.0;
+  double lam = 0.0, piv3 = 1.0, s1_last = 1.0;
   double m[10];  // M = L^{-1}, lower triangular, packed like sidx with (row >= col) -> sidx(col,row)
   for (int it = 0; it < 8; it++) {
     // ---- Cholesky of B - lam I; r_i = 1 / l_ii
@@ -218,6 +230,8 @@ __device__ __forceinline__ void smallest_eigvec4_cholesky(const double (&a)[10],
     const double w22 = fma(m22, m22, m32 * m32);
     const double w33 = m33 * m33;
     const double s1 = (w00 + w11) + (w22 + w33);
+    if (it == 0 && s1 * fma(2e-12, tr, lamcut) < 1.0) return false;
+    s1_last = s1;
     const double w01 = fma(m10, m11, fma(m20, m21, m30 * m31));
     const double w02 = fma(m20, m22, m30 * m32);
     const double w03 = m30 * m33;
@@ -255,13 +269,37 @@ __device__ __forceinline__ void smallest_eigvec4_cholesky(const double (&a)[10],
   out[1] = x1;
   out[2] = x2;
   out[3] = x3;
+  lam_lb = fma(1.0 - 1e-5, __builtin_amdgcn_rcp(s1_last), lam) - 2e-12 * tr;
+  return true;
 }
 
 #ifdef MOCAP_EIG_JACOBI
-__device__ __forceinline__ void smallest_eigvec4(double (&a)[10], double (&out)[4]) { smallest_eigvec4_jacobi(a, out); }
+__device__ __forceinline__ bool smallest_eigvec4(double (&a)[10], double (&out)[4], double, double& lam_lb) {
+  smallest_eigvec4_jacobi(a, out);
+  lam_lb = 0.0;  // no bound: nothing is ever cut
+  return true;
+}
 #else
-__device__ __forceinline__ void smallest_eigvec4(double (&a)[10], double (&out)[4]) { smallest_eigvec4_cholesky(a, out); }
+__device__ __forceinline__ bool smallest_eigvec4(double (&a)[10], double (&out)[4], double lamcut, double& lam_lb) {
+  return smallest_eigvec4_cholesky(a, out, lamcut, lam_lb);
+}
 #endif
+
+// Exact cut-off of candidate selection from the DLT matrix alone (frame path; everything else passes EigCut{}).
+// For ANY homogeneous point x = (X, 1):  x^T B x = sum over the views of z_c^2 (du_c^2 + dv_c^2)  (z_c = P_c[2].x, the
+// depth; rows ra.x = z (v - v^), rb.x = -z (u - u^) of helpers.py:315-316 when K = [[fx,0,cx],[0,fy,cy],[0,0,1]], which
+// makes the projection of P = K[R|t] the one cv.projectPoints computes -- the host switches the cut off otherwise),
+// and x^T B x >= lam1 |x|^2.  Hence  sum of squared residuals >= lam1 |x|^2 / max_c z_c^2  >= lam1 / max_c |P_c[2]|^2
+// (Cauchy-Schwarz).  A candidate whose bound exceeds the best error found so far for its root can never be selected,
+// so the rest of its evaluation is skipped: after the first factorisation with the X-free form (p3max2), after the
+// null vector with the depths of the point that would be reprojected.  `limit` below is the bound on the SUM the
+// reprojection cut-off uses; the allowances: float32 rounding of the projections (|fl(p) - p| <= 2^-24 |p|,
+// |p| <= |o| + |d|  =>  sqrt(S32) >= (1 - 2^-23) sqrt(S) - sqrt(2v) 2^-23 omax, squared with (a+b)^2 <= (1+h) a^2 +
+// (1+1/h) b^2, h = 2^-10), every other rounding inside the factor 1.002.
+struct EigCut {
+  double p3max2 = 0.0;   // (1 + 1e-5) * max over the cameras of |P[2]|^2; 0 = cut-off disabled
+  double o2slack = 0.0;  // 1100 * 2^-46 * omax^2, omax = largest |coordinate| among the frame's blobs
+};
 
 // DLT contribution of one view: rows ra = y*P2 - P1 and rb = P0 - x*P2 (helpers.py:315-316),
 // Bc = ra ra^T + rb rb^T (packed symmetric).  B = A^T A is the sum of the views' contributions in camera
@@ -331,13 +369,43 @@ __device__ __forceinline__ void score_point(const View& cv, int v, Obs2&& obs2, 
 template <bool UNIFORM_K, bool PAIRWISE, bool F32R, class View, class Obs2>
 __device__ __forceinline__ void solve_and_score(const View& cv, double (&B)[10], int v, Obs2&& obs2,
                                                 double (&X)[3], double& err,
-                                                double limit = __builtin_huge_val()) {
-  double vec[4];
-  smallest_eigvec4(B, vec);
+                                                double limit = __builtin_huge_val(), const EigCut& ec = EigCut{}) {
+  const double inf = __builtin_huge_val();
+  const bool cut = ec.p3max2 > 0.0;
+  // limit = +inf (no finite error for the root yet) keeps every comparison below false
+  const double limit_adj = fma(1.002, limit, (double)(2 * v) * ec.o2slack);
+  double vec[4], lam_lb;
+  if (!smallest_eigvec4(B, vec, cut ? ec.p3max2 * limit_adj : inf, lam_lb)) {
+    X[0] = X[1] = X[2] = 0.0;
+    err = inf;  // like a reprojection that was cut short
+    return;
+  }
   const double rw = recip_refined(vec[3]);
   X[0] = div_by(vec[0], vec[3], rw);  // helpers.py:321
   X[1] = div_by(vec[1], vec[3], rw);
   X[2] = div_by(vec[2], vec[3], rw);
+  if (cut) {
+    double Xp[3] = {X[0], X[1], X[2]};
+    if (F32R) {
+      Xp[0] = (double)(float)X[0];
+      Xp[1] = (double)(float)X[1];
+      Xp[2] = (double)(float)X[2];
+    }
+    const double n2 = fma(Xp[0], Xp[0], fma(Xp[1], Xp[1], fma(Xp[2], Xp[2], 1.0)));
+    double zmax2 = 1e-14 * (n2 * ec.p3max2);  // rounding of the depths below
+    for (int c = 0; c < cv.C; c++) {
+      double ox, oy;
+      if (obs2(c, ox, oy)) {
+        const auto RT = cv.rt(12 * c);
+        const double z = fma(RT[6], Xp[0], fma(RT[7], Xp[1], fma(RT[8], Xp[2], RT[11])));
+        zmax2 = fmax(zmax2, z * z);
+      }
+    }
+    if (lam_lb * n2 > zmax2 * limit_adj) {
+      err = inf;
+      return;
+    }
+  }
   score_point<UNIFORM_K, PAIRWISE, F32R>(cv, v, obs2, X, err, limit);
 }
 
@@ -398,7 +466,7 @@ __device__ __forceinline__ void score_point(const View& cv, int v, Obs2&& obs2, 
 template <bool UNIFORM_K, bool PAIRWISE, bool F32R, class View, class Obs1, class Obs2>
 __device__ __forceinline__ int triangulate_and_score(const View& cv, Obs1&& obs1, Obs2&& obs2,
                                                      double (&X)[3], double& err,
-                                                     double limit_e = __builtin_huge_val()) {
+                                                     double limit_e = __builtin_huge_val(), const EigCut& ec = EigCut{}) {
   const int C = cv.C;
   double B[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   int v = 0;
@@ -410,7 +478,7 @@ __device__ __forceinline__ int triangulate_and_score(const View& cv, Obs1&& obs1
     }
   }
   if (v <= 1) return v;  // helpers.py:300
-  solve_and_score<UNIFORM_K, PAIRWISE, F32R>(cv, B, v, obs2, X, err, limit_e * (double)(2 * v) * (1.0 + 0x1p-40));
+  solve_and_score<UNIFORM_K, PAIRWISE, F32R>(cv, B, v, obs2, X, err, limit_e * (double)(2 * v) * (1.0 + 0x1p-40), ec);
   return v;
 }
 
@@ -420,7 +488,7 @@ __device__ __forceinline__ int triangulate_and_score(const View& cv, Obs1&& obs1
 template <bool PAIRWISE, bool F32R, class Contrib, class Obs2>
 __device__ __forceinline__ int triangulate_and_score_tab(const CamView& cv, Contrib&& contrib, Obs2&& obs2,
                                                          double (&X)[3], double& err,
-                                                         double limit_e = __builtin_huge_val()) {
+                                                         double limit_e = __builtin_huge_val(), const EigCut& ec = EigCut{}) {
   const int C = cv.C;
   double B[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   int v = 0;
@@ -428,7 +496,7 @@ __device__ __forceinline__ int triangulate_and_score_tab(const CamView& cv, Cont
   if (v <= 1) return v;
   // limit_e is a bound on the ERROR (mean of 2 v squares) -> bound on their sum, with room for the rounding of
   // the two summation orders (~2 v ulp) and of the division
-  solve_and_score<true, PAIRWISE, F32R>(cv, B, v, obs2, X, err, limit_e * (double)(2 * v) * (1.0 + 0x1p-40));
+  solve_and_score<true, PAIRWISE, F32R>(cv, B, v, obs2, X, err, limit_e * (double)(2 * v) * (1.0 + 0x1p-40), ec);
   return v;
 }
 
