@@ -88,6 +88,9 @@ extern "C" int mocap_create(int device_id, mocap_ctx** out) {
   if ((t = getenv("MOCAP_FORCE_WIDE"))) c->force_wide = atoi(t) ? 1 : 0;
   if ((t = getenv("MOCAP_PRUNE"))) c->prune = atoi(t) ? 1 : 0;
   if ((t = getenv("MOCAP_EIGCUT"))) c->eigcut = atoi(t) ? 1 : 0;
+  if ((t = getenv("MOCAP_EVAL_BB"))) c->eval_bb = atoi(t) ? 1 : 0;
+  if ((t = getenv("MOCAP_BB_PL")) && atoi(t) >= 1 && atoi(t) <= 64) c->bb_pl = atoi(t);
+  if ((t = getenv("MOCAP_BB_FLUSH")) && atoi(t) >= 1) c->bb_flush = atoi(t);
   if ((t = getenv("MOCAP_FRAME_LAUNCHES"))) c->frame_launches = atoi(t) == 3 ? 3 : 1;  // 3: main / slice / merge launches (A/B)  // 0: every group is reprojected in full (A/B)
   *out = c;
   return MOCAP_OK;
@@ -469,6 +472,10 @@ static int match_dev_locked(mocap_ctx* ctx, int64_t n_frames, int M_max, const f
   a.wide = wide ? 1 : 0;
   a.prune = ctx->prune;
   a.p3max2 = ctx->prune && ctx->eigcut ? ctx->p3max2 : 0.0;
+  a.eval_bb = ctx->eval_bb && a.p3max2 > 0.0 && G_cap <= ((int64_t)1 << 24) && frame_bb_fits(ctx->C, M_max, K_max, T);
+  a.bb_pl = ctx->bb_pl;
+  a.bb_flush = ctx->bb_flush > 0 ? ctx->bb_flush : T;
+  while (a.bb_pl > 1 && (size_t)a.bb_pl * M_max * 2 * T >= ((size_t)1 << 22)) a.bb_pl /= 2;  // expanded-list counter: 22 bits
   a.ws = nullptr;
   a.ws_stride = 0;
   // persistent grid: enough workgroups to fill every CU at the LDS-limited occupancy

@@ -28,6 +28,9 @@ struct mocap_ctx {
   bool frame_q_clean = false;  // the queue counters were left at zero by the one-launch schedule
   int frame_launches = 1;   // 1: one persistent launch per batch (MODE_ALL); 3: main / slice / merge launches
   int prune = 1;            // stop a candidate group's reprojection once it cannot beat its root's best (exact)
+  int eval_bb = 1;          // branch-and-bound evaluation of the candidates (frame_kernel.hip evaluate_bb)
+  int bb_pl = 16;           // ... candidates per block (at least)
+  int bb_flush = 0;         // ... queued candidates that trigger their evaluation (0 = one per lane)
   int eigcut = 1;           // ... and drop it before the null vector / the reprojection on an eigenvalue bound (EigCut)
   double p3max2 = 0.0;      // EigCut constant of the current camera set (0: intrinsics not of the form the bound needs)
   hipStream_t own_stream = nullptr, stream = nullptr;

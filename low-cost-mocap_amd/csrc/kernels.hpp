@@ -53,6 +53,9 @@ struct FrameArgs {
   int H;
   int wide;
   int prune;  // cut the reprojection of a group short once it cannot beat the best of its root (exact, see evaluate())
+  int eval_bb;  // table mode: branch-and-bound evaluation (frame_kernel.hip evaluate_bb)
+  int bb_pl;    // ... candidates per block (at least)
+  int bb_flush; // ... queued candidates that trigger their evaluation
   double p3max2;  // EigCut: (1 + 1e-5) * max |P[2]|^2 over the cameras, 0 = eigenvalue cut-off off (see mocap_device.hpp)
 };
 
@@ -60,6 +63,7 @@ constexpr int kWideThreads = 1024;  // workgroup size of the wide-frame variant 
 // table = identical intrinsics (CamView::uniformK): per-blob DLT contributions tabulated in LDS (narrow frames only)
 size_t frame_lds_bytes(int C, int M, int R, int T, int H, bool wide, bool table);
 size_t frame_ws_bytes(int C, int M, int R, int T, int H, bool wide, bool table);
+bool frame_bb_fits(int C, int M, int R, int T);
 hipError_t launch_frame_kernel(const FrameArgs& a, int mode, int threads, int grid, hipStream_t stream);
 
 // object (drone) locator over the frame path's output (reference helpers.py:424-480), csrc/post_kernels.hip

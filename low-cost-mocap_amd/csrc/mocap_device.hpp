@@ -273,6 +273,30 @@ __device__ __forceinline__ bool smallest_eigvec4_cholesky(const double (&a)[10],
   return true;
 }
 
+// s1 = trace(B^-1) from the Cholesky factor of B itself (EigCut's first test on its own: the frame kernel's
+// branch-and-bound runs it on PARTIAL groups): lam1(B) >= 1 / s1.  tr = trace(B) for the rounding allowance.
+__device__ __forceinline__ double eigcut_s1(const double (&a)[10], double& tr) {
+  tr = (a[0] + a[4]) + (a[7] + a[9]);
+  const double floor_piv = tr * 1e-30 + 1e-300;
+  const double r0 = rsqrt_pos(fmax(a[0], floor_piv));
+  const double l10 = a[1] * r0, l20 = a[2] * r0, l30 = a[3] * r0;
+  const double r1 = rsqrt_pos(fmax(fma(-l10, l10, a[4]), floor_piv));
+  const double l21 = fma(-l20, l10, a[5]) * r1, l31 = fma(-l30, l10, a[6]) * r1;
+  const double r2 = rsqrt_pos(fmax(fma(-l21, l21, fma(-l20, l20, a[7])), floor_piv));
+  const double l32 = fma(-l31, l21, fma(-l30, l20, a[8])) * r2;
+  const double r3 = rsqrt_pos(fmax(fma(-l32, l32, fma(-l31, l31, fma(-l30, l30, a[9]))), floor_piv));
+  const double m10 = -(l10 * r0) * r1;
+  const double m21 = -(l21 * r1) * r2;
+  const double m32 = -(l32 * r2) * r3;
+  const double m20 = -fma(l21, m10, l20 * r0) * r2;
+  const double m31 = -fma(l32, m21, l31 * r1) * r3;
+  const double m30 = -fma(l32, m20, fma(l31, m10, l30 * r0)) * r3;
+  const double w00 = fma(r0, r0, fma(m10, m10, fma(m20, m20, m30 * m30)));
+  const double w11 = fma(r1, r1, fma(m21, m21, m31 * m31));
+  const double w22 = fma(r2, r2, m32 * m32);
+  return (w00 + w11) + (w22 + r3 * r3);
+}
+
 #ifdef MOCAP_EIG_JACOBI
 __device__ __forceinline__ bool smallest_eigvec4(double (&a)[10], double (&out)[4], double, double& lam_lb) {
   smallest_eigvec4_jacobi(a, out);
