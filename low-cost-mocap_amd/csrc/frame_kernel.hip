@@ -164,7 +164,7 @@ bool frame_bb_fits(int C, int M, int R, int T) {
   // slots: key, error, point = 5 doubles per (wave, root) in the 4 (T + R) doubles of the segment arrays; the small
   // per-root arrays in a column block of C T bytes
   return C <= 8 && M <= 255 && R <= 255 && R <= T && T <= 256 && T % 64 == 0 && 5 * W * R <= 4 * (T + R) && W * R <= T + R &&
-         (size_t)24 * R + 8 <= (size_t)C * T;
+         (size_t)24 * R + 8 <= (size_t)C * T && C * T / 8 + (4 * (T + R) - 5 * W * R) >= 2 * T;
 }
 size_t frame_ws_bytes(int C, int M, int R, int T, int H, bool wide, bool table) { return FrameLayout(C, M, R, T, H, wide, table && !wide).ws_total; }
 
@@ -808,6 +808,11 @@ struct FrameState {
     double* slot_x = slot_ea + W * R;                  // [W][R][3]   (seg_e and seg_x are contiguous: 4 (T + R) doubles)
     uint32_t* slot_g = seg_g;                          // [W][R]
     BRec* recs = (BRec*)wqueue;                        // [2 T] surviving blocks
+    // ... and the blob indices of each block's fixed cameras (0xFF = open or absent), so that a candidate only decodes
+    // its open digits: 2 T x 8 bytes, split over the digit columns and the unused tail of the segment arrays
+    unsigned long long* rpkA = (unsigned long long*)(dig - tid);
+    unsigned long long* rpkB = (unsigned long long*)seg_e + 5 * W * R;
+    const uint32_t capA = (uint32_t)(C * T) / 8u;
     int32_t* ctr = &misc[MI_DEFER];                    // blocks | their candidates << 10 (MI_DEFER is read before phase D)
     const double inf = __builtin_huge_val();
     EigCut ec;
@@ -856,15 +861,18 @@ struct FrameState {
       }
       return lo;
     };
-    auto push_block = [&](int r, uint32_t gh) {
+    auto push_block = [&](int r, uint32_t gh, unsigned long long packed) {
       const uint32_t old = (uint32_t)atomicAdd(ctr, (int32_t)(((uint32_t)bpl[r] << 10) | 1u));
+      const uint32_t slot = old & 0x3FFu;
       BRec rec;
       rec.gh = gh;
       rec.rs = (uint32_t)r | ((old >> 10) << 8);
-      recs[old & 0x3FFu] = rec;
+      recs[slot] = rec;
+      if (slot < capA) rpkA[slot] = packed; else rpkB[slot - capA] = packed;
     };
     // candidate i of the expanded block list -> (root, candidate index)
-    auto expanded = [&](uint32_t i, uint32_t ns, int& r, uint32_t& gl) {
+    // ... and its DLT matrix: the block's fixed cameras come with the record, the open digits are decoded from l
+    auto expanded = [&](uint32_t i, uint32_t ns, int& r, uint32_t& gl, double (&B)[10], unsigned long long& packed) {
       uint32_t lo = 0, hi = ns - 1;  // last record that starts at or before i
       while (lo < hi) {
         const uint32_t mid = (lo + hi + 1) >> 1;
@@ -872,7 +880,32 @@ struct FrameState {
       }
       const BRec rec = recs[lo];
       r = (int)(rec.rs & 0xFFu);
-      gl = rec.gh * (uint32_t)bpl[r] + (i - (rec.rs >> 8));
+      uint32_t rem = i - (rec.rs >> 8);
+      gl = rec.gh * (uint32_t)bpl[r] + rem;
+      packed = lo < capA ? rpkA[lo] : rpkB[lo - capA];
+      const uint8_t* a = act + (size_t)r * C;
+      const int nl = bnl[r];
+      for (int k = 0; k < nl; k++) {
+        const int c = a[k];
+        uint32_t qd, dgt;
+        divmod_small(rem, nh[(size_t)r * C + c], qd, dgt);
+        rem = qd;
+        const uint32_t idx = hits[((size_t)r * C + c) * Hs + dgt];
+        packed ^= (unsigned long long)(idx ^ 0xFFu) << (8 * c);
+      }
+      int v = 0;
+#pragma unroll
+      for (int e = 0; e < 10; e++) B[e] = 0.0;
+      for (int c = 0; c < C; c++) {  // cameras in ascending order: the one canonical rounding of B
+        const uint32_t k = (uint32_t)(packed >> (8 * c)) & 0xFFu;
+        if (k != 0xFFu) {
+          const double* t = bt + ((size_t)c * M + k) * 10;
+#pragma unroll
+          for (int e = 0; e < 10; e++) B[e] = B[e] + t[e];
+          v++;
+        }
+      }
+      return v;
     };
     // EigCut's first test of a (partial or full) group of root r against the best error of the root so far
     auto dropped = [&](int r, double s1, double tr) {
@@ -901,7 +934,10 @@ struct FrameState {
       if (bnb[r]) {
         const uint32_t gh = 0xFFFFFFFFu - (uint32_t)seedkey[r];
         seedgh[r] = gh;
-        push_block(r, gh);
+        double B[10];
+        unsigned long long packed;
+        group_matrix(r, gh, bnl[r], B, packed);
+        push_block(r, gh, packed);
       }
     }
     __syncthreads();
@@ -920,10 +956,9 @@ struct FrameState {
           int r = 0;
           uint32_t gl = 0;
           if (have) {
-            expanded(i, ns, r, gl);
             double B[10];
             unsigned long long packed;
-            const int v = group_matrix(r, gl, 0, B, packed);
+            const int v = expanded(i, ns, r, gl, B, packed);
             auto obs_p = [&](int c, double& x, double& y) -> bool {
               const uint32_t k = (uint32_t)(packed >> (8 * c)) & 0xFFu;
               if (k == 0xFFu) return false;
@@ -980,7 +1015,7 @@ struct FrameState {
             const double s1 = eigcut_s1(B, tr);
             survive = !dropped(r, s1, tr);
           }
-          if (survive) push_block(r, gh);
+          if (survive) push_block(r, gh, packed);
         }
       }
       __syncthreads();
