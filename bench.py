@@ -81,7 +81,8 @@ def executed_fp64(candidates, kernel_ms):
         return {"achieved": tf, "frac": tf / FP64_VALU_PEAK_TF, "flop_per_candidate": mix["fp64_flop_per_candidate"],
                 "valu_lane_instructions_per_candidate": mix["valu_lane_instructions_per_candidate"],
                 "fp64_share_of_valu_instructions": mix["fp64_share_of_valu_instructions"],
-                "source": "profiles/r02_fp64_mix.json (rocprofv3 PMC instruction mix, FMA = 2 flop, MUL/ADD/TRANS = 1)"}
+                "source": "profiles/r02_fp64_mix.json (rocprofv3 PMC instruction mix of this kernel, FMA = 2 flop, "
+                          "MUL/ADD/TRANS = 1; per candidate group of the Cartesian product, evaluated or dropped)"}
     except Exception:
         return None
 
@@ -602,9 +603,12 @@ def main():
             "roofline_fp64": {"bound": "fp64_valu", "achieved": flops / (kernel_ms * 1e-3) / 1e12,
                               "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s",
                               "frac": flops / (kernel_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TF,
-                              "model": "SURVEY 8d work model: candidates x (92 v + 1500) flop, v = mean views "
-                                       "(the kernel now needs fewer instructions than the model's Jacobi "
-                                       "eigen-solve; issue-slot utilisation from PMC: profiles/)", "v_mean": v_mean,
+                              "model": "SURVEY 8d work model: candidates x (92 v + 1500) flop, v = mean views -- the "
+                                       "REFERENCE's work disposed of per second, not work executed: the kernel "
+                                       "drops most candidate groups on partial-group eigenvalue bounds (branch and "
+                                       "bound, exact) and evaluates the rest without the model's Jacobi eigen-solve, "
+                                       "so this figure may exceed the peak; `executed` is the hardware-side number",
+                              "v_mean": v_mean,
                               "candidates_per_launch": float(n_cand.sum()),
                               "executed": executed_fp64(float(n_cand.sum()), kernel_ms) if default_wl else None},
         }

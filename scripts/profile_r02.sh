@@ -20,5 +20,7 @@ timeout 200 rocprofv3 --kernel-trace -d $OUT/ba16k -o p -- python $R/scripts/pro
 timeout 200 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAVES -d $OUT/ba_mfma -o p -- python $R/scripts/prof_ba.py 1000 > $OUT/ba_mfma.log 2>&1; summ $OUT/ba_mfma ba_pmc_mfma
 CMDS="python $R/bench.py --steps 2 --warmup 1 --frames 20000 --no-cpu-baseline --no-ba --no-blobs --no-latency"
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES -d $OUT/frame_f64 -o p -- $CMDS > $OUT/frame_f64.log 2>&1; summ $OUT/frame_f64 frame_pmc_f64
-timeout 60 rocprofv3 -L 2>&1 | grep -i "F64\|MFMA" > $OUT/counters_f64_mfma.txt
+# HBM traffic of the frame kernel: FETCH_SIZE and WRITE_SIZE in separate passes (MI355X_MICROARCH.md)
+timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/frame_fetch -o p -- $CMDS > $OUT/frame_fetch.log 2>&1; summ $OUT/frame_fetch frame_pmc_fetch
+timeout 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/frame_write -o p -- $CMDS > $OUT/frame_write.log 2>&1; summ $OUT/frame_write frame_pmc_write
 ls -la $OUT

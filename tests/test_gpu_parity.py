@@ -351,3 +351,65 @@ def test_medium_config_spills_to_wide_automatically(core):
     valid = np.arange(160)[None, :] < ref["n_out"][:, None]
     assert np.array_equal(res["corr"][valid], ref["corr"][valid])
     np.testing.assert_allclose(res["xyz"][valid], ref["xyz"][valid], rtol=XYZ_RTOL_TIGHT, atol=1e-12)
+
+
+def test_branch_and_bound_bit_identical_to_exhaustive(core):
+    """The branch-and-bound evaluation (partial-group eigenvalue bounds, frame_kernel.hip evaluate_bb) drops candidates
+    without evaluating them; what it returns must be, bit for bit, what the exhaustive odometer walk returns
+    (MOCAP_EVAL_BB=0: every candidate triangulated and reprojected) -- for any block size, on rigs of 4 to 8 cameras,
+    and on heavy frames."""
+    import os
+    from mocap_core import capi, synth
+
+    def ctx(env):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            return capi.MocapCore(0)
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    del os.environ[k]
+                else:
+                    os.environ[k] = v
+
+    exhaustive = ctx({"MOCAP_EVAL_BB": "0"})
+    variants = [ctx({"MOCAP_BB_PL": "2"}), ctx({"MOCAP_BB_PL": "64"}), ctx({"MOCAP_BB_PL": "16", "MOCAP_BB_FLUSH": "64"})]
+    try:
+        for C, M, F, K, seed in [(8, 16, 1500, 48, 7), (4, 8, 600, 24, 8), (5, 12, 600, 32, 9), (6, 16, 400, 40, 10)]:
+            rig = synth.ring_rig(C)
+            blobs, counts, _ = synth.make_blob_stream(rig, F, M, seed=seed)
+            exhaustive.set_cameras(rig["K"], rig["R"], rig["t"])
+            base = exhaustive.match_triangulate(blobs, counts, K_max=K)
+            assert not base["status"].any()
+            valid = np.arange(K)[None, :] < base["n_out"][:, None]
+            for c in [core] + variants:
+                c.set_cameras(rig["K"], rig["R"], rig["t"])
+                res = c.match_triangulate(blobs, counts, K_max=K)
+                for key in ("n_out", "status", "n_cand"):
+                    assert np.array_equal(res[key], base[key]), (C, M, key)
+                for key in ("xyz", "err", "corr"):
+                    assert np.array_equal(res[key][valid], base[key][valid]), (C, M, key)
+    finally:
+        exhaustive.close()
+        for c in variants:
+            c.close()
+
+
+def test_skewed_intrinsics_fall_back_to_exhaustive_evaluation(core):
+    """The eigenvalue bounds equate the DLT residual with cv.projectPoints' -- true for K = [[fx,0,cx],[0,fy,cy],[0,0,1]]
+    only (projectPoints ignores a skew entry, P = K[R|t] does not): with a skewed K the library must not use them.
+    Checked against the C oracle, which evaluates every candidate."""
+    from mocap_core import synth
+    from oracle import c_oracle
+    rig = synth.ring_rig(6)
+    K = rig["K"].copy()
+    K[:, 0, 1] = 0.37
+    blobs, counts, _ = synth.make_blob_stream(rig, 300, 10, seed=21)
+    core.set_cameras(K, rig["R"], rig["t"])
+    res = core.match_triangulate(blobs, counts, K_max=32)
+    ref = c_oracle.COracle(K, rig["R"], rig["t"]).match_triangulate(blobs, counts, K_max=32)
+    assert np.array_equal(res["n_out"], ref["n_out"])
+    valid = np.arange(32)[None, :] < ref["n_out"][:, None]
+    assert np.array_equal(res["corr"][valid], ref["corr"][valid])
+    np.testing.assert_allclose(res["xyz"][valid], ref["xyz"][valid], rtol=XYZ_RTOL_TIGHT, atol=1e-12)
