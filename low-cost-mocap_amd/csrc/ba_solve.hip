@@ -323,8 +323,9 @@ int ba_setup(mocap_ctx* ctx, BaWork& w, int64_t N, const double* obs, int Pmax, 
   // one launch per linearisation when the rig fits the fused kernel's LDS budget (MOCAP_BA_UNFUSED=1: the chain
   // of five launches it replaces, kept as the fallback for large rigs and for A/B measurements)
   // Any point count: the Gram partials are added by a 16-ary tree of last-arriver workgroups, so the serial tail
-  // stays at two short sums (measured per iteration, fused vs chain: 41 vs 58 us at 1 000 points, 97 vs 147 us at
-  // 16 000 points).
+  // stays at two short sums (per iteration, fused vs chain: 41 vs 58 us at 1 000 points, 97-102 vs 141-147 us at
+  // 16 000 points).  At 16 000 points BOTH schedules show a slow mode from one process to the next (fused 285-310 us in
+  // 6 of 18 runs, chain 340 us in 1 of 4): a property of the box (host thread / PCIe placement), not of the schedule.
   w.fused = ba_fused_eligible(C, w.n, w.NP, w.uniformK != 0) && !getenv("MOCAP_BA_UNFUSED");
   size_t nd_fout = 0;
   if (w.fused) {
@@ -343,7 +344,8 @@ int ba_setup(mocap_ctx* ctx, BaWork& w, int64_t N, const double* obs, int Pmax, 
     w.d_fJaug = want_jaug ? q : nullptr;
     HIP_TRY(ctx, hipMemsetAsync(w.d_fcounters, 0, (nd_cnt + nd_mail) * sizeof(double), ctx->stream));  // the kernel leaves the counters at zero
     nd_fout = al((size_t)w.NP * w.NP + 3) + al(8 * 19);  // + mailbox: 19 lines of {tag, 7 doubles} (n <= 127)
-    w.prearm = !getenv("MOCAP_BA_NO_PREARM") && w.n <= 112;  // the mailbox poll reads 16 lines of 7 parameters in one go
+    // launch-ahead: the mailbox poll reads 16 lines of 7 parameters in one go; used where it was validated
+    w.prearm = !getenv("MOCAP_BA_NO_PREARM") && w.n <= 112 && N <= 2048;
   }
   const size_t pin_bytes = sizeof(double) * (nd_x + nd_G + nd_cost + nd_fout);
   if (pin_bytes > ctx->ba_pin_cap) {

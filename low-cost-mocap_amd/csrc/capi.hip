@@ -91,6 +91,7 @@ extern "C" int mocap_create(int device_id, mocap_ctx** out) {
   if ((t = getenv("MOCAP_EVAL_BB"))) c->eval_bb = atoi(t) ? 1 : 0;
   if ((t = getenv("MOCAP_BB_PL")) && atoi(t) >= 1 && atoi(t) <= 64) c->bb_pl = atoi(t);
   if ((t = getenv("MOCAP_BB_FLUSH")) && atoi(t) >= 1) c->bb_flush = atoi(t);
+  if ((t = getenv("MOCAP_BB_MIN_G")) && atoi(t) >= 0) c->bb_min_g = atoi(t);
   if ((t = getenv("MOCAP_FRAME_LAUNCHES"))) c->frame_launches = atoi(t) == 3 ? 3 : 1;  // 3: main / slice / merge launches (A/B)  // 0: every group is reprojected in full (A/B)
   *out = c;
   return MOCAP_OK;
@@ -472,9 +473,11 @@ static int match_dev_locked(mocap_ctx* ctx, int64_t n_frames, int M_max, const f
   a.wide = wide ? 1 : 0;
   a.prune = ctx->prune;
   a.p3max2 = ctx->prune && ctx->eigcut ? ctx->p3max2 : 0.0;
+  if (!wide && ctx->frame_threads == 0 && T == 64) a.p3max2 = 0.0;  // tiny frames (a handful of candidates): the cut-offs cost more than they save
   a.eval_bb = ctx->eval_bb && a.p3max2 > 0.0 && G_cap <= ((int64_t)1 << 24) && frame_bb_fits(ctx->C, M_max, K_max, T);
   a.bb_pl = ctx->bb_pl;
   a.bb_flush = ctx->bb_flush > 0 ? ctx->bb_flush : T;
+  a.bb_min_g = ctx->bb_min_g;
   while (a.bb_pl > 1 && (size_t)a.bb_pl * M_max * 2 * T >= ((size_t)1 << 22)) a.bb_pl /= 2;  // expanded-list counter: 22 bits
   a.ws = nullptr;
   a.ws_stride = 0;
@@ -517,7 +520,11 @@ static int match_dev_locked(mocap_ctx* ctx, int64_t n_frames, int M_max, const f
   const void* wq_before = wq.ptr;
   if (wq.reserve(b_cnt + b_heavy + b_slice + b_gen + b_pe + b_pg + b_px))
     return ctx->fail(MOCAP_E_HIP, "hipMalloc(frame work queues) failed");
-  const bool one_launch = ctx->frame_launches != 3;
+  // Big batches of tiny frames (one-wave workgroups: 4 x 4) are bound by how many frames are in flight, and the lean
+  // kernel of the three-launch schedule keeps twice the waves of the all-in-one kernel resident (measured on 1 M frames
+  // of 4 x 4: 4.8 vs 8.2 ms); everything else takes the one persistent launch
+  const bool tiny_batch = !wide && ctx->frame_threads == 0 && T == 64 && n_frames >= 4096;
+  const bool one_launch = ctx->frame_launches != 3 && !(tiny_batch && !getenv("MOCAP_FRAME_LAUNCHES"));
   // one-launch schedule: the kernel leaves the counters at zero and slices carry a launch generation, so the queue
   // needs clearing only when the buffer is new, the layout moved, or the other schedule used it last
   const bool fresh = wq.ptr != wq_before || ctx->frame_q_cap != q.W_cap || !ctx->frame_q_clean;

@@ -30,6 +30,7 @@ struct mocap_ctx {
   int prune = 1;            // stop a candidate group's reprojection once it cannot beat its root's best (exact)
   int eval_bb = 1;          // branch-and-bound evaluation of the candidates (frame_kernel.hip evaluate_bb)
   int bb_pl = 16;           // ... candidates per block (at least)
+  int bb_min_g = 512;       // ... frames with fewer candidates are walked exhaustively
   int bb_flush = 0;         // ... queued candidates that trigger their evaluation (0 = one per lane)
   int eigcut = 1;           // ... and drop it before the null vector / the reprojection on an eigenvalue bound (EigCut)
   double p3max2 = 0.0;      // EigCut constant of the current camera set (0: intrinsics not of the form the bound needs)

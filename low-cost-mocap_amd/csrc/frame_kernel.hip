@@ -1137,6 +1137,7 @@ __global__ __launch_bounds__(T, MOCAP_FRAME_WAVES_PER_EU) void frame_kernel(Fram
   const int R = p.K_max;
 
   int chunk_next = 0, chunk_end = 0;  // lane 0 only: frames of the chunk it pulled last
+  int done_local = 0;                 // lane 0 only: frames finished since the last count (MODE_ALL)
   if constexpr (MODE == MODE_ALL) {
     const bool bb = decltype(st)::TABLE && p.eval_bb != 0;
     bool frames_left = true;  // lane 0 only
@@ -1153,6 +1154,11 @@ __global__ __launch_bounds__(T, MOCAP_FRAME_WAVES_PER_EU) void frame_kernel(Fram
           if (item >= p.n_frames) {
             item = -1;
             frames_left = false;
+            if (done_local) {  // the frames of a chunk that reached past the end of the batch
+              wait_own_stores();
+              q_add(&q.counters[QC_FRAMES_DONE], done_local);
+              done_local = 0;
+            }
           } else {
             kind = 1;
           }
@@ -1234,6 +1240,9 @@ __global__ __launch_bounds__(T, MOCAP_FRAME_WAVES_PER_EU) void frame_kernel(Fram
         __syncthreads();
         st.write_frame_header(frame);  // n_out / status / n_cand are known after the match, whoever evaluates
       }
+      // the search pays its fixed cost (a dozen barrier-separated rounds) only on frames with enough candidates; small
+      // frames are walked exhaustively (same result either way)
+      const bool bb_frame = bb && G >= (uint32_t)p.bb_min_g;
       // candidate range of this item: the whole frame, nothing (deferred to its slices), or one slice
       uint32_t g_lo = 0, g_hi = G;
       if (kind == 1) {
@@ -1245,7 +1254,7 @@ __global__ __launch_bounds__(T, MOCAP_FRAME_WAVES_PER_EU) void frame_kernel(Fram
 #ifndef MOCAP_DEBUG_NO_EVAL  // timing experiments only: phases A-C without candidate evaluation
       if (g_hi > g_lo) {
         if constexpr (decltype(st)::TABLE) {
-          if (bb)
+          if (bb_frame)
             st.evaluate_bb();
           else
             st.evaluate(g_lo, g_hi);
@@ -1265,7 +1274,7 @@ __global__ __launch_bounds__(T, MOCAP_FRAME_WAVES_PER_EU) void frame_kernel(Fram
 #ifndef MOCAP_DEBUG_NO_EVAL
         if (g_hi > g_lo) {
           if constexpr (decltype(st)::TABLE)
-            won = bb ? st.root_winner_bb(r, e, gl, X) : st.root_winner(r, g_lo, g_hi, e, gl, X);
+            won = bb_frame ? st.root_winner_bb(r, e, gl, X) : st.root_winner(r, g_lo, g_hi, e, gl, X);
           else
             won = st.root_winner(r, g_lo, g_hi, e, gl, X);
         }
@@ -1282,10 +1291,17 @@ __global__ __launch_bounds__(T, MOCAP_FRAME_WAVES_PER_EU) void frame_kernel(Fram
         }
       }
       if (kind == 1) {
-        __syncthreads();
+        // finished frames are counted per chunk, not per frame: one device-scope atomic per frame on a single address
+        // tops out near 90 M/s, which small frames (4 x 4) exceed.  (Lane 0 published this frame's slices itself, so
+        // its own stores are the ones that have to be out before the count; the count is only read by workgroups
+        // waiting for tickets, after they have run out of frames.)
         if (tid == 0) {
-          wait_own_stores();
-          q_add(&q.counters[QC_FRAMES_DONE], 1);
+          done_local++;
+          if (chunk_next >= chunk_end) {
+            wait_own_stores();
+            q_add(&q.counters[QC_FRAMES_DONE], done_local);
+            done_local = 0;
+          }
         }
       } else {
         // the workgroup that finishes a heavy frame's LAST slice merges them: it already holds the frame's roots, hit

@@ -56,6 +56,7 @@ struct FrameArgs {
   int eval_bb;  // table mode: branch-and-bound evaluation (frame_kernel.hip evaluate_bb)
   int bb_pl;    // ... candidates per block (at least)
   int bb_flush; // ... queued candidates that trigger their evaluation
+  int bb_min_g; // ... frames with fewer candidates are walked exhaustively
   double p3max2;  // EigCut: (1 + 1e-5) * max |P[2]|^2 over the cameras, 0 = eigenvalue cut-off off (see mocap_device.hpp)
 };
 
