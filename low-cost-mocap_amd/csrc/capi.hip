@@ -310,6 +310,40 @@ extern "C" int mocap_set_cameras(mocap_ctx* ctx, int C, const double* K, const d
     p3 = std::fmax(p3, r[6] * r[6] + r[7] * r[7] + r[8] * r[8] + t[3 * c + 2] * t[3 * c + 2]);
   }
   ctx->p3max2 = plainK && std::isfinite(p3) ? p3 * (1.0 + 1e-5) : 0.0;
+  // the branch and bound takes its bounds in a frame whose origin is the point closest (least squares) to all optical
+  // axes -- any point gives a valid bound, one inside the working volume gives a tight one (eigcut_s1_shifted)
+  double A[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, bb[3] = {0, 0, 0};
+  for (int c = 0; c < C; c++) {
+    const double* r = R + 9 * c;
+    const double* tt = t + 3 * c;
+    const double d[3] = {r[6], r[7], r[8]};  // optical axis (R is orthonormal up to the user's rounding)
+    const double o[3] = {-(r[0] * tt[0] + r[3] * tt[1] + r[6] * tt[2]), -(r[1] * tt[0] + r[4] * tt[1] + r[7] * tt[2]),
+                         -(r[2] * tt[0] + r[5] * tt[1] + r[8] * tt[2])};  // camera centre -R^T t
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) {
+        const double pij = (i == j ? 1.0 : 0.0) - d[i] * d[j];
+        A[3 * i + j] += pij;
+        bb[i] += pij * o[j];
+      }
+  }
+  double c0[3] = {0, 0, 0};
+  {
+    const double det = A[0] * (A[4] * A[8] - A[5] * A[7]) - A[1] * (A[3] * A[8] - A[5] * A[6]) + A[2] * (A[3] * A[7] - A[4] * A[6]);
+    if (std::isfinite(det) && std::fabs(det) > 1e-6 * C * C * C) {  // (parallel axes: keep the world origin)
+      c0[0] = (bb[0] * (A[4] * A[8] - A[5] * A[7]) - A[1] * (bb[1] * A[8] - A[5] * bb[2]) + A[2] * (bb[1] * A[7] - A[4] * bb[2])) / det;
+      c0[1] = (A[0] * (bb[1] * A[8] - A[5] * bb[2]) - bb[0] * (A[3] * A[8] - A[5] * A[6]) + A[2] * (A[3] * bb[2] - bb[1] * A[6])) / det;
+      c0[2] = (A[0] * (A[4] * bb[2] - bb[1] * A[7]) - A[1] * (A[3] * bb[2] - bb[1] * A[6]) + bb[0] * (A[3] * A[7] - A[4] * A[6])) / det;
+      if (!(std::isfinite(c0[0]) && std::isfinite(c0[1]) && std::isfinite(c0[2]))) c0[0] = c0[1] = c0[2] = 0.0;
+    }
+  }
+  double p3c = 0.0;
+  for (int c = 0; c < C; c++) {
+    const double* r = R + 9 * c;
+    const double w = r[6] * c0[0] + r[7] * c0[1] + r[8] * c0[2] + t[3 * c + 2];
+    p3c = std::fmax(p3c, r[6] * r[6] + r[7] * r[7] + r[8] * r[8] + w * w);
+  }
+  for (int i = 0; i < 3; i++) ctx->eig_c0[i] = c0[i];
+  ctx->p3max2c = plainK && std::isfinite(p3c) ? p3c * (1.0 + 1e-5) : 0.0;
   return MOCAP_OK;
 }
 
@@ -474,8 +508,10 @@ static int match_dev_locked(mocap_ctx* ctx, int64_t n_frames, int M_max, const f
   a.prune = ctx->prune;
   a.p3max2 = ctx->prune && ctx->eigcut ? ctx->p3max2 : 0.0;
   if (!wide && ctx->frame_threads == 0 && T == 64) a.p3max2 = 0.0;  // tiny frames (a handful of candidates): the cut-offs cost more than they save
-  a.eval_bb = ctx->eval_bb && a.p3max2 > 0.0 && G_cap <= ((int64_t)1 << 24) && frame_bb_fits(ctx->C, M_max, K_max, T);
+  a.eval_bb = ctx->eval_bb && a.p3max2 > 0.0 && ctx->p3max2c > 0.0 && G_cap <= ((int64_t)1 << 24) && frame_bb_fits(ctx->C, M_max, K_max, T);
   a.bb_pl = ctx->bb_pl;
+  for (int i = 0; i < 3; i++) a.bb_c0[i] = ctx->eig_c0[i];
+  a.p3max2c = ctx->p3max2c;
   a.bb_flush = ctx->bb_flush > 0 ? ctx->bb_flush : T;
   a.bb_min_g = ctx->bb_min_g;
   while (a.bb_pl > 1 && (size_t)a.bb_pl * M_max * 2 * T >= ((size_t)1 << 22)) a.bb_pl /= 2;  // expanded-list counter: 22 bits

@@ -33,6 +33,8 @@ struct mocap_ctx {
   int bb_min_g = 512;       // ... frames with fewer candidates are walked exhaustively
   int bb_flush = 0;         // ... queued candidates that trigger their evaluation (0 = one per lane)
   int eigcut = 1;           // ... and drop it before the null vector / the reprojection on an eigenvalue bound (EigCut)
+  double eig_c0[3] = {0, 0, 0};  // ... origin for the branch-and-bound's bounds: the point closest to all optical axes
+  double p3max2c = 0.0;     // ... and the constant in that frame
   double p3max2 = 0.0;      // EigCut constant of the current camera set (0: intrinsics not of the form the bound needs)
   hipStream_t own_stream = nullptr, stream = nullptr;
   std::mutex mu;            // one context = one serialised caller (include/mocap_core.h)

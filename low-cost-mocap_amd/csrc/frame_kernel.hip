@@ -821,6 +821,7 @@ struct FrameState {
       ec.p3max2 = p.p3max2;
       ec.o2slack = (1100.0 * 0x1p-46) * (om * om);
     }
+    const double c0[3] = {p.bb_c0[0], p.bb_c0[1], p.bb_c0[2]};  // origin of the frame the block bounds are taken in
     const uint32_t PL = (uint32_t)p.bb_pl;
     for (int r = tid; r < nroots; r += T) {
       const uint8_t* a = act + (size_t)r * C;
@@ -913,7 +914,7 @@ struct FrameState {
       const double bound = __longlong_as_double((long long)rbound[r]);
       const double limit = bound * (double)(2 * vf) * (1.0 + 0x1p-40);
       const double limit_adj = fma(1.002, limit, (double)(2 * vf) * ec.o2slack);
-      return s1 * fma(2e-12, tr, ec.p3max2 * limit_adj) < 1.0;
+      return s1 * fma(2e-12, tr, p.p3max2c * limit_adj) < 1.0;
     };
     // ---- 1. seeds: the block with the largest s1 (smallest bound) of every root is evaluated first
     for (uint32_t b0 = 0; b0 < nblocks; b0 += T) {
@@ -925,7 +926,7 @@ struct FrameState {
         unsigned long long packed;
         const int v = group_matrix(r, gh, bnl[r], B, packed);
         float s1 = 0.0f;  // a one-view partial group carries no information: any block will do
-        if (v >= 2) s1 = (float)fmin(eigcut_s1(B, tr), 3e38);
+        if (v >= 2) s1 = (float)fmin(eigcut_s1_shifted(B, c0, tr), 3e38);
         atomicMax(&seedkey[r], ((unsigned long long)__float_as_uint(s1) << 32) | (unsigned long long)(0xFFFFFFFFu - gh));
       }
     }
@@ -1012,7 +1013,7 @@ struct FrameState {
           const int v = group_matrix(r, gh, bnl[r], B, packed);
           bool survive = true;
           if (v >= 2) {
-            const double s1 = eigcut_s1(B, tr);
+            const double s1 = eigcut_s1_shifted(B, c0, tr);
             survive = !dropped(r, s1, tr);
           }
           if (survive) push_block(r, gh, packed);

@@ -57,6 +57,8 @@ struct FrameArgs {
   int bb_pl;    // ... candidates per block (at least)
   int bb_flush; // ... queued candidates that trigger their evaluation
   int bb_min_g; // ... frames with fewer candidates are walked exhaustively
+  double bb_c0[3]; // branch and bound: origin of the frame its bounds are taken in (a point inside the working volume)
+  double p3max2c;  // ... (1 + 1e-5) * max |P[2] M|^2 in that frame
   double p3max2;  // EigCut: (1 + 1e-5) * max |P[2]|^2 over the cameras, 0 = eigenvalue cut-off off (see mocap_device.hpp)
 };
 
