@@ -734,12 +734,12 @@ struct FrameState {
   // The candidate groups of a root are a Cartesian product, and the DLT matrix of a group is a SUM over its views, so
   // a PARTIAL group (some cameras left open) bounds all its completions at once: B_partial <= B_full (positive
   // semi-definite terms), hence by EigCut's argument (mocap_device.hpp)
-  //     sum of squared residuals of ANY completion  >=  lam1(B_partial) / max_c |P_c[2]|^2 .
+  //     sum of squared residuals of ANY completion  >=  lam1(B_partial) / max_c |P_c[2]|^2
+  // (taken in a world frame moved to the middle of the working volume, eigcut_s1_shifted: same inequality, much tighter).
   // A root's candidates are split into BLOCKS: the `nl` fastest digits (product pl >= bb_pl) are left open, one block
   // per value of the remaining digits -- a contiguous run of pl candidate indices.  One Cholesky factorisation per
-  // block (eigcut_s1) drops the whole block when its bound exceeds the smallest error found for the root so far; only
-  // the candidates of surviving blocks are triangulated and reprojected.  On the 8 x 16 bench stream that is one block
-  // test per ~5 candidates and one evaluation per ~6, instead of one evaluation per candidate.
+  // block drops the whole block when its bound exceeds the smallest error found for the root so far; only the
+  // candidates of surviving blocks are triangulated and reprojected (counts and timings: DESIGN.md 3.1a).
   //   1. seeds: every block's s1; the block with the largest s1 (smallest bound) of each root almost always holds the
   //      root's winner: its candidates are evaluated first, which makes the bound tight before any block is tested;
   //   2. block tests, T at a time; the survivors' candidates are spread over all lanes of the workgroup (a block's
