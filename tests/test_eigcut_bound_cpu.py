@@ -110,3 +110,100 @@ def test_dlt_rows_are_depth_times_residual():
             p = P @ x
             rhs += p[2] ** 2 * ((o[0] - p[0] / p[2]) ** 2 + (o[1] - p[1] / p[2]) ** 2)
         assert abs(lhs - rhs) <= 1e-9 * max(abs(lhs), 1.0)
+
+
+def test_block_search_selects_what_the_exhaustive_walk_selects():
+    """A CPU model of the search the frame kernel runs (blocks of the Cartesian product, seed = the block
+    with the largest s1, drop a block when its bound beats the root's best error by the kernel's allowances, winner =
+    lexicographic minimum of (error, candidate index) over what was evaluated) against the reference's selection
+    (every candidate evaluated, np.argmin = first minimum), with the oracle's arithmetic for the errors."""
+    C, M = 8, 14
+    rig = synth.ring_rig(C)
+    blobs, counts, _ = synth.make_blob_stream(rig, 5, M, seed=11)
+    Ks, R, t = rig["K"], rig["R"], rig["t"]
+    P = np.stack([mo.projection_matrix(Ks[c], R[c], t[c]) for c in range(C)])
+    A, b = np.zeros((3, 3)), np.zeros(3)
+    for c in range(C):
+        Pm = np.eye(3) - np.outer(R[c][2], R[c][2])
+        A += Pm
+        b += Pm @ (-R[c].T @ t[c])
+    Mx = np.eye(4)
+    Mx[:3, 3] = np.linalg.solve(A, b)
+    p3max2 = float(np.max(((P[:, 2] @ Mx) ** 2).sum(1))) * (1 + 1e-5)
+    Ftab = mo.fundamental_table(Ks, R, t)
+    PL = 8
+    roots_checked = evaluated = total = 0
+    for f in range(blobs.shape[0]):
+        omax = float(np.abs(blobs[f][np.arange(M)[None, :] < counts[f][:, None]]).max())
+        o2slack = (1100.0 * 2.0 ** -46) * omax ** 2
+        roots, hits = mo.match_frame(blobs[f], counts[f], Ftab)
+        for r, root in enumerate(roots):
+            groups = list(mo.enumerate_groups(root, hits[r], C))
+            if len(groups) < 2 or (groups[0] >= 0).sum() < 2:
+                continue
+            G = len(groups)
+            v = int((groups[0] >= 0).sum())
+
+            def error(g):
+                corr = groups[g]
+                obs = np.full((C, 2), np.nan)
+                for c in range(C):
+                    if corr[c] >= 0:
+                        obs[c] = blobs[f, c, corr[c]]
+                e = mo.reprojection_error(obs, mo.triangulate_point(obs, Ks, R, t), Ks, R, t)
+                return np.inf if e is None or not np.isfinite(e) else float(e)
+
+            ref_err = [error(g) for g in range(G)]
+            ref_win = int(np.argmin(ref_err))                       # helpers.py:418
+            # blocks: the fastest digits (cameras root+1 ... with >= 2 hits) stay open until their product reaches PL
+            active = [c for c in range(root[0] + 1, C) if len(hits[r][c]) >= 2]
+            pl, nl = 1, 0
+            while nl < len(active) and pl < PL:
+                pl *= len(hits[r][active[nl]])
+                nl += 1
+            open_cams = set(active[:nl])
+            nblk = G // pl
+
+            def s1_of_block(gh):
+                corr = groups[gh * pl]                              # any candidate of the block: fixed cameras agree
+                B = np.zeros((4, 4))
+                views = 0
+                for c in range(C):
+                    if corr[c] >= 0 and c not in open_cams:
+                        B += _contribution(P[c], blobs[f, c, corr[c]])
+                        views += 1
+                if views < 2:
+                    return 0.0, 0.0
+                Bs = Mx.T @ B @ Mx
+                return float(np.trace(np.linalg.inv(Bs))), float(np.trace(Bs) + 2 * (Mx[:3, 3] @ Mx[:3, 3] + 1) * np.trace(B))
+
+            s1 = [s1_of_block(gh) for gh in range(nblk)]
+            seed = int(np.argmax([x[0] for x in s1]))
+            best = (np.inf, -1)
+            seen = set()
+
+            def evaluate_block(gh):
+                nonlocal best, evaluated
+                for g in range(gh * pl, (gh + 1) * pl):
+                    e = ref_err[g]
+                    evaluated += 1
+                    seen.add(g)
+                    if (e, g) < best:
+                        best = (e, g)
+
+            evaluate_block(seed)
+            for gh in range(nblk):
+                if gh == seed:
+                    continue
+                s, tr = s1[gh]
+                limit = best[0] * (2 * v) * (1 + 2.0 ** -40)
+                limit_adj = 1.002 * limit + (2 * v) * o2slack
+                dropped = s > 0.0 and s * (p3max2 * limit_adj + 2e-12 * tr) < 1.0
+                if not dropped:
+                    evaluate_block(gh)
+            assert best[1] == ref_win, (f, r, best, ref_win, ref_err[ref_win])
+            roots_checked += 1
+            total += G
+    assert roots_checked > 60
+    print('evaluated', evaluated, 'of', total)
+    assert evaluated < 0.5 * total  # and it does skip work
