@@ -305,11 +305,20 @@ int mocap_ba_profile(mocap_ctx* ctx, const double* x, int64_t N, const double* o
  *   ftol, xtol, gtol    termination tolerances (reference: ftol=1e-2, others 1e-8)
  *   max_iter            cap on LM iterations (0 = 100*n like scipy's max_nfev)
  *   f32_residuals       see above
- *   info [10]           (may be NULL) {iterations, nfev, status, cost0, cost, optimality, m, elapsed_ms, njev, 0}:
- *                       nfev / njev / status / cost / optimality as scipy's OptimizeResult reports them
- *                       (njev = 1 + accepted steps); iterations also counts passes whose every trial was rejected */
+ *   info [8]            (may be NULL) {iterations, nfev, status, cost0, cost, optimality, m, elapsed_ms}:
+ *                       nfev / status / cost / optimality as scipy's OptimizeResult reports them; iterations also
+ *                       counts passes whose every trial was rejected.  EXACTLY 8 doubles are written: this symbol
+ *                       keeps the buffer size it was first exported with. */
 int mocap_ba_solve(mocap_ctx* ctx, double* x, int64_t N, const double* obs, double ftol, double xtol,
                    double gtol, int max_iter, int f32_residuals, int use_cauchy, double* info);
+
+/* mocap_ba_solve_ex: the same solve; `info_len` = doubles the caller's `info` holds, min(info_len,
+ * MOCAP_BA_INFO_DOUBLES) are written: the 8 above, then [8] njev (= 1 + accepted steps, scipy's count), [9] number of
+ * linearisations that had to be launched a second time because the kernel launched ahead of the host's decision had
+ * abandoned itself (device watchdog, 2 s: the host was held up between two iterations; 0 in normal operation). */
+#define MOCAP_BA_INFO_DOUBLES 10
+int mocap_ba_solve_ex(mocap_ctx* ctx, double* x, int64_t N, const double* obs, double ftol, double xtol,
+                      double gtol, int max_iter, int f32_residuals, int use_cauchy, double* info, int info_len);
 
 #ifdef __cplusplus
 }

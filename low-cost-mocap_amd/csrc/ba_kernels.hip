@@ -463,7 +463,16 @@ __global__ __launch_bounds__(kFusedThreads) void ba_fused_kernel(BaFusedArgs a) 
       drain_stores();
       __syncthreads();
       if (tid == 0) st_agent(&dm[0], sh_last ? a.stamp : -a.stamp);  // -stamp: this launch is abandoned
-      if (!sh_last) return;
+      if (!sh_last) {
+        // ... and the host is told so (it may be on its way to hand this launch a point: a watchdog exit, not a quit tag):
+        // -stamp in the completion word makes it relaunch with the point passed by value instead of waiting for a stamp
+        // that will never come
+        if (tid == 0) {
+          __threadfence_system();
+          *(volatile double*)(a.out + (size_t)NP * NP + 2) = -a.stamp;
+        }
+        return;
+      }
     } else {
       if (tid == 0) {
         const unsigned long long t0 = wall_clock64();
@@ -786,6 +795,27 @@ hipError_t launch_ba_cost(const double* r, const int32_t* valid, int64_t m, int 
                           int use_cauchy, double* out, hipStream_t stream) {
   hipLaunchKernelGGL(ba_cost_kernel, dim3(1), dim3(256), 0, stream, r, valid, m, f32_residuals, use_cauchy,
                      out);
+  return hipGetLastError();
+}
+
+// Stage-in without a copy engine: 4-byte words from device-visible (pinned) host memory to device memory, and the
+// arrival counters of the one-launch linearisation back to zero.  mocap_ba_solve's set-up used hipMemcpyAsync from the
+// caller's pageable arrays and hipMemsetAsync; both go through runtime-internal machinery (user-pointer pinning, SDMA
+// queues, blit kernels created on first use) that a solve of a few milliseconds should not depend on.
+__global__ void ba_stage_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, size_t n_words,
+                                uint32_t* __restrict__ zero, size_t n_zero) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += stride) dst[i] = src[i];
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_zero; i += stride) zero[i] = 0u;
+}
+
+hipError_t launch_ba_stage(const void* src, void* dst, size_t n_words, void* zero, size_t n_zero_words, hipStream_t stream) {
+  const size_t work = n_words > n_zero_words ? n_words : n_zero_words;
+  if (!work) return hipSuccess;
+  size_t grid = (work + 255) / 256;
+  if (grid > 1024) grid = 1024;
+  hipLaunchKernelGGL(ba_stage_kernel, dim3((unsigned)grid), dim3(256), 0, stream, (const uint32_t*)src, (uint32_t*)dst, n_words,
+                     (uint32_t*)zero, n_zero_words);
   return hipGetLastError();
 }
 

@@ -16,6 +16,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <thread>
 #include <cmath>
 #include <limits>
 #include <cstdio>
@@ -268,6 +269,12 @@ struct BaWork {
          *d_fmail = nullptr;
   bool prearm = false, armed = false;  // a linearisation kernel launched ahead of its base point (ba_fused_kernel)
   double armed_stamp = 0.0;
+  // MOCAP_BA_PROFILE: where a slow linearisation spent its time.  A large gap between two consecutive clock reads of
+  // the spinning host thread means the THREAD was not running (pre-empted / CFS-throttled), not that the GPU was slow.
+  bool prof = false;
+  int handovers = 0;         // points handed to a launched-ahead kernel in this solve
+  int prof_relaunches = 0;   // linearisations repeated because a launched-ahead kernel had abandoned itself
+  double prof_wait_max_ms = 0.0, prof_gap_max_ms = 0.0, prof_launch_max_ms = 0.0, prof_setup_ms = 0.0;
   int32_t* d_fcounters = nullptr;
 };
 
@@ -303,6 +310,18 @@ int ba_setup(mocap_ctx* ctx, BaWork& w, int64_t N, const double* obs, int Pmax, 
                nd_part = al((size_t)w.ksplit * w.NP * w.NP), nd_G = al((size_t)w.NP * w.NP), nd_cost = 32,
                nd_rho = al((size_t)std::max<int64_t>(w.m, 1));
   const size_t total = nd_x + nd_params + nd_h + nd_Pq + nd_RT + nd_obs + nd_r + nd_J + nd_part + nd_G + nd_cost + nd_rho;
+  void* zero_ptr = nullptr;
+  size_t zero_words = 0;
+  const auto ts0 = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!w.prof) return;
+    static thread_local std::chrono::steady_clock::time_point last;
+    const auto tn = std::chrono::steady_clock::now();
+    const double d = std::chrono::duration<double, std::milli>(tn - (what ? last : ts0)).count();
+    if (what && d > 0.3) fprintf(stderr, "[ba_setup] %s: %.3f ms\n", what, d);
+    last = tn;
+  };
+  lap(nullptr);
   if (ctx->scratch[1].reserve(total * sizeof(double))) return ctx->fail(MOCAP_E_HIP, "hipMalloc(BA workspace) failed");
   if (ctx->scratch[2].reserve(sizeof(int32_t) * (size_t)std::max<int64_t>(w.m, 1)))
     return ctx->fail(MOCAP_E_HIP, "hipMalloc(BA valid list) failed");
@@ -320,6 +339,7 @@ int ba_setup(mocap_ctx* ctx, BaWork& w, int64_t N, const double* obs, int Pmax, 
   w.d_cost = p;     p += nd_cost;
   w.d_rho = p;
   w.d_valid = (int32_t*)ctx->scratch[2].ptr;
+  lap("device workspace (hipMalloc)");
   // one launch per linearisation when the rig fits the fused kernel's LDS budget (MOCAP_BA_UNFUSED=1: the chain
   // of five launches it replaces, kept as the fallback for large rigs and for A/B measurements)
   // Any point count: the Gram partials are added by a 16-ary tree of last-arriver workgroups, so the serial tail
@@ -342,11 +362,13 @@ int ba_setup(mocap_ctx* ctx, BaWork& w, int64_t N, const double* obs, int Pmax, 
     w.d_fcounters = (int32_t*)q;  q += nd_cnt;
     w.d_fmail = q;     q += nd_mail;
     w.d_fJaug = want_jaug ? q : nullptr;
-    HIP_TRY(ctx, hipMemsetAsync(w.d_fcounters, 0, (nd_cnt + nd_mail) * sizeof(double), ctx->stream));  // the kernel leaves the counters at zero
+    zero_ptr = w.d_fcounters;  // (the kernel leaves its counters at zero; the mailbox mirror is re-tagged per launch)
+    zero_words = (nd_cnt + nd_mail) * sizeof(double) / 4;
     nd_fout = al((size_t)w.NP * w.NP + 3) + al(8 * 19);  // + mailbox: 19 lines of {tag, 7 doubles} (n <= 127)
     // launch-ahead: the mailbox poll reads 16 lines of 7 parameters in one go; used where it was validated
     w.prearm = !getenv("MOCAP_BA_NO_PREARM") && w.n <= 112 && N <= 2048;
   }
+  lap("fused workspace (hipMalloc)");
   const size_t pin_bytes = sizeof(double) * (nd_x + nd_G + nd_cost + nd_fout);
   if (pin_bytes > ctx->ba_pin_cap) {
     if (ctx->ba_pin) (void)hipHostFree(ctx->ba_pin);
@@ -361,13 +383,46 @@ int ba_setup(mocap_ctx* ctx, BaWork& w, int64_t N, const double* obs, int Pmax, 
   w.h_G = w.h_x + nd_x;
   w.h_fout = w.fused ? w.h_G + nd_G + nd_cost : nullptr;
   if (w.h_fout) {
-    w.h_fout[(size_t)w.NP * w.NP + 2] = -1.0;
+    w.h_fout[(size_t)w.NP * w.NP + 2] = 0.0;  // neither a stamp (>= 1) nor an abandon mark (-stamp)
     w.h_mail = w.h_fout + al((size_t)w.NP * w.NP + 3);
     w.h_mail[0] = 0.0;
   }
-  HIP_TRY(ctx, hipMemcpyAsync(w.d_obs, obs, sizeof(double) * (size_t)N * C * 2, hipMemcpyHostToDevice, ctx->stream));
-  if (w.m)
-    HIP_TRY(ctx, hipMemcpyAsync(w.d_valid, w.valid.data(), sizeof(int32_t) * (size_t)w.m, hipMemcpyHostToDevice, ctx->stream));
+  lap("pinned result buffer (hipHostMalloc)");
+  // Stage-in.  Default: the inputs are copied into the context's own pinned staging buffer and pulled to the device by
+  // ONE small kernel that also zeroes the arrival counters -- no copy engine, no pinning of the caller's pages, no
+  // runtime blit kernel.  MOCAP_BA_STAGE=0 (hipMemcpyAsync from the caller's arrays + hipMemsetAsync, the round-2 path)
+  // and =1 (pinned staging + hipMemcpyAsync) stay for A/B runs (scripts/diag_ba_stall.py).
+  static const int stage_mode = getenv("MOCAP_BA_STAGE") ? atoi(getenv("MOCAP_BA_STAGE")) : 2;
+  const size_t b_obs = sizeof(double) * (size_t)N * C * 2, b_valid = sizeof(int32_t) * (size_t)w.m;
+  if (stage_mode == 0) {
+    if (zero_words) HIP_TRY(ctx, hipMemsetAsync(zero_ptr, 0, zero_words * 4, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(w.d_obs, obs, b_obs, hipMemcpyHostToDevice, ctx->stream));
+    if (w.m) HIP_TRY(ctx, hipMemcpyAsync(w.d_valid, w.valid.data(), b_valid, hipMemcpyHostToDevice, ctx->stream));
+    lap("pageable copies + memset queued");
+    return MOCAP_OK;
+  }
+  if (b_obs + b_valid > ctx->ba_stage_cap) {
+    if (ctx->ba_stage) (void)hipHostFree(ctx->ba_stage);
+    ctx->ba_stage = nullptr;
+    ctx->ba_stage_cap = 0;
+    const size_t want = std::max<size_t>((b_obs + b_valid) * 5 / 4, (size_t)1 << 20);
+    HIP_TRY(ctx, hipHostMalloc(&ctx->ba_stage, want, hipHostMallocDefault));
+    ctx->ba_stage_cap = want;
+    lap("pinned staging buffer (hipHostMalloc)");
+  }
+  char* st = (char*)ctx->ba_stage;
+  memcpy(st, obs, b_obs);
+  if (w.m) memcpy(st + b_obs, w.valid.data(), b_valid);
+  lap("host copy into the staging buffer");
+  if (stage_mode == 1) {
+    if (zero_words) HIP_TRY(ctx, hipMemsetAsync(zero_ptr, 0, zero_words * 4, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(w.d_obs, st, b_obs, hipMemcpyHostToDevice, ctx->stream));
+    if (w.m) HIP_TRY(ctx, hipMemcpyAsync(w.d_valid, st + b_obs, b_valid, hipMemcpyHostToDevice, ctx->stream));
+  } else {
+    HIP_TRY(ctx, launch_ba_stage(st, w.d_obs, b_obs / 4, zero_ptr, zero_words, ctx->stream));
+    if (w.m) HIP_TRY(ctx, launch_ba_stage(st + b_obs, w.d_valid, b_valid / 4, nullptr, 0, ctx->stream));
+  }
+  lap("stage-in queued");
   return MOCAP_OK;
 }
 
@@ -482,6 +537,7 @@ int ba_disarm(mocap_ctx* ctx, BaWork& w) {
   __atomic_thread_fence(__ATOMIC_RELEASE);
   *(volatile double*)w.h_mail = -1.0;
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  *(volatile double*)w.h_mail = 0.0;  // the next launch-ahead must not read the quit tag before its point arrives
   return MOCAP_OK;
 }
 struct BaDisarmGuard {
@@ -495,6 +551,7 @@ int ba_linearize_fused(mocap_ctx* ctx, BaWork& w, const double* x, int f32, int 
                        std::vector<double>& G, double& cost, bool* finite) {
   double stamp = 0.0;
   int rc;
+  const auto t_launch0 = std::chrono::steady_clock::now();
   if (w.prearm) {
     // the kernel for THIS point was launched while the host was still computing the point (it is resident and
     // polls the mailbox): hand it x, then queue the next one behind it before waiting
@@ -504,6 +561,15 @@ int ba_linearize_fused(mocap_ctx* ctx, BaWork& w, const double* x, int f32, int 
       w.armed = true;
     }
     stamp = w.armed_stamp;
+    {  // test hook: MOCAP_BA_DEBUG_HOST_STALL="k:ms" holds the host up for ms before the k-th hand-over of a solve, long
+       // enough (> 2 s) for the device watchdog to abandon the resident kernel (tests/test_gpu_ba.py)
+      static const char* hook = getenv("MOCAP_BA_DEBUG_HOST_STALL");
+      if (hook) {
+        int k = 0, ms_ = 0;
+        if (sscanf(hook, "%d:%d", &k, &ms_) == 2 && w.handovers == k) std::this_thread::sleep_for(std::chrono::milliseconds(ms_));
+      }
+      w.handovers++;
+    }
     // mailbox = 64-byte lines {tag, 7 doubles of x}: data first, then the tag of the line
     for (int l = 0; l * 7 < w.n; l++) {
       volatile double* line = w.h_mail + 8 * l;
@@ -519,12 +585,32 @@ int ba_linearize_fused(mocap_ctx* ctx, BaWork& w, const double* x, int f32, int 
     rc = ba_fused_launch(ctx, w, x, f32, cauchy, rel_step, stamp);
     if (rc) return rc;
   }
+  if (w.prof)
+    w.prof_launch_max_ms = std::max(w.prof_launch_max_ms, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_launch0).count());
   // the kernel's last workgroup stores G, the cost and then the stamp into this pinned buffer: spin on the stamp
   // (a few microseconds; an event query costs a driver call per poll)
   const size_t nG = (size_t)w.NP * w.NP;
   volatile double* done = w.h_fout + nG + 2;
   const auto t0 = std::chrono::steady_clock::now();
+  auto t_prev = t0;
   for (long spins = 0; *done != stamp; spins++) {
+    if (*done == -stamp) {
+      // the launched-ahead kernel gave up before the point reached it (device watchdog: the host was held up for
+      // seconds between arming it and this call -- a progress callback, a descheduled thread): same linearisation
+      // again, point passed by value, no launch-ahead until the next call re-arms
+      rc = ba_disarm(ctx, w);  // the launch queued behind the dead one would wait for ITS point until its own watchdog fires
+      if (rc) return rc;
+      HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+      rc = ba_fused_launch(ctx, w, x, f32, cauchy, rel_step, stamp);
+      if (rc) return rc;
+      w.prof_relaunches++;
+      continue;
+    }
+    if (w.prof && (spins & 0xff) == 0xff) {
+      const auto tn = std::chrono::steady_clock::now();
+      w.prof_gap_max_ms = std::max(w.prof_gap_max_ms, std::chrono::duration<double, std::milli>(tn - t_prev).count());
+      t_prev = tn;
+    }
     if ((spins & 0xffff) == 0xffff) {
       const hipError_t e = hipStreamQuery(ctx->stream);  // a failed launch never writes the stamp
       if (e != hipSuccess && e != hipErrorNotReady) return ctx->hip_fail(e, "ba_fused_kernel");
@@ -533,6 +619,8 @@ int ba_linearize_fused(mocap_ctx* ctx, BaWork& w, const double* x, int f32, int 
     }
   }
   __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  if (w.prof)
+    w.prof_wait_max_ms = std::max(w.prof_wait_max_ms, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
   const int n = w.n, NP = w.NP;
   G.assign(nG, 0.0);
   for (int i = 0; i <= n; i++)
@@ -833,8 +921,29 @@ extern "C" int mocap_ba_profile(mocap_ctx* ctx, const double* x, int64_t N, cons
   return MOCAP_OK;
 }
 
+static int ba_solve_impl(mocap_ctx* ctx, double* x, int64_t N, const double* obs, double ftol, double xtol, double gtol,
+                         int max_iter, int f32_residuals, int use_cauchy, double* info_out, int info_len);
+
+// info [8]: the layout this symbol has had since it was first exported -- a caller's 8-double buffer stays valid
 extern "C" int mocap_ba_solve(mocap_ctx* ctx, double* x, int64_t N, const double* obs, double ftol, double xtol,
                               double gtol, int max_iter, int f32_residuals, int use_cauchy, double* info) {
+  return ba_solve_impl(ctx, x, N, obs, ftol, xtol, gtol, max_iter, f32_residuals, use_cauchy, info, 8);
+}
+
+// the same with the caller stating how many doubles `info` holds (at most MOCAP_BA_INFO_DOUBLES are written)
+extern "C" int mocap_ba_solve_ex(mocap_ctx* ctx, double* x, int64_t N, const double* obs, double ftol, double xtol,
+                                 double gtol, int max_iter, int f32_residuals, int use_cauchy, double* info, int info_len) {
+  return ba_solve_impl(ctx, x, N, obs, ftol, xtol, gtol, max_iter, f32_residuals, use_cauchy, info, info_len);
+}
+
+static int ba_solve_impl(mocap_ctx* ctx, double* x, int64_t N, const double* obs, double ftol, double xtol, double gtol,
+                         int max_iter, int f32_residuals, int use_cauchy, double* info_out, int info_len) {
+  double info_buf[MOCAP_BA_INFO_DOUBLES] = {0};
+  double* info = info_out ? info_buf : nullptr;
+  struct InfoCopy {  // every return path hands over what was filled in
+    double* dst; const double* src; int n;
+    ~InfoCopy() { if (dst) memcpy(dst, src, sizeof(double) * (size_t)std::max(0, std::min(n, (int)MOCAP_BA_INFO_DOUBLES))); }
+  } info_copy{info_out, info_buf, info_len};
   if (!ctx) return MOCAP_E_ARG;
   std::lock_guard<std::mutex> lk(ctx->mu);
   if (!x) return ctx->fail(MOCAP_E_ARG, "mocap_ba_solve: bad argument");
@@ -847,8 +956,10 @@ extern "C" int mocap_ba_solve(mocap_ctx* ctx, double* x, int64_t N, const double
     return std::chrono::duration<double, std::milli>(b - a).count();
   };
   BaWork w;
+  w.prof = prof;
   int rc = ba_setup(ctx, w, N, obs, 1 + 7 * (ctx->C - 1) + 1);
   if (rc) return rc;
+  w.prof_setup_ms = ms(t_begin, now());
   BaDisarmGuard guard{ctx, &w};  // every return path below abandons the kernel that was launched ahead
   const int n = w.n, NP = w.NP;
   if (w.m < 1) return ctx->fail(MOCAP_E_ARG, "mocap_ba_solve: no point is seen by two cameras");
@@ -856,8 +967,10 @@ extern "C" int mocap_ba_solve(mocap_ctx* ctx, double* x, int64_t N, const double
 
   std::vector<double> xv(x, x + n), G, JtJ((size_t)n * n), g(n), step, x_new(n);
   double cost = 0;
+  const auto t_first0 = now();
   rc = ba_linearize(ctx, w, xv.data(), f32_residuals, use_cauchy, G, cost);
   if (rc) return rc;
+  const double t_first = ms(t_first0, now());
   const double cost0 = cost;
   int nfev = 1, njev = 1, iteration = 0, termination = 0;
   double Delta = norm2(xv);  // x_scale = 1 (scipy default)
@@ -868,6 +981,7 @@ extern "C" int mocap_ba_solve(mocap_ctx* ctx, double* x, int64_t N, const double
   TrSubproblem tr;
   bool have_trial = false;
   const bool speculate = !getenv("MOCAP_BA_NO_SPECULATION");
+  if (!speculate) w.prearm = false;  // cost-only evaluations queue plain kernels on the stream: nothing may be parked on it
   std::vector<double> G_trial;
 
   while (true) {
@@ -954,7 +1068,13 @@ extern "C" int mocap_ba_solve(mocap_ctx* ctx, double* x, int64_t N, const double
     if (actual_reduction > 0) {
       xv = x_new;
       cost = cost_new;
-      if (ctx->ba_progress) ctx->ba_progress(xv.data(), n, ctx->ba_progress_user);  // once per accepted step
+      if (ctx->ba_progress) {
+        // once per accepted step.  The callback is the caller's code (a socket emit under the GIL in the reference's
+        // handler): no kernel may sit on the GPU polling for a point while it runs, however long it takes
+        rc = ba_disarm(ctx, w);
+        if (rc) return rc;
+        ctx->ba_progress(xv.data(), n, ctx->ba_progress_user);
+      }
       njev++;              // scipy re-linearises even when it is about to stop (trf.py:534); the result is unused,
       if (!termination) {  // so only the count is kept
         const auto tl0 = now();
@@ -990,7 +1110,10 @@ extern "C" int mocap_ba_solve(mocap_ctx* ctx, double* x, int64_t N, const double
   }
   if (prof)
     fprintf(stderr, "[mocap_ba_solve] iterations %d nfev %d njev %d: linearize %.2f ms, eigen %.2f ms, trust region %.2f ms, "
-            "cost evals %.2f ms, total %.2f ms\n", iteration, nfev, njev, t_lin, t_eig, t_tr, t_cost, ms(t_begin, now()));
+            "cost evals %.2f ms, total %.2f ms | setup %.3f ms, first linearise %.3f ms, longest launch call %.3f ms, longest "
+            "wait for a stamp %.3f ms, longest gap between two clock reads of the spinning host thread %.3f ms\n",
+            iteration, nfev, njev, t_lin, t_eig, t_tr, t_cost, ms(t_begin, now()), w.prof_setup_ms, t_first, w.prof_launch_max_ms,
+            w.prof_wait_max_ms, w.prof_gap_max_ms);
   if (info) {
     const auto t_end = std::chrono::steady_clock::now();
     info[0] = iteration;
@@ -1002,7 +1125,7 @@ extern "C" int mocap_ba_solve(mocap_ctx* ctx, double* x, int64_t N, const double
     info[6] = (double)w.m;
     info[7] = std::chrono::duration<double, std::milli>(t_end - t_begin).count();
     info[8] = njev;
-    info[9] = 0.0;
+    info[9] = w.prof_relaunches;
   }
   return termination ? MOCAP_OK : MOCAP_E_NOCONV;
 }

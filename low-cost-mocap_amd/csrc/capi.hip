@@ -121,6 +121,7 @@ extern "C" void mocap_destroy(mocap_ctx* ctx) {
   ctx->img_zero.release();
   ctx->world.release();
   if (ctx->ba_pin) (void)hipHostFree(ctx->ba_pin);
+  if (ctx->ba_stage) (void)hipHostFree(ctx->ba_stage);
   if (ctx->ba_event) (void)hipEventDestroy(ctx->ba_event);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;

@@ -51,6 +51,8 @@ struct mocap_ctx {
   void* ba_pin = nullptr;
   size_t ba_pin_cap = 0;
   hipEvent_t ba_event = nullptr;
+  void* ba_stage = nullptr;  // pinned staging of a solve's inputs (observations | valid list): no pageable copies
+  size_t ba_stage_cap = 0;
   void (*ba_progress)(const double* x, int n, void* user) = nullptr;  // mocap_set_ba_progress
   void* ba_progress_user = nullptr;
   DevBuf ba_fused;          // one-launch linearisation: chunk partial tiles | chunk costs | counters | (Jaug dump)

@@ -231,6 +231,9 @@ size_t ba_fused_records(int chunks);   // records of the reduction tree (one per
 size_t ba_fused_counters(int chunks);  // arrival counters: one per chunk, one per tree node
 hipError_t launch_ba_fused(const BaFusedArgs& a, hipStream_t stream);
 
+// words (4 bytes) from pinned host memory -> device memory, plus `n_zero_words` words at `zero` set to 0, in one launch
+hipError_t launch_ba_stage(const void* src, void* dst, size_t n_words, void* zero, size_t n_zero_words, hipStream_t stream);
+
 // cost-only evaluation: sum of rho over valid points of residual row r [N]
 hipError_t launch_ba_cost(const double* r, const int32_t* valid, int64_t m, int f32_residuals,
                           int use_cauchy, double* out /*[2]: cost, finite flag*/, hipStream_t stream);

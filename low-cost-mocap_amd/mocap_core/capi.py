@@ -65,6 +65,7 @@ SIGNATURES = {
     "mocap_set_ba_progress": (_i32, [_vp, _vp, _vp]),
     "mocap_ba_profile": (_i32, [_vp, _vp, _i64, _vp, _i32, _i32, _i32, _vp]),
     "mocap_ba_solve": (_i32, [_vp, _vp, _i64, _vp, _dbl, _dbl, _dbl, _i32, _i32, _i32, _vp]),
+    "mocap_ba_solve_ex": (_i32, [_vp, _vp, _i64, _vp, _dbl, _dbl, _dbl, _i32, _i32, _i32, _vp, _i32]),
 }
 
 _lib = None
@@ -403,8 +404,8 @@ class MocapCore:
         x = np.array(x0, dtype=np.float64)
         obs = np.ascontiguousarray(obs, dtype=np.float64).reshape(-1, self.C, 2)
         info = np.zeros(10)
-        rc = self._check(self.lib.mocap_ba_solve(self._h, _p(x), obs.shape[0], _p(obs), float(ftol), float(xtol),
-                                                 float(gtol), int(max_iter), int(f32_residuals), int(use_cauchy),
-                                                 _p(info)), allow=(MOCAP_E_NOCONV,))
-        keys = ("iterations", "nfev", "status", "cost0", "cost", "optimality", "m", "elapsed_ms", "njev")
+        rc = self._check(self.lib.mocap_ba_solve_ex(self._h, _p(x), obs.shape[0], _p(obs), float(ftol), float(xtol),
+                                                    float(gtol), int(max_iter), int(f32_residuals), int(use_cauchy),
+                                                    _p(info), info.size), allow=(MOCAP_E_NOCONV,))
+        keys = ("iterations", "nfev", "status", "cost0", "cost", "optimality", "m", "elapsed_ms", "njev", "relaunches")
         return x, dict(zip(keys, info.tolist()), converged=(rc == MOCAP_OK))

@@ -14,8 +14,9 @@ Two payload formats:
   * compact (compact_tracks / gather_compact_async, what bench.py uses at N > 1): only the valid points travel,
     as records of track_record_bytes(C) = 32 + 2 C bytes (padded to 8) in frame order, plus n_out int32 per frame:
     1.1 KB per frame.  The records are produced on the device by mocap_compact_tracks_dev (prefix sum over n_out
-    + scatter); shard sizes differ, so the exchange is count-first: an all-gather of one int64 per rank, then
-    point-to-point transfers of exactly the valid bytes into the root (7 xGMI links, no ring).
+    + scatter); shard sizes differ, so the exchange is count-first with the count riding in the first point-to-point
+    message ({record count | n_out}, fixed size), then exactly the valid bytes (7 xGMI links into the root, no ring,
+    no collective, no host synchronisation on the senders).
 """
 import os
 
@@ -203,9 +204,14 @@ def unpack_compact(n_out, records, C, K_max, fill=np.nan):
 class TrackCompactor:
     """Device buffers + launch of mocap_compact_tracks_dev for one shard (reused from step to step).
     compact() enqueues on the core's stream and returns immediately; count() is the number of records of the LAST
-    compact() and waits for it (the kernel drops the count into pinned host memory)."""
+    compact() and waits for it (the kernel drops the count into pinned host memory).
 
-    def __init__(self, core, F, K_max, C, device, n_buffers=2):
+    Buffer reuse: an exchange that is still in flight reads records[i] / n_out[i] (the sender's isend, the root's lazy
+    view of its own shard), so the handle returned by gather_compact_async is attached to its buffer (attach()) and
+    compact() completes that handle before it lets the kernels overwrite the buffer.  With n_buffers >= the number of
+    exchanges the caller keeps in flight + 1 that wait never blocks."""
+
+    def __init__(self, core, F, K_max, C, device, n_buffers=3):
         import torch
         self.core, self.F, self.K, self.C = core, int(F), int(K_max), int(C)
         self.stride = track_record_bytes(C)
@@ -214,11 +220,20 @@ class TrackCompactor:
         self.n_out = [torch.empty(self.F, dtype=torch.int32, device=device) for _ in range(n_buffers)]
         self.totals = [torch.zeros(1, dtype=torch.int64).pin_memory() for _ in range(n_buffers)]
         self.events = [torch.cuda.Event() for _ in range(n_buffers)]
+        self._pending = [None] * n_buffers
         self._i = -1
+
+    def attach(self, i, handle):
+        """The exchange `handle` reads buffer i: compact() will not reuse the buffer before the handle is complete."""
+        self._pending[i] = handle
+        return handle
 
     def compact(self, n_out, xyz, err, corr, stream):
         self._i = (self._i + 1) % len(self.records)
         i = self._i
+        if self._pending[i] is not None:
+            self._pending[i].result()      # idempotent: the caller's own result() later returns the same tensors
+            self._pending[i] = None
         self.core.compact_tracks_dev(self.F, self.K, n_out.data_ptr(), xyz.data_ptr(), err.data_ptr(), corr.data_ptr(),
                                      self.offsets[i].data_ptr(), self.records[i].data_ptr(), self.F * self.K,
                                      self.totals[i].data_ptr())
@@ -233,54 +248,82 @@ class TrackCompactor:
 
 class PendingCompactGather:
     """In-flight compact exchange.  result() on `dst`: (n_out int32 [sum F_r] tensor, records uint8 [sum P_r][stride]
-    tensor) in rank order; None elsewhere."""
+    tensor) in rank order; None elsewhere.  result() may be called more than once (the first call completes the
+    transfers and materialises the concatenation, later calls return it)."""
 
     def __init__(self, works, n_parts, r_parts, is_dst):
         self._works, self._n, self._r, self._is_dst = works, n_parts, r_parts, is_dst
+        self._done, self._out = False, None
 
     def result(self):
         import torch
-        for w in self._works:
-            w.wait()
-        self._works = []
-        if not self._is_dst:
-            return None
-        return torch.cat(self._n), torch.cat(self._r)
+        if not self._done:
+            for w in self._works:
+                w.wait()
+            self._works = []
+            if self._is_dst:
+                # torch.cat copies: the result no longer aliases the compactor's buffers
+                self._out = (torch.cat(self._n), torch.cat(self._r))
+            self._n = self._r = None
+            self._done = True
+        return self._out
+
+
+COMPACT_HEADER_BYTES = 8   # int64 record count in front of the shard's n_out array
 
 
 def gather_compact_async(n_out, records, n_records, frames_per_rank, dst=0):
     """The one exchange of the path in its compact form.  n_out: this shard's int32 [F_r]; records: uint8
     [>= n_records][stride] (only the first n_records rows travel); frames_per_rank: F_r of every rank (static,
-    from shard_bounds).  Count-first: an all-gather of one int64 per rank tells the root how many records each
-    shard holds, then every rank sends exactly its valid bytes point to point."""
+    from shard_bounds).
+
+    Count-first WITHOUT a collective: every sender's first message has a fixed size -- {int64 record count | n_out
+    int32 [F_r]} -- and its second message carries exactly the valid records.  Senders post both and return at once
+    (no host synchronisation at all).  The root posts the header receives, waits for those small messages only (on
+    the stream it was called on: the compute stream keeps running the kernels that were queued before), reads the
+    counts and posts the record receives of the right sizes.  This replaces an all_gather + .item() per step, which
+    synchronised every rank's host with every other rank's GPU inside the pipeline."""
     import torch
     import torch.distributed as dist
     rec = records[:n_records]
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return PendingCompactGather([], [n_out], [rec], True)
     world, rank = dist.get_world_size(), dist.get_rank()
-    mine = torch.tensor([int(n_records)], dtype=torch.int64, device=n_out.device)
-    counts = [torch.zeros_like(mine) for _ in range(world)]
-    dist.all_gather(counts, mine)
-    counts = [int(c.item()) for c in counts]
     stride = records.shape[1]
-    ops, n_parts, r_parts = [], [], []
-    if rank == dst:
-        for r in range(world):
-            if r == dst:
-                n_parts.append(n_out)
-                r_parts.append(rec)
-                continue
-            nb = torch.empty(int(frames_per_rank[r]), dtype=torch.int32, device=n_out.device)
-            rb = torch.empty((counts[r], stride), dtype=torch.uint8, device=n_out.device)
-            n_parts.append(nb)
-            r_parts.append(rb)
-            ops.append(dist.P2POp(dist.irecv, nb.view(torch.uint8), r))
-            if counts[r]:
-                ops.append(dist.P2POp(dist.irecv, rb, r))
-    else:
-        ops.append(dist.P2POp(dist.isend, n_out.contiguous().view(torch.uint8), dst))
+    dev = n_out.device
+    if rank != dst:
+        head = torch.empty(COMPACT_HEADER_BYTES + 4 * n_out.numel(), dtype=torch.uint8, device=dev)
+        head[:COMPACT_HEADER_BYTES] = torch.tensor([int(n_records)], dtype=torch.int64).view(torch.uint8).to(dev, non_blocking=True)
+        head[COMPACT_HEADER_BYTES:] = n_out.contiguous().view(torch.uint8)
+        # two groups, mirroring the root's two receive groups (header first, then the records)
+        works = list(dist.batch_isend_irecv([dist.P2POp(dist.isend, head, dst)]))
         if n_records:
-            ops.append(dist.P2POp(dist.isend, rec.contiguous(), dst))
-    works = dist.batch_isend_irecv(ops) if ops else []
-    return PendingCompactGather(list(works), n_parts, r_parts, rank == dst)
+            works += list(dist.batch_isend_irecv([dist.P2POp(dist.isend, rec.contiguous(), dst)]))
+        return PendingCompactGather(works, [head], [rec], False)   # keeps the staged header alive until the sends are done
+    heads, ops = {}, []
+    for r in range(world):
+        if r == dst:
+            continue
+        heads[r] = torch.empty(COMPACT_HEADER_BYTES + 4 * int(frames_per_rank[r]), dtype=torch.uint8, device=dev)
+        ops.append(dist.P2POp(dist.irecv, heads[r], r))
+    for w in (dist.batch_isend_irecv(ops) if ops else []):
+        w.wait()
+    if heads:
+        # one small device -> host copy of the counts (synchronises the CALLING stream only)
+        cnt = torch.stack([heads[r][:COMPACT_HEADER_BYTES].view(torch.int64)[0] for r in sorted(heads)]).cpu().tolist()
+        counts = dict(zip(sorted(heads), (int(c) for c in cnt)))
+    else:
+        counts = {}
+    ops, n_parts, r_parts = [], [], []
+    for r in range(world):
+        if r == dst:
+            n_parts.append(n_out)
+            r_parts.append(rec)
+            continue
+        n_parts.append(heads[r][COMPACT_HEADER_BYTES:].view(torch.int32))
+        rb = torch.empty((counts[r], stride), dtype=torch.uint8, device=dev)
+        r_parts.append(rb)
+        if counts[r]:
+            ops.append(dist.P2POp(dist.irecv, rb, r))
+    works = list(dist.batch_isend_irecv(ops)) if ops else []
+    return PendingCompactGather(works, n_parts, r_parts, True)

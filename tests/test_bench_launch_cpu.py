@@ -1,0 +1,34 @@
+"""bench.py --gpus N must start its own ranks (the driver's command line is the only contract the multi-GPU path has:
+the reference has no multi-anything).  No GPU here: MOCAP_BENCH_DRY=1 keeps the launcher, the rank
+bookkeeping and the compact count-first exchange (gloo, two transfers in flight) and swaps the kernels for made-up
+track records."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(extra_env, *argv):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(extra_env)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], env=env, capture_output=True, text=True,
+                          timeout=240)
+
+
+def test_bench_gpus2_self_launches_and_prints_one_rank0_line():
+    p = _run({"MOCAP_BENCH_DRY": "1"}, "--gpus", "2", "--steps", "3", "--warmup", "1", "--frames", "24")
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout                      # rank 0 only
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["dry_run"] is True and line["value"] is None
+    ex = line["config"]["exchange"]
+    assert ex["payload_checksums_match"] is True and ex["records_sent_all_ranks"] > 0
+    assert line["config"]["frames_per_rank"] == [24, 25]  # uneven shards went through the count-first exchange
+
+
+def test_bench_world_size_mismatch_is_an_error_not_a_silent_single_rank_run():
+    p = _run({"MOCAP_BENCH_DRY": "1", "WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"}, "--gpus", "2")
+    assert p.returncode != 0 and "WORLD_SIZE" in (p.stderr + p.stdout)

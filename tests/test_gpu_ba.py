@@ -377,3 +377,111 @@ def test_helpers_bundle_adjustment_api(core):
         assert all(np.asarray(p["R"]).shape == (3, 3) and np.asarray(p["t"]).size == 3 for p in out)
     helpers.set_bundle_adjustment_mode("resident")
     assert Sock.n >= 2            # progress events: tests/test_gpu_boundary.py counts them
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The launch-ahead hand-over (a kernel resident on the GPU polling a host mailbox for its base point) under a host
+# that is late: device watchdog -> abandoned launch -> the host notices and repeats the linearisation.
+def _ba_case(n_pts=400):
+    from mocap_core import helpers, synth
+    rig = synth.ring_rig(8)
+    rng = np.random.default_rng(77)
+    obs, _ = synth.make_ba_observations(rig, n_pts, seed=77)
+    init = synth.perturb_rig(rig, rng)
+    helpers.set_camera_params([{"intrinsic_matrix": k.tolist()} for k in rig["K"]])
+    x0 = helpers._ba_x0([{"R": init["R"][i], "t": init["t"][i]} for i in range(8)])
+    return rig, init, obs, x0
+
+
+_ABANDON_CHILD = r"""
+import json, sys, time
+import numpy as np
+sys.path[:0] = [{root!r}, {pkg!r}]
+sys.path.insert(0, {tests!r})
+import torch
+from mocap_core import capi
+from test_gpu_ba import _ba_case
+rig, init, obs, x0 = _ba_case()
+core = capi.MocapCore(0)
+core.set_cameras(rig["K"], init["R"], init["t"])
+t0 = time.perf_counter()
+x, info = core.ba_solve(x0, obs, ftol=0.0, xtol=0.0, gtol=0.0, max_iter=30)
+print(json.dumps({{"x": x.tolist(), "info": info, "seconds": time.perf_counter() - t0}}))
+"""
+
+
+def _run_child(env_extra):
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = _ABANDON_CHILD.format(root=root, pkg=os.path.join(root, "low-cost-mocap_amd"), tests=os.path.join(root, "tests"))
+    env = dict(os.environ)
+    env.update(env_extra)
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=180)
+    assert p.returncode == 0, p.stderr[-3000:]
+    return json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+
+
+def test_abandoned_launch_ahead_is_detected_and_repeated():
+    """MOCAP_BA_DEBUG_HOST_STALL holds the host up for 2.6 s before its 6th hand-over: the resident kernel's 2 s device
+    watchdog fires, it writes the abandon mark, the host repeats that linearisation with the point passed by value and
+    carries on -- same iterates as the undisturbed solve, bit for bit (the arithmetic does not depend on how the base
+    point reached the kernel), one relaunch counted, and nowhere near the 20 s give-up."""
+    plain = _run_child({})
+    late = _run_child({"MOCAP_BA_DEBUG_HOST_STALL": "5:2600"})
+    assert plain["info"]["relaunches"] == 0
+    assert late["info"]["relaunches"] >= 1
+    assert late["seconds"] < 12.0
+    assert late["info"]["nfev"] == plain["info"]["nfev"] and late["info"]["iterations"] == plain["info"]["iterations"]
+    assert np.array_equal(np.array(late["x"]), np.array(plain["x"]))
+
+
+def test_slow_progress_callback_does_not_strand_a_resident_kernel(core):
+    """The reference emits a socket event per evaluation (helpers.py:274); the callback is foreign code that may block
+    (GIL, an eventlet yield).  It runs with nothing parked on the GPU: a 2.3 s callback -- longer than the device
+    watchdog -- changes neither the result nor the relaunch count."""
+    import time
+    rig, init, obs, x0 = _ba_case()
+    core.set_cameras(rig["K"], init["R"], init["t"])
+    x_ref, info_ref = core.ba_solve(x0, obs, ftol=0.0, xtol=0.0, gtol=0.0, max_iter=12)
+    calls = []
+
+    def cb(x):
+        calls.append(x.copy())
+        if len(calls) == 2:
+            time.sleep(2.3)
+    core.set_ba_progress(cb)
+    try:
+        x, info = core.ba_solve(x0, obs, ftol=0.0, xtol=0.0, gtol=0.0, max_iter=12)
+    finally:
+        core.set_ba_progress(None)
+    assert len(calls) >= 2 and info["relaunches"] == 0
+    assert np.array_equal(x, x_ref) and info["nfev"] == info_ref["nfev"]
+
+
+def test_no_speculation_mode_with_launch_ahead_default():
+    """MOCAP_BA_NO_SPECULATION=1 (cost-only trial evaluations, the documented A/B mode) used to queue its kernels
+    behind a resident launch-ahead kernel that was waiting for a mailbox write: 2 s per evaluation, then a failure.
+    It now switches the launch-ahead off for the solve."""
+    a = _run_child({"MOCAP_BA_NO_SPECULATION": "1"})
+    b = _run_child({})
+    assert a["seconds"] < 8.0 and a["info"]["relaunches"] == 0
+    np.testing.assert_allclose(np.array(a["x"]), np.array(b["x"]), rtol=0, atol=1e-9)
+
+
+def test_ba_solve_keeps_its_8_double_info_abi(core):
+    """mocap_ba_solve writes exactly 8 doubles (the buffer size it was first exported with); the longer record is
+    mocap_ba_solve_ex's, bounded by the length the caller states."""
+    import ctypes
+    rig, init, obs, x0 = _ba_case(120)
+    core.set_cameras(rig["K"], init["R"], init["t"])
+    obs = np.ascontiguousarray(obs, dtype=np.float64)
+    for fn, extra, n_written in ((core.lib.mocap_ba_solve, (), 8), (core.lib.mocap_ba_solve_ex, (9,), 9)):
+        x = np.array(x0, dtype=np.float64)
+        info = np.full(12, -7.0)
+        rc = fn(core._h, x.ctypes.data_as(ctypes.c_void_p), obs.shape[0], obs.ctypes.data_as(ctypes.c_void_p), 1e-2, 1e-8,
+                1e-8, 0, 1, 1, info.ctypes.data_as(ctypes.c_void_p), *extra)
+        assert rc in (0, -5)
+        assert np.all(info[n_written:] == -7.0) and info[0] >= 1 and info[6] > 0
