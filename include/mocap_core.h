@@ -61,6 +61,11 @@ int mocap_create(int device_id, mocap_ctx** out);
 void mocap_destroy(mocap_ctx* ctx);
 const char* mocap_last_error(const mocap_ctx* ctx);
 const char* mocap_version(void);
+/* mocap_last_frame_kernel: which kernel the last frame batch of this context went to ("frame_bb_kernel<CW=1>" = the
+ * exact branch-and-bound kernel of csrc/frame_bb.hip, "frame_kernel<256>" = the exhaustive walk, ...).  Diagnostic:
+ * results never depend on it.  The string is a literal owned by the library. */
+const char* mocap_last_frame_kernel(mocap_ctx* ctx);
+
 /* enqueue on an existing hipStream_t (e.g. the host framework's current stream);
  * NULL restores the context's own stream. */
 int mocap_set_stream(mocap_ctx* ctx, void* hip_stream);

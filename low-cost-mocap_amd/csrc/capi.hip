@@ -34,6 +34,7 @@ int mocap_ctx::fail(int code, const char* fmt, ...) {
 }
 
 int mocap_ctx::hip_fail(hipError_t e, const char* what) {
+  frame_q_clean = false;  // a launch that failed or aborted may have left the self-cleaning queue counters dirty
   return fail(MOCAP_E_HIP, "%s: %s", what, hipGetErrorString(e));
 }
 
@@ -143,8 +144,22 @@ extern "C" const char* mocap_version(void) { return "mocap_core 0.1 (gfx950)"; }
 extern "C" int mocap_set_stream(mocap_ctx* ctx, void* hip_stream) {
   if (!ctx) return MOCAP_E_ARG;
   std::lock_guard<std::mutex> lk(ctx->mu);
-  ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+  hipStream_t ns = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+  // the frame path's work queues clean themselves at the END of a launch: a launch still running on the previous
+  // stream has not done so yet, and nothing orders the next launch (on the new stream) behind it
+  if (ns != ctx->stream) {
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);  // per-context workspaces (queues, scratch) are shared by whatever stream is current
+    ctx->frame_q_clean = false;
+  }
+  ctx->stream = ns;
   return MOCAP_OK;
+}
+
+extern "C" const char* mocap_last_frame_kernel(mocap_ctx* ctx) {
+  if (!ctx) return "none";
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  return ctx->last_frame_kernel;  // string literals: valid for the life of the library
 }
 
 extern "C" int mocap_synchronize(mocap_ctx* ctx) {
@@ -509,18 +524,28 @@ static int match_dev_locked(mocap_ctx* ctx, int64_t n_frames, int M_max, const f
   a.prune = ctx->prune;
   a.p3max2 = ctx->prune && ctx->eigcut ? ctx->p3max2 : 0.0;
   if (!wide && ctx->frame_threads == 0 && T == 64) a.p3max2 = 0.0;  // tiny frames (a handful of candidates): the cut-offs cost more than they save
-  a.eval_bb = ctx->eval_bb && a.p3max2 > 0.0 && ctx->p3max2c > 0.0 && G_cap <= ((int64_t)1 << 24) && frame_bb_fits(ctx->C, M_max, K_max, T);
+  // The realistic rigs go to their own kernel (csrc/frame_bb.hip: exact branch and bound): identical plain intrinsics
+  // (the eigenvalue bounds need K = [[fx,0,cx],[0,fy,cy],[0,0,1]]), <= 16 cameras, <= 64 blobs per camera, <= 255 roots,
+  // frames big enough for a 256-lane workgroup.  Everything else -- and MOCAP_EVAL_BB=0 -- takes the exhaustive walk.
+  const bool use_bb = ctx->eval_bb && !wide && ctx->cv.uniformK && a.p3max2 > 0.0 && ctx->p3max2c > 0.0 &&
+                      (ctx->frame_threads == 0 || ctx->frame_threads == 256) && ctx->C * M_max > 32 && ctx->frame_launches != 3 &&
+                      frame_bb_fits(ctx->C, M_max, K_max);
+  a.eval_bb = use_bb ? 1 : 0;
   a.bb_pl = ctx->bb_pl;
   for (int i = 0; i < 3; i++) a.bb_c0[i] = ctx->eig_c0[i];
   a.p3max2c = ctx->p3max2c;
-  a.bb_flush = ctx->bb_flush > 0 ? ctx->bb_flush : T;
+  a.bb_flush = ctx->bb_flush > 0 ? ctx->bb_flush : 256;
   a.bb_min_g = ctx->bb_min_g;
-  while (a.bb_pl > 1 && (size_t)a.bb_pl * M_max * 2 * T >= ((size_t)1 << 22)) a.bb_pl /= 2;  // expanded-list counter: 22 bits
+  while (a.bb_pl > 1 && (size_t)a.bb_pl * M_max * 2 * 256 >= ((size_t)1 << 22)) a.bb_pl /= 2;  // expanded-list counter: 22 bits
+  if (use_bb) {
+    T = 256;
+    lds = frame_bb_lds_bytes(ctx->C, M_max, K_max);
+  }
   a.ws = nullptr;
   a.ws_stride = 0;
   // persistent grid: enough workgroups to fill every CU at the LDS-limited occupancy
   int per_cu = (int)((160 * 1024) / lds);
-  const int wave_cap = 16 / (T / 64) > 0 ? 16 / (T / 64) : 1;  // 128 VGPRs -> 16 waves per CU
+  const int wave_cap = use_bb ? frame_bb_wg_per_cu_cap() : (16 / (T / 64) > 0 ? 16 / (T / 64) : 1);  // 128 VGPRs -> 16 waves per CU
   if (per_cu > wave_cap) per_cu = wave_cap;
   if (per_cu < 1) per_cu = 1;
   const int64_t full_grid = (int64_t)ctx->num_cus * per_cu;
@@ -578,13 +603,21 @@ static int match_dev_locked(mocap_ctx* ctx, int64_t n_frames, int M_max, const f
   q.part_e = (double*)w;        w += b_pe;
   q.part_g = (uint32_t*)w;      w += b_pg;
   q.part_x = (double*)w;
-  if (!one_launch || fresh) {
+  if ((!one_launch && !use_bb) || fresh) {
     HIP_TRY(ctx, hipMemsetAsync(q.counters, 0, b_cnt, ctx->stream));
     if (q.heavy_threshold) HIP_TRY(ctx, hipMemsetAsync(q.slice_heavy, 0xFF, b_slice, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(q.slice_gen, 0, b_gen, ctx->stream));
   }
   ctx->frame_q_cap = q.W_cap;
   ctx->frame_q_clean = false;  // until the launch below is known to be queued
+  if (use_bb) {
+    // frames only: a frame's cost follows its surviving blocks, not its candidate count -- no heavy list, no slices
+    ctx->last_frame_kernel = ctx->C <= 8 ? "frame_bb_kernel<CW=1>" : "frame_bb_kernel<CW=2>";
+    HIP_TRY(ctx, launch_frame_bb(a, (int)grid, ctx->stream));
+    ctx->frame_q_clean = true;
+    return MOCAP_OK;
+  }
+  ctx->last_frame_kernel = wide ? "frame_kernel<1024, wide>" : (T == 64 ? "frame_kernel<64>" : (T == 128 ? "frame_kernel<128>" : "frame_kernel<256>"));
   if (one_launch) {
     // one launch: frames, then slices of the heavy frames, merged by the workgroup that finishes a frame's last slice.
     // Few frames (live calls): still enough workgroups for a heavy frame's slices to run side by side.

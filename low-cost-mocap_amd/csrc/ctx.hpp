@@ -25,10 +25,11 @@ struct mocap_ctx {
   int force_wide = 0;       // route every frame batch through the wide (HBM workspace) variant
   int32_t frame_gen = 0;    // generation of the last frame-path launch (tags the slices it publishes)
   int frame_q_cap = 0;      // W_cap the work-queue buffer was laid out for
+  const char* last_frame_kernel = "none";  // which kernel the last frame batch went to (mocap_last_frame_kernel)
   bool frame_q_clean = false;  // the queue counters were left at zero by the one-launch schedule
   int frame_launches = 1;   // 1: one persistent launch per batch (MODE_ALL); 3: main / slice / merge launches
   int prune = 1;            // stop a candidate group's reprojection once it cannot beat its root's best (exact)
-  int eval_bb = 1;          // branch-and-bound evaluation of the candidates (frame_kernel.hip evaluate_bb)
+  int eval_bb = 1;          // branch-and-bound selection (csrc/frame_bb.hip) wherever it applies; 0: always the exhaustive walk
   int bb_pl = 16;           // ... candidates per block (at least)
   int bb_min_g = 512;       // ... frames with fewer candidates are walked exhaustively
   int bb_flush = 0;         // ... queued candidates that trigger their evaluation (0 = one per lane)

@@ -1,0 +1,1012 @@
+// frame_bb.hip -- the frame path for the realistic rigs (identical plain intrinsics, <= 16 cameras, <= 64 blobs per
+// camera, <= 255 roots): epipolar correspondence search + EXACT branch-and-bound selection, one 256-lane workgroup per
+// frame, persistent, everything between the blob arrays in and the kept points out in LDS.  Replaces
+//   find_point_correspondance_and_object_points   (reference computer_code/api/helpers.py:339-421)
+// like frame_kernel.hip does (which keeps the general case: per-camera intrinsics, wide frames, tiny frames, and
+// the exhaustive walk every result of this file is tested against, MOCAP_EVAL_BB=0).
+//
+// What is different from frame_kernel.hip, and why (round 3):
+//  * its own kernel and LDS layout.  The round-2 search lived inside the all-in-one kernel (match + odometer walk +
+//    search + slice merge in one function: 128 VGPRs with 18 spilled, 217 SGPR spills) and borrowed its arrays from
+//    the odometer walk, which capped it at K_max <= 48, C <= 8.  Here: C <= 16 (blob indices of a group in one or two
+//    64-bit words), any K_max <= 255 that fits LDS (the reference seam's default K_max = min(C M, 64) included).
+//  * phase B without the per-camera barrier chain.  The reference matches camera after camera (helpers.py:359-406)
+//    because a blob no root claims becomes a new root for the cameras after it.  Only THAT is sequential: the roots of
+//    camera 0 exist from the start, their lines, gates, orders and claims in all C - 1 other cameras are independent
+//    of each other -> one barrier-free parallel pass over (root, camera) pairs on all four waves.  What remains is a
+//    short chain over the cameras that involves only the roots created on the way (a few per frame): one wave, no
+//    workgroup barriers, wave-level ballots.  (Round 2: 7 x [lines | barrier | gate-rank-claim | barrier | new roots]
+//    = 19 us per frame = 29 % of the kernel, most of it three waves waiting for one.)
+//  * one evaluation path: a frame below the search threshold queues all its blocks unconditionally (no seed pass, no
+//    bound tests) and takes the same evaluation rounds -- no second copy of the geometry core in the kernel.
+//
+// Phases per frame (256 lanes = 4 waves):
+//   A   blobs / counts -> LDS; largest coordinate (float32 allowance of the bounds)
+//   B0  roots of camera 0; every (camera-0 root, camera) pair: epipolar line (helpers.py:362-364), point-line
+//       distances (helpers.py:373), 5 px gate + stable (distance, index) order (helpers.py:375-385), claim of the
+//       closest hit BY VALUE (helpers.py:391) -- lanes = (pair, blob), groups of 2^ceil(log2 M) lanes, ballots only
+//   B1  wave 0: for camera i = 1 .. C-1: the roots created at cameras < i against camera i (same code), then the
+//       unclaimed blobs of camera i become roots (helpers.py:402-406); meanwhile waves 1-3 tabulate the DLT
+//       contribution of every blob (mocap_device.hpp dlt_contribution)
+//   C   per-root candidate counts (helpers.py:394-400), offsets, output slots
+//   D   branch and bound over blocks of the Cartesian product: seeds, block tests, evaluation of the
+//       survivors' candidates spread over all lanes; per (wave, root) slot = lexicographic minimum of (error bits,
+//       candidate index) = np.argmin's first minimum (helpers.py:418) whatever the evaluation order
+//   E   one lane per kept root: merge the four waves' slots, decode the winning group, write xyz / err / corr
+#include "mocap_device.hpp"
+#include "kernels.hpp"
+#include "frame_common.hpp"
+
+// timing experiments only (results invalid): bit 0 = no search / no output, bit 1 = no chain over the cameras,
+// bit 2 = no camera-0 pairs, bit 3 = no speculative lines (scripts/build_bb_variants.sh)
+#ifndef MOCAP_BB_DEBUG_SKIP
+#define MOCAP_BB_DEBUG_SKIP 0
+#endif
+
+namespace mocap {
+
+constexpr int kBBThreads = 256;
+constexpr int kBBWaves = kBBThreads / 64;
+constexpr int kBBRecs = kBBThreads + 64;  // surviving blocks queued between two evaluation rounds (flush above 64)
+
+// LDS carving, identical on host (size) and device (pointers).  Arrays that are live only while matching (none at
+// M <= 64: gate / order / claim run in registers and ballots) could share the search's region; the search's own
+// arrays (block records, result slots, per-root block bookkeeping) are laid out behind the persistent frame state.
+struct BBLayout {
+  size_t bxy, bxy_nx, cnt_nx, bt, rbound, seedkey, slot_key, slot_x, claimw, recs, rpk, scr, scr_bytes, goff, gcnt, outslot, boff, bnb, seedgh, slot_g, cnt,
+      misc, bpl, nh, hits, act, root_blob, root_cam, nact, bnl, bv, total;
+  __host__ __device__ static size_t al(size_t x, size_t a) { return (x + a - 1) / a * a; }
+  __host__ __device__ BBLayout(int C, int M, int R, int CW) {
+    size_t o = 0;
+    auto take = [&](size_t bytes, size_t a) {
+      o = al(o, a);
+      const size_t at = o;
+      o += bytes;
+      return at;
+    };
+    bt = take(sizeof(double) * 10 * (size_t)C * M, 16);      // DLT contribution per (camera, blob): five b128 reads
+    bxy = take(sizeof(float2) * (size_t)C * M, 8);
+    bxy_nx = take(sizeof(float2) * (size_t)C * M, 8);  // the NEXT frame's blobs, parked here while this one is searched
+    cnt_nx = take(4 * (size_t)C, 4);
+    rbound = take(8 * (size_t)R, 8);
+    claimw = take(8 * (size_t)C, 8);
+    // the search's block records and result slots: dead while matching -> phase B keeps the speculative epipolar
+    // lines here (match(): lines of every blob that MIGHT become a root, computed off the critical path)
+    scr = seedkey = take(8 * (size_t)R, 8);
+    slot_key = take(8 * (size_t)kBBWaves * R, 8);
+    slot_x = take(24 * (size_t)kBBWaves * R, 8);
+    recs = take(8 * (size_t)kBBRecs, 8);
+    rpk = take(8 * (size_t)kBBRecs * CW, 8);
+    scr_bytes = o - scr;
+    goff = take(4 * (size_t)(R + 1), 4);
+    gcnt = take(4 * (size_t)R, 4);
+    outslot = take(4 * (size_t)R, 4);
+    boff = take(4 * (size_t)(R + 1), 4);
+    bnb = take(4 * (size_t)R, 4);
+    seedgh = take(4 * (size_t)R, 4);
+    slot_g = take(4 * (size_t)kBBWaves * R, 4);
+    cnt = take(4 * (size_t)C, 4);
+    misc = take(4 * 16, 4);
+    bpl = take(2 * (size_t)R, 2);
+    nh = take((size_t)R * C, 1);
+    hits = take((size_t)R * C * M, 1);
+    act = take((size_t)R * C, 1);
+    root_blob = take((size_t)R, 1);
+    root_cam = take((size_t)R, 1);
+    nact = take((size_t)R, 1);
+    bnl = take((size_t)R, 1);
+    bv = take((size_t)R, 1);
+    total = al(o, 16);
+  }
+};
+
+size_t frame_bb_lds_bytes(int C, int M, int R) { return BBLayout(C, M, R, C <= 8 ? 1 : 2).total; }
+bool frame_bb_fits(int C, int M, int R) {
+  // blob indices and root numbers are bytes (0xFF = none); a (root, blob) group is at most one wave; the expanded
+  // candidate list of one evaluation round is counted in 22 bits (FrameArgs::bb_pl is lowered by the host if needed)
+  return C >= 2 && C <= 16 && M >= 1 && M <= 64 && R >= 1 && R <= 255 && frame_bb_lds_bytes(C, M, R) <= (size_t)64 * 1024;
+}
+
+// blob indices of one (partial) group: one byte per camera, 0xFF = the camera is open or not in the group
+template <int CW>
+struct Packed {
+  unsigned long long w[CW];
+  __device__ __forceinline__ void clear() {
+#pragma unroll
+    for (int k = 0; k < CW; k++) w[k] = ~0ull;
+  }
+  __device__ __forceinline__ void set(int c, uint32_t idx) {  // the camera's byte must still be 0xFF
+    if (CW == 1)
+      w[0] ^= (unsigned long long)(idx ^ 0xFFu) << (8 * c);
+    else
+      w[c >> 3] ^= (unsigned long long)(idx ^ 0xFFu) << (8 * (c & 7));
+  }
+  __device__ __forceinline__ uint32_t get(int c) const {
+    return CW == 1 ? (uint32_t)(w[0] >> (8 * c)) & 0xFFu : (uint32_t)(w[c >> 3] >> (8 * (c & 7))) & 0xFFu;
+  }
+};
+
+template <bool F32R, int CW>
+struct BBState {
+  static constexpr int T = kBBThreads, W = kBBWaves;
+  const FrameArgs& p;
+  const CamView& cv;
+  const int C, M, R, tid, lane, wave;
+  double* bt;
+  float2 *bxy, *bxy_nx;
+  int32_t* cnt_nx;
+  unsigned long long *rbound, *seedkey, *slot_key, *claimw, *rpk;
+  double* slot_x;
+  struct BRec { uint32_t gh, rs; };  // surviving block gh of root (rs & 0xFF); its candidates start at rs >> 8 of the expanded list
+  BRec* recs;
+  uint32_t *goff, *gcnt, *boff, *bnb, *seedgh, *slot_g;
+  int32_t *outslot, *cnt, *misc;
+  uint16_t* bpl;
+  uint8_t *nh, *hits, *act, *root_blob, *root_cam, *nact, *bnl, *bv;
+  unsigned char* scr;  // phase B scratch = the search's records and slots (BBLayout::scr)
+  size_t scr_bytes;
+  static constexpr unsigned long long kInfBits = 0x7ff0000000000000ull;
+
+  __device__ BBState(const FrameArgs& p_, unsigned char* smem)
+      : p(p_), cv(p_.cv), C(p_.cv.C), M(p_.M), R(p_.K_max), tid(threadIdx.x), lane(threadIdx.x & 63), wave(threadIdx.x >> 6) {
+    const BBLayout L(C, M, R, CW);
+    bt = (double*)(smem + L.bt);
+    bxy = (float2*)(smem + L.bxy);
+    bxy_nx = (float2*)(smem + L.bxy_nx);
+    cnt_nx = (int32_t*)(smem + L.cnt_nx);
+    rbound = (unsigned long long*)(smem + L.rbound);
+    seedkey = (unsigned long long*)(smem + L.seedkey);
+    slot_key = (unsigned long long*)(smem + L.slot_key);
+    slot_x = (double*)(smem + L.slot_x);
+    claimw = (unsigned long long*)(smem + L.claimw);
+    recs = (BRec*)(smem + L.recs);
+    rpk = (unsigned long long*)(smem + L.rpk);
+    goff = (uint32_t*)(smem + L.goff);
+    gcnt = (uint32_t*)(smem + L.gcnt);
+    outslot = (int32_t*)(smem + L.outslot);
+    boff = (uint32_t*)(smem + L.boff);
+    bnb = (uint32_t*)(smem + L.bnb);
+    seedgh = (uint32_t*)(smem + L.seedgh);
+    slot_g = (uint32_t*)(smem + L.slot_g);
+    cnt = (int32_t*)(smem + L.cnt);
+    misc = (int32_t*)(smem + L.misc);
+    bpl = (uint16_t*)(smem + L.bpl);
+    nh = (uint8_t*)(smem + L.nh);
+    hits = (uint8_t*)(smem + L.hits);
+    act = (uint8_t*)(smem + L.act);
+    root_blob = (uint8_t*)(smem + L.root_blob);
+    root_cam = (uint8_t*)(smem + L.root_cam);
+    nact = (uint8_t*)(smem + L.nact);
+    bnl = (uint8_t*)(smem + L.bnl);
+    bv = (uint8_t*)(smem + L.bv);
+    scr = smem + L.scr;
+    scr_bytes = L.scr_bytes;
+  }
+
+  // ---------------------------------------------------------------- phase B building blocks
+  // Epipolar line of root r in camera i: cv.computeCorrespondEpilines on a float32 point -- double math, scale by
+  // 1/sqrt(a^2+b^2), float32 result (helpers.py:363-364); den = sqrt(a^2+b^2) of the ROUNDED line, by which
+  // helpers.py:373 divides again, and its reciprocal for the quotients.  The same expressions, in the same order, as
+  // frame_kernel.hip phase B1 (bit-identical by construction; tested against it).
+  struct Line { double a, b, c, den, rden; };
+  __device__ __forceinline__ Line epiline(int r, int i) const { return epiline_of(root_cam[r], root_blob[r], i); }
+  __device__ __forceinline__ Line epiline_of(int rc, int rb, int i) const {
+    const double* Fm = cv.F + 9 * ((size_t)rc * C + i);  // (per-lane camera pair: vector loads, L1/L2-resident table)
+    const float2 rp = bxy[(size_t)rc * M + rb];
+    const double x = (double)rp.x, y = (double)rp.y;
+    double a = Fm[0] * x + Fm[1] * y + Fm[2];
+    double b = Fm[3] * x + Fm[4] * y + Fm[5];
+    double c = Fm[6] * x + Fm[7] * y + Fm[8];
+    double nu = a * a + b * b;
+    nu = nu != 0.0 ? 1.0 / sqrt(nu) : 1.0;
+    a *= nu;
+    b *= nu;
+    c *= nu;
+    if (F32R) {
+      a = (double)(float)a;
+      b = (double)(float)b;
+      c = (double)(float)c;
+    }
+    Line L;
+    L.a = a;
+    L.b = b;
+    L.c = c;
+    L.den = sqrt(a * a + b * b);
+    L.rden = recip_refined(L.den);
+    return L;
+  }
+
+  // Gate / order / claim of up to 64 (root, camera) pairs whose lines sit in the lanes of this wave (lane l holds the
+  // line of pair l; pair_r / pair_i = its root and camera, n_pairs valid).  Lanes regroup as (pair slot, blob):
+  // GS = 2^gs_shift >= M lanes per pair, 64 / GS pairs per sub-pass.
+  // CHAIN: every pair is in camera `cam` (wave-uniform, Mi blobs); the blobs the pairs claim come back as a mask
+  // (wave-uniform) instead of going to claimw[] -- the chain over the cameras keeps its state in registers.
+  template <bool CHAIN>
+  __device__ __forceinline__ unsigned long long match_pairs(const Line& mine, int pair_r, int pair_i, int n_pairs, int gs_shift,
+                                                            int cam = 0, int Mi_chain = 0) {
+    const int GS = 1 << gs_shift, PPS = 64 >> gs_shift;
+    const int k = lane & (GS - 1), q = lane >> gs_shift;
+    const int gl0 = lane & ~(GS - 1);
+    const unsigned long long gall = gs_shift == 6 ? ~0ull : ((1ull << GS) - 1ull);
+    unsigned long long claims = 0ull;
+    for (int s0 = 0; s0 < n_pairs; s0 += PPS) {  // wave-uniform trip count
+      const int src = s0 + q;                    // the lane that holds this group's line
+      const bool has = src < n_pairs;
+      const int sl = has ? src : 0;
+      const double la = __shfl(mine.a, sl), lb = __shfl(mine.b, sl), lc = __shfl(mine.c, sl);
+      const double lden = __shfl(mine.den, sl), lrden = __shfl(mine.rden, sl);
+      const int r = __shfl(pair_r, sl);
+      const int i = CHAIN ? cam : __shfl(pair_i, sl);
+      const int Mi = has ? (CHAIN ? Mi_chain : cnt[i]) : 0;
+      const bool valid = k < Mi;
+      float2 pt = make_float2(0.f, 0.f);
+      double d = 0.0;
+      bool hit = false;
+      if (valid) {
+        pt = bxy[(size_t)i * M + k];
+        const double num = fabs(la * (double)pt.x + lb * (double)pt.y + lc);  // helpers.py:373
+        d = div_by(num, lden, lrden);
+        hit = d < p.gate_px;  // strict <, helpers.py:375,383
+      }
+      const unsigned long long wm = __ballot(hit);
+      const unsigned long long gm = (wm >> gl0) & gall;
+      // rank among the group's hits by (distance, blob index): a stable order where NumPy's default argsort is not
+      // (helpers.py:384; documented deviation).  The loop runs over the hits of the whole wave (a handful), each
+      // broadcast from its lane; a lane counts the ones of its own group that precede it.
+      int rank = 0;
+      const unsigned int dlo = (unsigned int)__double_as_longlong(d), dhi = (unsigned int)(__double_as_longlong(d) >> 32);
+      for (unsigned long long mm = wm; mm;) {
+        const int j = __ffsll((long long)mm) - 1;  // wave-uniform
+        mm &= mm - 1;
+        const double dj = __longlong_as_double(((long long)__builtin_amdgcn_readlane((int)dhi, j) << 32) |
+                                               (unsigned int)__builtin_amdgcn_readlane((int)dlo, j));
+        const bool mine_grp = (j & ~(GS - 1)) == gl0 && j != lane;
+        rank += (hit && mine_grp && (dj < d || (dj == d && j < lane))) ? 1 : 0;
+      }
+      if (hit) hits[((size_t)r * C + i) * M + rank] = (uint8_t)k;
+      const unsigned long long g0 = (__ballot(hit && rank == 0) >> gl0) & gall;
+      // removal by value (helpers.py:391): every blob with the closest hit's coordinates is claimed
+      bool same = false;
+      if (valid && g0) {
+        const float2 p0 = bxy[(size_t)i * M + (__ffsll((long long)g0) - 1)];
+        same = pt.x == p0.x && pt.y == p0.y;
+      }
+      const unsigned long long cw = __ballot(same);
+      if (CHAIN) {
+        for (int sh = 0; sh < 64; sh += GS) claims |= (cw >> sh) & gall;  // lane -> blob: fold the groups onto each other
+      }
+      if (has && k == 0) {
+        nh[(size_t)r * C + i] = (uint8_t)__popcll(gm);
+        if (!CHAIN) {
+          const unsigned long long cm = (cw >> gl0) & gall;
+          if (cm) atomicOr(&claimw[i], cm);
+        }
+      }
+    }
+    return claims;
+  }
+
+  // The next frame's blobs and counts travel from HBM into registers while the current frame is searched (the loads
+  // are issued before the search, consumed after it): neither the queue atomic nor the first touch of a frame sits on
+  // the per-frame critical path.  A lane holds blobs tid and tid + 256 (C M <= 512; more are read in stage()).
+  struct Pre {
+    float2 b0, b1;
+    int n;
+  };
+  __device__ __forceinline__ void prefetch(int64_t frame, Pre& q) const {
+    const float2* src = (const float2*)(p.blobs + (size_t)frame * C * M * 2);
+    const int CM = C * M;
+    q.b0 = tid < CM ? src[tid] : make_float2(0.f, 0.f);
+    q.b1 = tid + T < CM ? src[tid + T] : make_float2(0.f, 0.f);
+    q.n = tid < C ? p.counts[(size_t)frame * C + tid] : 0;
+  }
+  // registers -> the spare blob buffer.  Called where the search's register pressure is low (after its seed pass): the
+  // prefetched values must not stay live across the candidate evaluation.
+  __device__ __forceinline__ void park(const Pre& q) {
+    const int CM = C * M;
+    if (tid < CM) bxy_nx[tid] = q.b0;
+    if (tid + T < CM) bxy_nx[tid + T] = q.b1;
+    if (tid < C) cnt_nx[tid] = q.n < 0 ? 0 : (q.n > M ? M : q.n);
+  }
+  // the parked frame becomes the current one (buffer swap; blobs beyond 512 are read here)
+  __device__ __forceinline__ void stage(int64_t frame) {
+    float2* t = bxy;
+    bxy = bxy_nx;
+    bxy_nx = t;
+    const int CM = C * M;
+    if (CM > 2 * T) {
+      const float2* src = (const float2*)(p.blobs + (size_t)frame * C * M * 2);
+      for (int i = tid + 2 * T; i < CM; i += T) bxy[i] = src[i];
+    }
+    if (tid < C) {
+      cnt[tid] = cnt_nx[tid];
+      claimw[tid] = 0ull;
+    }
+    if (tid == 0) {
+      misc[MI_STATUS] = 0;
+      misc[MI_OMAX] = 0;
+    }
+  }
+
+  // ---------------------------------------------------------------- phases B-C (the frame is staged)
+  // next_item: lane 0's pull of the NEXT frame from the queue (issued by the caller before this call); it is dropped
+  // into misc[MI_NEXT] here, between two barriers that exist anyway, so that every lane can prefetch that frame.
+  __device__ void match(int next_item) {
+    __syncthreads();
+    int gs_shift = 0;
+    while ((1 << gs_shift) < M) gs_shift++;
+    const int n0 = cnt[0] < R ? cnt[0] : R;
+    {  // roots from camera 0 (helpers.py:349,357)
+      for (int r = tid; r < n0; r += T) {
+        root_cam[r] = 0;
+        root_blob[r] = (uint8_t)r;
+      }
+      if (tid == 0 && cnt[0] > R) misc[MI_STATUS] |= MOCAP_ST_ROOT_OVERFLOW_;
+    }
+    __syncthreads();
+    // B0: the (camera-0 root, camera) pairs, ONE LANE PER PAIR, the camera's blobs walked serially.  The kernel is
+    // instruction-issue bound (PMC), so what counts is instructions per pair, not latency: a lane per
+    // (pair, blob) spends ~250 wave instructions on every 4 pairs (line broadcast, ballots, rank loop), a lane per
+    // pair ~10 per pair.  Pass 1 collects the gated blobs of the pair as a bit mask (M <= 64); pass 2 extracts them in
+    // (distance, index) order by repeated minimum -- hit lists are a handful long, distances are simply recomputed
+    // (same expression, same bits).  Waves take 64 pairs each: full lanes, as few waves as possible.
+    {
+      const int NP = (MOCAP_BB_DEBUG_SKIP & 4) ? 0 : n0 * (C - 1);
+      int Mmax = 0;
+      for (int c = 1; c < C; c++) Mmax = cnt[c] > Mmax ? cnt[c] : Mmax;  // wave-uniform
+      for (int base = wave * 64; base < NP; base += W * 64) {
+        const int pi = base + lane;
+        const bool have = pi < NP;
+        int r = 0, i = 1, Mi = 0;
+        Line L = {0, 0, 0, 1, 1};
+        if (have) {
+          r = pi / (C - 1);
+          i = 1 + (pi - r * (C - 1));
+          Mi = cnt[i];
+          L = epiline(r, i);
+        }
+        const float2* pts = bxy + (size_t)i * M;
+        auto dist = [&](int k) {
+          const float2 pt = pts[k];
+          return div_by(fabs(L.a * (double)pt.x + L.b * (double)pt.y + L.c), L.den, L.rden);  // helpers.py:373
+        };
+        unsigned long long hm = 0ull;
+        for (int k = 0; k < Mmax; k++)
+          if (k < Mi && dist(k) < p.gate_px) hm |= 1ull << k;  // strict <, helpers.py:375,383
+        if (have) nh[(size_t)r * C + i] = (uint8_t)__popcll(hm);
+        // order by (distance, blob index): a stable order where NumPy's default argsort is not (helpers.py:384;
+        // documented deviation); the closest hit's coordinates claim every blob that has them (helpers.py:391)
+        unsigned long long rem = hm, claim = 0ull;
+        uint8_t* hl = hits + ((size_t)r * C + i) * M;
+        int pos = 0;
+        float2 p0 = make_float2(0.f, 0.f);
+        while (__ballot(rem != 0ull)) {
+          if (rem) {
+            double bd = __builtin_huge_val();
+            int bk = 0;
+            for (unsigned long long t = rem; t; t &= t - 1) {  // ascending index, strict <: ties keep the smaller index
+              const int k = __ffsll((long long)t) - 1;
+              const double d = dist(k);
+              if (d < bd) {
+                bd = d;
+                bk = k;
+              }
+            }
+            hl[pos] = (uint8_t)bk;
+            if (pos == 0) {
+              p0 = pts[bk];
+              for (unsigned long long t = hm; t; t &= t - 1) {
+                const int k = __ffsll((long long)t) - 1;
+                const float2 q = pts[k];
+                if (q.x == p0.x && q.y == p0.y) claim |= 1ull << k;
+              }
+            }
+            rem &= ~(1ull << bk);
+            pos++;
+          }
+        }
+        if (claim) atomicOr(&claimw[i], claim);
+      }
+    }
+    // Speculative lines.  Which blobs of cameras 1 .. C-2 become roots is only known inside the chain below, but their
+    // epipolar lines in the cameras after them depend on nothing: all of them are computed here, by all waves, off the
+    // chain's critical path (a line is ~90 dependent FP64 instructions; the chain would pay them once per camera).
+    // Table = the search's dead arrays: line (j, k) -> i at  sp_base(j) + k (C-1-j) + (i-j-1),  stored as the float32
+    // values they are (F32R: a, b, c are rounded to float32, helpers.py:364) + den in double; without F32R, or when
+    // the table does not fit, the chain computes its lines itself.
+    const int NL = M * ((C - 1) * (C - 2) / 2);
+    const bool spec = !(MOCAP_BB_DEBUG_SKIP & 8) && F32R && (size_t)NL * 20 + 8 <= scr_bytes;
+    double* sp_den = (double*)scr;
+    float* sp_abc = (float*)(sp_den + NL);
+    auto sp_base = [&](int j) { return M * ((j - 1) * (C - 1) - (j - 1) * j / 2); };  // lines of cameras 1 .. j-1
+    if (spec) {
+      for (int l = tid; l < NL; l += T) {
+        int j = 1;
+        while (j < C - 2 && l >= sp_base(j + 1)) j++;
+        const int rel = l - sp_base(j), span = C - 1 - j;
+        const int k = rel / span, i = j + 1 + (rel - k * span);
+        if (k < cnt[j]) {
+          const Line L = epiline_of(j, k, i);
+          sp_den[l] = L.den;
+          sp_abc[3 * l + 0] = (float)L.a;
+          sp_abc[3 * l + 1] = (float)L.b;
+          sp_abc[3 * l + 2] = (float)L.c;
+        }
+      }
+    }
+    __syncthreads();
+    if (wave == 0) {
+      // B1: the chain over the cameras -- only the roots created on the way take part (camera-0 roots are done).
+      // State in registers: lane l <-> camera l (blob count, blobs claimed so far), lane l <-> the l-th new root.
+      const int cntL = lane < C ? cnt[lane] : 0;
+      const unsigned long long clmL = lane < C ? claimw[lane] : 0ull;  // the camera-0 roots' claims (B0 is complete)
+      int nr_cam = 0, nr_blob = 0;
+      int n_roots = n0;
+      bool over = false;
+      for (int i = 1; i < ((MOCAP_BB_DEBUG_SKIP & 2) ? 1 : C); i++) {
+        const int Mi = __builtin_amdgcn_readlane(cntL, i);
+        unsigned long long claimed = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)(clmL >> 32), i) << 32) |
+                                     (unsigned int)__builtin_amdgcn_readlane((int)clmL, i);
+        const int n_new = n_roots - n0;
+        for (int base = 0; base < n_new; base += 64) {
+          const int l = base + lane;
+          const bool have = l < n_new;  // created at an earlier camera
+          int j = nr_cam, k = nr_blob;
+          if (base) {                   // (beyond the 64 kept in registers: from the root arrays this wave wrote)
+            wave_lds_sync();
+            j = have ? root_cam[n0 + l] : 0;
+            k = have ? root_blob[n0 + l] : 0;
+          }
+          Line L = {0, 0, 0, 1, 1};
+          if (have) {
+            if (spec) {
+              const int ll = sp_base(j) + k * (C - 1 - j) + (i - j - 1);
+              L.a = (double)sp_abc[3 * ll + 0];
+              L.b = (double)sp_abc[3 * ll + 1];
+              L.c = (double)sp_abc[3 * ll + 2];
+              L.den = sp_den[ll];
+              L.rden = recip_refined(L.den);
+            } else {
+              L = epiline_of(j, k, i);
+            }
+          }
+          claimed |= match_pairs<true>(L, n0 + l, i, (n_new - base < 64) ? n_new - base : 64, gs_shift, i, Mi);
+        }
+        // unclaimed blobs become new roots, in blob order (helpers.py:402-406)
+        const bool flag = lane < Mi && !((claimed >> lane) & 1ull);
+        const unsigned long long mask = __ballot(flag);
+        const int pos = __popcll(mask & ((1ull << lane) - 1ull));
+        if (flag) {
+          const int rr = n_roots + pos;
+          if (rr < R) {
+            root_cam[rr] = (uint8_t)i;
+            root_blob[rr] = (uint8_t)lane;
+          }
+        }
+        int slot = n_new;
+        for (unsigned long long mm = mask; mm; slot++) {  // wave-uniform: the new roots' registers
+          const int jb = __ffsll((long long)mm) - 1;
+          mm &= mm - 1;
+          if (lane == slot) {
+            nr_cam = i;
+            nr_blob = jb;
+          }
+        }
+        n_roots += __popcll(mask);
+        if (n_roots > R) {
+          over = true;
+          n_roots = R;
+        }
+      }
+      if (lane == 0) {
+        if (over) misc[MI_STATUS] |= MOCAP_ST_ROOT_OVERFLOW_;
+        misc[MI_NROOTS] = n_roots;
+      }
+    } else {
+      // meanwhile: DLT contribution of every blob, once per frame (a candidate group then ADDS ten doubles per view),
+      // and the largest coordinate (float32 allowance of the bounds)
+      float om = 0.0f;
+      for (int i = tid - 64; i < C * M; i += T - 64) {
+        const int c = i / M, k = i - c * M;
+        if (k < cnt[c]) {
+          const float2 v = bxy[i];
+          om = fmaxf(om, fmaxf(fabsf(v.x), fabsf(v.y)));
+          double Bc[10];
+          dlt_contribution(Bc, as_ctab(cv.Pq + 12 * c), (double)v.x, (double)v.y);
+#pragma unroll
+          for (int e = 0; e < 10; e++) bt[(size_t)i * 10 + e] = Bc[e];
+        }
+      }
+      if (om > 0.0f) atomicMax(&misc[MI_OMAX], __float_as_int(om));
+    }
+    __syncthreads();
+
+    // C: candidate counts per root
+    const int nroots = misc[MI_NROOTS];
+    for (int r = tid; r < nroots; r += T) {
+      const int rc = root_cam[r];
+      unsigned long long total = 1;
+      int views = 1, na = 0;
+      bool over = false;
+      for (int c = rc + 1; c < C; c++) {
+        const unsigned n = nh[(size_t)r * C + c];
+        if (n > 1) act[(size_t)r * C + na++] = (uint8_t)c;  // multi-hit cameras = the digits of the candidate index
+        if (n) {
+          views++;
+          total *= n;
+          if (total > (unsigned long long)p.G_cap) {
+            over = true;
+            total = 1;
+          }
+        }
+      }
+      if (over) atomicOr(&misc[MI_STATUS], MOCAP_ST_CAND_OVERFLOW_);
+      nact[r] = (uint8_t)na;
+      bv[r] = (uint8_t)views;
+      rbound[r] = kInfBits;
+      gcnt[r] = (views > 1 && !over) ? (uint32_t)total : 0u;  // helpers.py:413-414 drops 1-view roots
+    }
+    if (tid == 0) misc[MI_NEXT] = next_item;
+    __syncthreads();
+    if (wave == 0) {  // candidate offsets and output slots: scans over the roots, 64 at a time (sums stay below 2^32: 255 x 2^24)
+      uint32_t carry = 0;
+      int slots = 0;
+      for (int base = 0; base < nroots; base += 64) {
+        const int r = base + lane;
+        const uint32_t g = r < nroots ? gcnt[r] : 0u;
+        const uint32_t incl = wave_inclusive_scan(g, lane);
+        const unsigned long long nz = __ballot(g != 0u);
+        if (r < nroots) {
+          goff[r] = carry + incl - g;
+          outslot[r] = g ? slots + __popcll(nz & ((1ull << lane) - 1ull)) : -1;
+        }
+        carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        slots += __popcll(nz);
+      }
+      if (lane == 0) {
+        goff[nroots] = carry;
+        misc[MI_NOUT] = slots;
+        misc[MI_G] = misc[MI_STATUS] ? 0 : (int32_t)carry;
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---------------------------------------------------------------- phase D
+  // DLT matrix of candidate `rem` of root r with the first `skip` multi-hit cameras left open (skip = 0: the whole
+  // group, rem = candidate index; skip = bnl[r]: the block's partial group, rem = block index).  Returns the views.
+  template <bool WITH_B>
+  __device__ __forceinline__ int group_matrix(int r, uint32_t rem, int skip, double (&B)[10], Packed<CW>& pk) const {
+    const int rc = root_cam[r];
+    const uint8_t* nhr = nh + (size_t)r * C;
+    const uint8_t* hr = hits + (size_t)r * C * M;
+    pk.clear();
+    int v = 0, ka = 0;
+    if (WITH_B) {
+#pragma unroll
+      for (int e = 0; e < 10; e++) B[e] = 0.0;
+    }
+    for (int c = 0; c < C; c++) {
+      uint32_t k = 0xFFu;
+      if (c == rc) {
+        k = root_blob[r];
+      } else if (c > rc) {
+        const uint32_t n = nhr[c];
+        if (n == 1) {
+          k = hr[(size_t)c * M];
+        } else if (n > 1) {
+          if (ka >= skip) {
+            uint32_t qd, dgt;
+            divmod_small(rem, n, qd, dgt);
+            rem = qd;
+            k = hr[(size_t)c * M + dgt];
+          }
+          ka++;
+        }
+      }
+      if (k != 0xFFu) {
+        if (WITH_B) {
+          const double* t = bt + ((size_t)c * M + k) * 10;
+#pragma unroll
+          for (int e = 0; e < 10; e++) B[e] = B[e] + t[e];
+        }
+        v++;
+        pk.set(c, k);
+      }
+    }
+    return v;
+  }
+
+  __device__ void search(bool bound_tests, const Pre& pre, bool have_pre) {
+    const int nroots = misc[MI_NROOTS];
+    int32_t* ctr = &misc[MI_BBCTR];  // queued blocks | their candidates << 10
+    const double inf = __builtin_huge_val();
+    EigCut ec;
+    {
+      const double om = (double)__int_as_float(misc[MI_OMAX]);
+      ec.p3max2 = p.p3max2;
+      ec.o2slack = (1100.0 * 0x1p-46) * (om * om);
+    }
+    const double c0[3] = {p.bb_c0[0], p.bb_c0[1], p.bb_c0[2]};  // origin of the frame the block bounds are taken in
+    const uint32_t PL = (uint32_t)p.bb_pl;
+    for (int r = tid; r < nroots; r += T) {
+      const uint8_t* a = act + (size_t)r * C;
+      const int na = nact[r];
+      uint32_t pl = 1, nb = 1;
+      int nl = 0;
+      while (nl < na && pl < PL) pl *= nh[(size_t)r * C + a[nl++]];
+      for (int k = nl; k < na; k++) nb *= nh[(size_t)r * C + a[k]];
+      bpl[r] = (uint16_t)pl;
+      bnl[r] = (uint8_t)nl;
+      bnb[r] = gcnt[r] ? nb : 0u;
+      seedkey[r] = 0ull;
+      seedgh[r] = 0xFFFFFFFFu;
+    }
+    for (int s = tid; s < W * R; s += T) {
+      slot_key[s] = ~0ull;
+      slot_g[s] = 0xFFFFFFFFu;
+    }
+    if (tid == 0) *ctr = 0;
+    __syncthreads();
+    if (wave == 0) {
+      uint32_t carry = 0;
+      for (int base = 0; base < nroots; base += 64) {
+        const int r = base + lane;
+        const uint32_t g = r < nroots ? bnb[r] : 0u;
+        const uint32_t incl = wave_inclusive_scan(g, lane);
+        if (r < nroots) boff[r] = carry + incl - g;
+        carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+      }
+      if (lane == 0) boff[nroots] = carry;
+    }
+    __syncthreads();
+    const uint32_t nblocks = boff[nroots];
+    // root of block b0 + tid (consecutive blocks per wave): last root whose first block is <= b
+    auto root_of_block = [&](uint32_t b_first_of_wave, uint32_t b) {
+      return coop_last_le([&](int r) { return boff[r]; }, nroots, b_first_of_wave, b, lane);
+    };
+    auto push_block = [&](int r, uint32_t gh, const Packed<CW>& pk) {
+      const uint32_t old = (uint32_t)atomicAdd(ctr, (int32_t)(((uint32_t)bpl[r] << 10) | 1u));
+      const uint32_t slot = old & 0x3FFu;
+      BRec rec;
+      rec.gh = gh;
+      rec.rs = (uint32_t)r | ((old >> 10) << 8);
+      recs[slot] = rec;
+#pragma unroll
+      for (int k = 0; k < CW; k++) rpk[(size_t)slot * CW + k] = pk.w[k];
+    };
+    // EigCut's first test of a partial group of root r against the best error of the root so far
+    auto dropped = [&](int r, double s1, double tr) {
+      const int vf = bv[r];
+      const double bound = __longlong_as_double((long long)rbound[r]);
+      const double limit = bound * (double)(2 * vf) * (1.0 + 0x1p-40);
+      const double limit_adj = fma(1.002, limit, (double)(2 * vf) * ec.o2slack);
+      return s1 * fma(2e-12, tr, p.p3max2c * limit_adj) < 1.0;
+    };
+    if (!bound_tests && have_pre) park(pre);
+    if (bound_tests) {
+      // ---- 1. seeds: the block with the largest s1 (smallest bound) of every root is evaluated first
+      for (uint32_t b0 = 0; b0 < nblocks; b0 += T) {
+        const uint32_t b = b0 + (uint32_t)tid;
+        if (b0 + (uint32_t)(wave * 64) >= nblocks) continue;  // wave-uniform
+        const int r = root_of_block(b0 + (uint32_t)(wave * 64), b < nblocks ? b : nblocks - 1);
+        if (b < nblocks) {
+          const uint32_t gh = b - boff[r];
+          double B[10], tr;
+          Packed<CW> pk;
+          const int v = group_matrix<true>(r, gh, bnl[r], B, pk);
+          float s1 = 0.0f;  // a one-view partial group carries no information: any block will do
+          if (v >= 2) s1 = (float)fmin(eigcut_s1_shifted(B, c0, tr), 3e38);
+          atomicMax(&seedkey[r], ((unsigned long long)__float_as_uint(s1) << 32) | (unsigned long long)(0xFFFFFFFFu - gh));
+        }
+      }
+      if (have_pre) park(pre);  // the next frame's blobs have arrived by now: out of the registers before the evaluation rounds
+      __syncthreads();
+      for (int r = tid; r < nroots; r += T) {
+        if (bnb[r]) {
+          const uint32_t gh = 0xFFFFFFFFu - (uint32_t)seedkey[r];
+          seedgh[r] = gh;
+          double B[10];
+          Packed<CW> pk;
+          group_matrix<false>(r, gh, bnl[r], B, pk);
+          push_block(r, gh, pk);
+        }
+      }
+      __syncthreads();
+    }
+    // ---- 2. the queued blocks' candidates (spread over all lanes, whatever root they belong to), then the next
+    // blocks' tests, until nothing is left
+    uint32_t b0 = 0;
+    while (true) {
+      const uint32_t cv_ = (uint32_t)*ctr;
+      const uint32_t ns = cv_ & 0x3FFu, ne = cv_ >> 10;
+      const bool blocks_left = b0 < nblocks;
+      if (ns && (!blocks_left || ne >= (uint32_t)p.bb_flush || ns > (uint32_t)(kBBRecs - T))) {
+        for (uint32_t i0 = 0; i0 < ne; i0 += T) {
+          const uint32_t i = i0 + (uint32_t)tid;
+          const bool have = i < ne;
+          double e = inf, X[3] = {0, 0, 0};
+          int r = 0;
+          uint32_t gl = 0;
+          // the record (surviving block) that candidate i of the expanded list belongs to: last one starting at or before i
+          uint32_t lo = 0;
+          if (i0 + (uint32_t)(wave * 64) < ne)  // wave-uniform
+            lo = (uint32_t)coop_last_le([&](int k) { return recs[k].rs >> 8; }, (int)ns, i0 + (uint32_t)(wave * 64), have ? i : ne - 1, lane);
+          if (have) {
+            const BRec rec = recs[lo];
+            r = (int)(rec.rs & 0xFFu);
+            uint32_t rem = i - (rec.rs >> 8);
+            gl = rec.gh * (uint32_t)bpl[r] + rem;
+            Packed<CW> pk;
+#pragma unroll
+            for (int k = 0; k < CW; k++) pk.w[k] = rpk[(size_t)lo * CW + k];
+            const uint8_t* a = act + (size_t)r * C;
+            const int nl = bnl[r];
+            for (int k = 0; k < nl; k++) {  // the block's open digits
+              const int c = a[k];
+              uint32_t qd, dgt;
+              divmod_small(rem, nh[(size_t)r * C + c], qd, dgt);
+              rem = qd;
+              pk.set(c, hits[((size_t)r * C + c) * M + dgt]);
+            }
+            double B[10];
+            int v = 0;
+#pragma unroll
+            for (int ee = 0; ee < 10; ee++) B[ee] = 0.0;
+            for (int c = 0; c < C; c++) {  // cameras in ascending order: the one canonical rounding of B
+              const uint32_t k = pk.get(c);
+              if (k != 0xFFu) {
+                const double* t = bt + ((size_t)c * M + k) * 10;
+#pragma unroll
+                for (int ee = 0; ee < 10; ee++) B[ee] = B[ee] + t[ee];
+                v++;
+              }
+            }
+            auto obs_p = [&](int c, double& x, double& y) -> bool {
+              const uint32_t k = pk.get(c);
+              if (k == 0xFFu) return false;
+              const float2 w = bxy[(size_t)c * M + k];
+              x = (double)w.x;
+              y = (double)w.y;
+              return true;
+            };
+            const double bound = __longlong_as_double((long long)rbound[r]);
+            solve_and_score<true, true, F32R>(cv, B, v, obs_p, X, e, bound * (double)(2 * v) * (1.0 + 0x1p-40), ec);
+#ifdef MOCAP_DEBUG_EIGCHECK  // self-check build: a candidate whose evaluation was cut short must not beat the bound it was cut against
+            if (!(e < inf)) {
+              double B2[10], X2[3], e2;
+#pragma unroll
+              for (int ee = 0; ee < 10; ee++) B2[ee] = 0.0;
+              for (int c = 0; c < C; c++) {
+                const uint32_t k = pk.get(c);
+                if (k != 0xFFu) {
+                  const double* t = bt + ((size_t)c * M + k) * 10;
+#pragma unroll
+                  for (int ee = 0; ee < 10; ee++) B2[ee] = B2[ee] + t[ee];
+                }
+              }
+              solve_and_score<true, true, F32R>(cv, B2, v, obs_p, X2, e2);
+              atomicAdd(&p.status[p.n_frames], 1);
+              if (e2 <= bound) printf("EIGCHECK candidate: root %d g %u bound %.17g true %.17g\n", r, gl, bound, e2);
+            }
+#endif
+          }
+          // deliver: lexicographic minimum of (error bits, candidate index) in the (wave, root) slot; an error that is
+          // not finite counts as +inf (such a candidate only ever stands when the root has no finite error at all);
+          // the index word carries "the error was NaN" in its lowest bit (the error itself is not stored)
+          const bool fin = e < inf;
+          const unsigned long long key = fin ? (unsigned long long)__double_as_longlong(e) : kInfBits;
+          const uint32_t gword = (gl << 1) | ((e != e) ? 1u : 0u);
+          const int ss = wave * R + r;
+          if (fin) atomicMin(&rbound[r], key);
+          const bool want = have && (key < slot_key[ss] || (key == slot_key[ss] && gword < slot_g[ss]));
+          if (__ballot(want)) {
+            unsigned long long old = 0;
+            if (want) old = atomicMin(&slot_key[ss], key);
+            wave_lds_sync();
+            const bool holder = want && slot_key[ss] == key;
+            if (holder && old > key) slot_g[ss] = 0xFFFFFFFFu;  // the error went down in this round: any index is better
+            wave_lds_sync();
+            if (holder) atomicMin(&slot_g[ss], gword);
+            wave_lds_sync();
+            if (holder && slot_g[ss] == gword) {
+              slot_x[3 * ss + 0] = X[0];
+              slot_x[3 * ss + 1] = X[1];
+              slot_x[3 * ss + 2] = X[2];
+            }
+            wave_lds_sync();
+          }
+        }
+        __syncthreads();
+        if (tid == 0) *ctr = 0;
+        __syncthreads();
+        continue;
+      }
+      if (!blocks_left) break;
+      const uint32_t b = b0 + (uint32_t)tid;
+      const uint32_t bw = b0 + (uint32_t)(wave * 64);
+      b0 += T;
+      int r = 0;
+      if (bw < nblocks) r = root_of_block(bw, b < nblocks ? b : nblocks - 1);  // wave-uniform branch
+      if (b < nblocks) {
+        const uint32_t gh = b - boff[r];
+        if (gh != seedgh[r]) {
+          double B[10], tr;
+          Packed<CW> pk;
+          bool survive = true;
+          if (bound_tests) {
+            const int v = group_matrix<true>(r, gh, bnl[r], B, pk);
+            if (v >= 2) {
+              const double s1 = eigcut_s1_shifted(B, c0, tr);
+              survive = !dropped(r, s1, tr);
+            }
+          } else {
+            group_matrix<false>(r, gh, bnl[r], B, pk);
+          }
+          if (survive) push_block(r, gh, pk);
+#ifdef MOCAP_DEBUG_EIGCHECK  // self-check build: EVERY candidate of a dropped block is evaluated in full against the bound it was dropped on
+          if (!survive) {
+            const double bound = __longlong_as_double((long long)rbound[r]);
+            const uint32_t pl = bpl[r];
+            for (uint32_t l = 0; l < pl; l++) {
+              double B2[10], X2[3], e2 = inf;
+              Packed<CW> pk2;
+              const int v2 = group_matrix<true>(r, gh * pl + l, 0, B2, pk2);
+              auto obs2 = [&](int c, double& x, double& y) -> bool {
+                const uint32_t k = pk2.get(c);
+                if (k == 0xFFu) return false;
+                const float2 w = bxy[(size_t)c * M + k];
+                x = (double)w.x;
+                y = (double)w.y;
+                return true;
+              };
+              solve_and_score<true, true, F32R>(cv, B2, v2, obs2, X2, e2);
+              atomicAdd(&p.status[p.n_frames + 1], 1);
+              if (e2 <= bound) printf("EIGCHECK block: root %d block %u candidate %u bound %.17g true %.17g\n", r, gh, l, bound, e2);
+            }
+          }
+#endif
+        }
+      }
+      __syncthreads();
+    }
+    __syncthreads();
+  }
+
+  // winner of root r: the (wave, root) slots merged
+  __device__ bool root_winner(int r, double& eb, uint32_t& gb, double (&Xb)[3]) const {
+    if (!gcnt[r]) return false;
+    unsigned long long kb = ~0ull;
+    uint32_t gw = 0xFFFFFFFFu;
+    int sb = r;
+    for (int w = 0; w < W; w++) {
+      const int s = w * R + r;
+      const unsigned long long k = slot_key[s];
+      const uint32_t g = slot_g[s];
+      if (k < kb || (k == kb && g < gw)) {
+        kb = k;
+        gw = g;
+        sb = s;
+      }
+    }
+    if (kb == ~0ull) return false;
+    gb = gw >> 1;
+    eb = kb != kInfBits ? __longlong_as_double((long long)kb)
+                        : ((gw & 1u) ? __longlong_as_double(0x7ff8000000000000ll) : __builtin_huge_val());
+    Xb[0] = slot_x[3 * sb + 0];
+    Xb[1] = slot_x[3 * sb + 1];
+    Xb[2] = slot_x[3 * sb + 2];
+    return true;
+  }
+
+  // ---------------------------------------------------------------- phase E
+  __device__ void write_point(int64_t frame, int r, double e, uint32_t gl, const double (&X)[3]) const {
+    const size_t o = (size_t)frame * R + outslot[r];
+    store_point(p, o, X);  // incl. the fused world-coordinate epilogue (helpers.py:96-103)
+    p.err[o] = e;
+    uint32_t rem = gl;  // decode the winning group
+    const int rc = root_cam[r];
+    int16_t* co = p.corr + o * C;
+    for (int c = 0; c < C; c++) {
+      int16_t s = -1;
+      if (c == rc) {
+        s = (int16_t)root_blob[r];
+      } else if (c > rc) {
+        const uint32_t n = nh[(size_t)r * C + c];
+        if (n) {
+          uint32_t qd, dgt;
+          divmod_small(rem, n, qd, dgt);
+          s = (int16_t)hits[((size_t)r * C + c) * M + dgt];
+          rem = qd;
+        }
+      }
+      co[c] = s;
+    }
+  }
+};
+
+#ifndef MOCAP_BB_WAVES_PER_EU
+#define MOCAP_BB_WAVES_PER_EU 4
+#endif
+
+template <bool F32R, int CW>
+__global__ __launch_bounds__(kBBThreads, MOCAP_BB_WAVES_PER_EU) void frame_bb_kernel(FrameArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  BBState<F32R, CW> st(p, smem);
+  const int tid = threadIdx.x;
+  const FrameQueues& q = p.q;
+  int chunk_next = 0, chunk_end = 0;  // lane 0 only: frames of the chunk it pulled last
+  auto pull = [&]() -> int {          // lane 0 only: next frame of the batch, or -1
+    if (chunk_next >= chunk_end) {
+      chunk_next = q_add(&q.counters[QC_NEXT_FRAME], q.frame_chunk);
+      chunk_end = chunk_next + q.frame_chunk;
+    }
+    const int item = chunk_next++;
+    return item < p.n_frames ? item : -1;
+  };
+  // software pipeline over the frames: while frame k is searched, frame k + 1 is already pulled from the queue and on
+  // its way from HBM into registers
+  if (tid == 0) st.misc[MI_ITEM] = pull();
+  __syncthreads();
+  int item = st.misc[MI_ITEM];
+  typename BBState<F32R, CW>::Pre pre = {make_float2(0.f, 0.f), make_float2(0.f, 0.f), 0};
+  if (item >= 0) {
+    st.prefetch(item, pre);
+    st.park(pre);
+  }
+  __syncthreads();
+  while (item >= 0) {
+    const int64_t frame = item;
+    st.stage(frame);
+    int next_item = -1;
+    if (tid == 0) next_item = pull();  // (the atomic's result is first needed inside match(), a few barriers later)
+    st.match(next_item);
+    const int next = st.misc[MI_NEXT];
+    if (next >= 0) st.prefetch(next, pre);  // in flight during the first part of the search
+    if (tid == 0) {
+      const int status = st.misc[MI_STATUS];
+      p.n_out[frame] = status ? 0 : st.misc[MI_NOUT];
+      p.status[frame] = status;
+      if (p.n_cand) p.n_cand[frame] = st.misc[MI_G];
+    }
+    const uint32_t G = (MOCAP_BB_DEBUG_SKIP & 1) ? 0u : (uint32_t)st.misc[MI_G];
+    if (G) {
+      // the bound tests pay their fixed cost (seed pass + a test per block) only on frames with enough candidates;
+      // smaller frames queue every block -- same evaluation rounds, same result
+      st.search(G >= (uint32_t)p.bb_min_g, pre, next >= 0);
+      const int nroots = st.misc[MI_NROOTS];
+      for (int r = tid; r < nroots; r += kBBThreads) {
+        if (st.outslot[r] < 0) continue;
+        double e, X[3];
+        uint32_t gl;
+        if (st.root_winner(r, e, gl, X)) st.write_point(frame, r, e, gl, X);
+      }
+    } else if (next >= 0) {
+      st.park(pre);
+    }
+    __syncthreads();  // the frame's LDS state is dead: the next one may be staged
+    item = next;
+  }
+  // the last workgroup to leave puts the queue counters back to zero: the next launch needs no memset
+  if (tid == 0 && q_add(&q.counters[QC_EXITED], 1) == (int)gridDim.x - 1)
+    for (int c = 0; c < QC_COUNT; c++) q_store(&q.counters[c], 0);
+}
+
+int frame_bb_wg_per_cu_cap() { return MOCAP_BB_WAVES_PER_EU; }
+
+hipError_t launch_frame_bb(const FrameArgs& a, int grid, hipStream_t stream) {
+  const size_t lds = frame_bb_lds_bytes(a.cv.C, a.M, a.K_max);
+  void (*k)(FrameArgs);
+  if (a.cv.C <= 8)
+    k = a.cv.f32_rounding ? frame_bb_kernel<true, 1> : frame_bb_kernel<false, 1>;
+  else
+    k = a.cv.f32_rounding ? frame_bb_kernel<true, 2> : frame_bb_kernel<false, 2>;
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(k, dim3(grid), dim3(kBBThreads), lds, stream, a);
+  return hipGetLastError();
+}
+
+}  // namespace mocap

@@ -39,52 +39,15 @@
 // launch).  The three-launch form stays selectable (MOCAP_FRAME_LAUNCHES=3) for A/B runs; results are identical.
 #include "mocap_device.hpp"
 #include "kernels.hpp"
+#include "frame_common.hpp"
 
 namespace mocap {
-
-constexpr uint16_t kNone = 0xFFFF;
 
 // register budget: 4 waves per SIMD (<= 128 VGPRs); the LDS footprint at 8 x 16 allows 4 workgroups
 // of 256 lanes per CU, so both limits meet at 16 waves per CU
 #ifndef MOCAP_FRAME_WAVES_PER_EU
 #define MOCAP_FRAME_WAVES_PER_EU 4
 #endif
-
-// Exact quotient/remainder for rem < 2^24, 1 <= n <= 2^16: float(rem) is exact and the float
-// quotient (1-ulp v_rcp_f32, one rounded multiply, truncation) is within [-2, +1] of the true one
-// (|error| <= 3/n, exact for n = 1, 2), so two correction steps per direction make it exact at about
-// half the instructions of a 32-bit integer division.  Candidate indices per root are < 2^24 (G_cap).
-__device__ __forceinline__ void divmod_small(uint32_t rem, uint32_t n, uint32_t& q, uint32_t& r) {
-  const float inv = __builtin_amdgcn_rcpf((float)n);
-  q = (uint32_t)((float)rem * inv);
-  int32_t rr = (int32_t)(rem - q * n);
-#pragma unroll
-  for (int k = 0; k < 2; k++) {
-    if (rr < 0) { rr += (int32_t)n; q--; }
-    if (rr >= (int32_t)n) { rr -= (int32_t)n; q++; }
-  }
-  r = (uint32_t)rr;
-}
-
-// queue words shared between workgroups inside one launch (MODE_ALL): agent-scope relaxed accesses (sc1)
-__device__ __forceinline__ int q_load(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void q_store(int32_t* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ int q_add(int32_t* p, int v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-template <class Tp>
-__device__ __forceinline__ Tp q_ld(const Tp* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-template <class Tp>
-__device__ __forceinline__ void q_st(Tp* p, Tp v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-// per-root epipolar line record in LDS: a, b, c, sqrt(a^2+b^2), its reciprocal, pad
-constexpr int kLineStride = 6;
-
-// LDS accesses of one wave execute in order; this only stops the compiler from moving them across
-// the point where lanes of the same wave exchange data through LDS (no s_barrier needed)
-__device__ __forceinline__ void wave_lds_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 
 // Where the per-frame state lives.  Narrow frames (the realistic rigs: 8 cameras x 16 markers needs
 // 39 KB) keep everything in LDS.  Wide frames (up to 64 cameras x 256 blobs: the blobs alone are
@@ -93,7 +56,7 @@ __device__ __forceinline__ void wave_lds_sync() {
 // place from the input batch.  Same code either way: the arrays are reached through pointers.
 struct FrameLayout {
   // byte offsets, computed identically on host (sizes) and device (carving)
-  size_t line, wq, dist, seg_e, seg_x, seg_g, goff, gcnt, outslot, hcount, root_blob, root_cam, claimed, nact,
+  size_t line, dist, seg_e, seg_x, seg_g, goff, gcnt, outslot, hcount, root_blob, root_cam, claimed, nact,
       cnt, misc, rbound, lds_total;                  // always LDS
   size_t bxy, cxy, hits, dig, nh, act, hb_d, hb_k;   // LDS when narrow, workspace when wide
   size_t bt;                                          // table mode: DLT contribution per (camera, blob)
@@ -107,10 +70,6 @@ struct FrameLayout {
     Hs = wide ? H : M;
     size_t o = 0;
     line = o;      o += sizeof(double) * kLineStride * R;
-    // table mode: the block records of the branch-and-bound evaluation (2 T of 8 bytes) live where the epipolar
-    // lines were -- phase B is over when phase D starts
-    wq = line;
-    if (table && (size_t)16 * T > o - line) o = line + (size_t)16 * T;
     seg_e = o;     o += sizeof(double) * (T + R);
     seg_x = o;     o += sizeof(double) * 3 * (T + R);
     // dist (phase B scratch) and the segment arrays (phase D/E) are never live together
@@ -157,20 +116,7 @@ struct FrameLayout {
 };
 
 size_t frame_lds_bytes(int C, int M, int R, int T, int H, bool wide, bool table) { return FrameLayout(C, M, R, T, H, wide, table && !wide).lds_total; }
-// the branch-and-bound evaluation packs a group into 8 x 8 bits, a root into 8 bits, and keeps its bookkeeping in
-// arrays the odometer variant owns (FrameState::evaluate_bb)
-bool frame_bb_fits(int C, int M, int R, int T) {
-  const int W = T / 64;
-  // slots: key, error, point = 5 doubles per (wave, root) in the 4 (T + R) doubles of the segment arrays; the small
-  // per-root arrays in a column block of C T bytes
-  return C <= 8 && M <= 255 && R <= 255 && R <= T && T <= 256 && T % 64 == 0 && 5 * W * R <= 4 * (T + R) && W * R <= T + R &&
-         (size_t)24 * R + 8 <= (size_t)C * T && C * T / 8 + (4 * (T + R) - 5 * W * R) >= 2 * T;
-}
 size_t frame_ws_bytes(int C, int M, int R, int T, int H, bool wide, bool table) { return FrameLayout(C, M, R, T, H, wide, table && !wide).ws_total; }
-
-// misc[] slots
-enum { MI_NROOTS = 0, MI_STATUS = 1, MI_NOUT = 2, MI_G = 3, MI_ITEM = 4, MI_DEFER = 5, MI_KIND = 6,
-       MI_OMAX = 7 /* bit pattern of the largest |coordinate| among the frame's blobs (float >= 0) */ };
 
 template <int T, bool UNIFORM_K, bool F32R, bool WIDE>
 struct FrameState {
@@ -179,7 +125,6 @@ struct FrameState {
   const int C, M, R, tid;
   int Hs;  // hit-list stride per (root, camera)
   double *line, *dist, *seg_e, *seg_x;
-  void* wqueue;  // branch and bound: 2 T block records (16 T bytes), where the epipolar lines of phase B were
   unsigned long long* rbound;  // [R] bit pattern of the smallest error any lane has found for the root (+inf at start)
   uint32_t *seg_g, *goff, *gcnt;
   int32_t *outslot, *cnt, *misc;
@@ -201,7 +146,6 @@ struct FrameState {
     const FrameLayout L(C, M, R, T, p_.H, WIDE, TABLE);
     Hs = L.Hs;
     line = (double*)(smem + L.line);
-    wqueue = (void*)(smem + L.wq);
     dist = (double*)(smem + L.dist);
     seg_e = (double*)(smem + L.seg_e);
     seg_x = (double*)(smem + L.seg_x);
@@ -730,328 +674,6 @@ struct FrameState {
     __syncthreads();
   }
 
-  // ---------------------------------------------------------------- phase D/E, branch and bound (table mode)
-  // The candidate groups of a root are a Cartesian product, and the DLT matrix of a group is a SUM over its views, so
-  // a PARTIAL group (some cameras left open) bounds all its completions at once: B_partial <= B_full (positive
-  // semi-definite terms), hence by EigCut's argument (mocap_device.hpp)
-  //     sum of squared residuals of ANY completion  >=  lam1(B_partial) / max_c |P_c[2]|^2
-  // (taken in a world frame moved to the middle of the working volume, eigcut_s1_shifted: same inequality, much tighter).
-  // A root's candidates are split into BLOCKS: the `nl` fastest digits (product pl >= bb_pl) are left open, one block
-  // per value of the remaining digits -- a contiguous run of pl candidate indices.  One Cholesky factorisation per
-  // block drops the whole block when its bound exceeds the smallest error found for the root so far; only the
-  // candidates of surviving blocks are triangulated and reprojected (counts and timings: DESIGN.md 3.1a).
-  //   1. seeds: every block's s1; the block with the largest s1 (smallest bound) of each root almost always holds the
-  //      root's winner: its candidates are evaluated first, which makes the bound tight before any block is tested;
-  //   2. block tests, T at a time; the survivors' candidates are spread over all lanes of the workgroup (a block's
-  //      record carries the offset of its candidates in the expanded list), whatever root they belong to.
-  // Exactness: a dropped candidate's error exceeds the error of a candidate that WAS evaluated, by more than every
-  // rounding allowance -- it is neither the minimum nor tied with it; the winner is the lexicographic minimum of
-  // (error, candidate index) over the evaluated ones = the first minimum in candidate order (np.argmin,
-  // helpers.py:418), whatever the evaluation order.  Results are kept per (wave, root) and merged by root_winner_bb.
-  struct BRec { uint32_t gh, rs; };  // surviving block gh of root r = rs & 0xFF; its candidates are [start, start + pl[r]) of the expanded list, start = rs >> 8
-  static constexpr unsigned long long kInfBits = 0x7ff0000000000000ull;
-
-  // DLT matrix of candidate `rem` of root r with the first `skip` multi-hit cameras left out (skip = 0: the whole
-  // group, rem = candidate index; skip = nl: the block's partial group, rem = block index).  packed: blob index per
-  // camera (0xFF = not in the group).  Returns the number of views.
-  __device__ int group_matrix(int r, uint32_t rem, int skip, double (&B)[10], unsigned long long& packed) {
-    const int rc = root_cam[r];
-    const uint16_t* nhr = nh + (size_t)r * C;
-    const uint8_t* hr = hits + (size_t)r * C * Hs;
-    packed = ~0ull;
-    int v = 0, ka = 0;
-#pragma unroll
-    for (int e = 0; e < 10; e++) B[e] = 0.0;
-    for (int c = 0; c < C; c++) {
-      uint32_t k = 0xFFu;
-      if (c == rc) {
-        k = root_blob[r];
-      } else if (c > rc) {
-        const uint32_t n = nhr[c];
-        if (n == 1) {
-          k = hr[(size_t)c * Hs];
-        } else if (n > 1) {
-          if (ka >= skip) {
-            uint32_t qd, dgt;
-            divmod_small(rem, n, qd, dgt);
-            rem = qd;
-            k = hr[(size_t)c * Hs + dgt];
-          }
-          ka++;
-        }
-      }
-      if (k != 0xFFu) {
-        const double* t = bt + ((size_t)c * M + k) * 10;
-#pragma unroll
-        for (int e = 0; e < 10; e++) B[e] = B[e] + t[e];
-        v++;
-        packed ^= (unsigned long long)(k ^ 0xFFu) << (8 * c);
-      }
-    }
-    return v;
-  }
-
-  __device__ void evaluate_bb() {
-    constexpr int W = T / 64;
-    const int nroots = misc[MI_NROOTS];
-    const int wave = tid >> 6;
-    // arrays of this variant live where the odometer variant keeps its columns and segments
-    uint32_t* boff = (uint32_t*)(cix - tid);           // [R + 1] block offsets (cix / dig point at the lane's column)
-    uint32_t* bnb = boff + (R + 1);                    // [R] blocks of the root
-    uint32_t* seedgh = bnb + R;                        // [R] seed block
-    unsigned long long* seedkey = (unsigned long long*)(seedgh + R + ((3 * R + 1) & 1));  // [R] (s1 as float, ~index) max
-    uint16_t* bpl = (uint16_t*)(seedkey + R);          // [R] candidates per block
-    uint8_t* bnl = (uint8_t*)(bpl + R);                // [R] open digits
-    uint8_t* bv = bnl + R;                             // [R] views of a full group
-    unsigned long long* slot_key = (unsigned long long*)seg_e;  // [W][R] error bits, +inf for "not finite", ~0 = empty
-    double* slot_ea = seg_e + W * R;                   // [W][R] the error as computed (inf / NaN when no finite one)
-    double* slot_x = slot_ea + W * R;                  // [W][R][3]   (seg_e and seg_x are contiguous: 4 (T + R) doubles)
-    uint32_t* slot_g = seg_g;                          // [W][R]
-    BRec* recs = (BRec*)wqueue;                        // [2 T] surviving blocks
-    // ... and the blob indices of each block's fixed cameras (0xFF = open or absent), so that a candidate only decodes
-    // its open digits: 2 T x 8 bytes, split over the digit columns and the unused tail of the segment arrays
-    unsigned long long* rpkA = (unsigned long long*)(dig - tid);
-    unsigned long long* rpkB = (unsigned long long*)seg_e + 5 * W * R;
-    const uint32_t capA = (uint32_t)(C * T) / 8u;
-    int32_t* ctr = &misc[MI_DEFER];                    // blocks | their candidates << 10 (MI_DEFER is read before phase D)
-    const double inf = __builtin_huge_val();
-    EigCut ec;
-    {
-      const double om = (double)__int_as_float(misc[MI_OMAX]);
-      ec.p3max2 = p.p3max2;
-      ec.o2slack = (1100.0 * 0x1p-46) * (om * om);
-    }
-    const double c0[3] = {p.bb_c0[0], p.bb_c0[1], p.bb_c0[2]};  // origin of the frame the block bounds are taken in
-    const uint32_t PL = (uint32_t)p.bb_pl;
-    for (int r = tid; r < nroots; r += T) {
-      const uint8_t* a = act + (size_t)r * C;
-      const int na = nact[r], rc = root_cam[r];
-      uint32_t pl = 1, nb = 1;
-      int nl = 0;
-      while (nl < na && pl < PL) pl *= nh[(size_t)r * C + a[nl++]];
-      for (int k = nl; k < na; k++) nb *= nh[(size_t)r * C + a[k]];
-      int views = 1;
-      for (int c = rc + 1; c < C; c++) views += nh[(size_t)r * C + c] ? 1 : 0;
-      bpl[r] = (uint16_t)pl;
-      bnl[r] = (uint8_t)nl;
-      bv[r] = (uint8_t)views;
-      bnb[r] = gcnt[r] ? nb : 0u;
-      seedkey[r] = 0ull;
-    }
-    for (int s = tid; s < W * R; s += T) {
-      slot_key[s] = ~0ull;
-      slot_g[s] = 0xFFFFFFFFu;
-    }
-    if (tid == 0) *ctr = 0;
-    __syncthreads();
-    if (tid == 0) {
-      uint32_t acc = 0;
-      for (int r = 0; r < nroots; r++) {
-        boff[r] = acc;
-        acc += bnb[r];
-      }
-      boff[nroots] = acc;
-    }
-    __syncthreads();
-    const uint32_t nblocks = boff[nroots];
-    auto root_of_block = [&](uint32_t b) {
-      int lo = 0, hi = nroots - 1;
-      while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (boff[mid] <= b) lo = mid; else hi = mid - 1;
-      }
-      return lo;
-    };
-    auto push_block = [&](int r, uint32_t gh, unsigned long long packed) {
-      const uint32_t old = (uint32_t)atomicAdd(ctr, (int32_t)(((uint32_t)bpl[r] << 10) | 1u));
-      const uint32_t slot = old & 0x3FFu;
-      BRec rec;
-      rec.gh = gh;
-      rec.rs = (uint32_t)r | ((old >> 10) << 8);
-      recs[slot] = rec;
-      if (slot < capA) rpkA[slot] = packed; else rpkB[slot - capA] = packed;
-    };
-    // candidate i of the expanded block list -> (root, candidate index)
-    // ... and its DLT matrix: the block's fixed cameras come with the record, the open digits are decoded from l
-    auto expanded = [&](uint32_t i, uint32_t ns, int& r, uint32_t& gl, double (&B)[10], unsigned long long& packed) {
-      uint32_t lo = 0, hi = ns - 1;  // last record that starts at or before i
-      while (lo < hi) {
-        const uint32_t mid = (lo + hi + 1) >> 1;
-        if ((recs[mid].rs >> 8) <= i) lo = mid; else hi = mid - 1;
-      }
-      const BRec rec = recs[lo];
-      r = (int)(rec.rs & 0xFFu);
-      uint32_t rem = i - (rec.rs >> 8);
-      gl = rec.gh * (uint32_t)bpl[r] + rem;
-      packed = lo < capA ? rpkA[lo] : rpkB[lo - capA];
-      const uint8_t* a = act + (size_t)r * C;
-      const int nl = bnl[r];
-      for (int k = 0; k < nl; k++) {
-        const int c = a[k];
-        uint32_t qd, dgt;
-        divmod_small(rem, nh[(size_t)r * C + c], qd, dgt);
-        rem = qd;
-        const uint32_t idx = hits[((size_t)r * C + c) * Hs + dgt];
-        packed ^= (unsigned long long)(idx ^ 0xFFu) << (8 * c);
-      }
-      int v = 0;
-#pragma unroll
-      for (int e = 0; e < 10; e++) B[e] = 0.0;
-      for (int c = 0; c < C; c++) {  // cameras in ascending order: the one canonical rounding of B
-        const uint32_t k = (uint32_t)(packed >> (8 * c)) & 0xFFu;
-        if (k != 0xFFu) {
-          const double* t = bt + ((size_t)c * M + k) * 10;
-#pragma unroll
-          for (int e = 0; e < 10; e++) B[e] = B[e] + t[e];
-          v++;
-        }
-      }
-      return v;
-    };
-    // EigCut's first test of a (partial or full) group of root r against the best error of the root so far
-    auto dropped = [&](int r, double s1, double tr) {
-      const int vf = bv[r];
-      const double bound = __longlong_as_double((long long)rbound[r]);
-      const double limit = bound * (double)(2 * vf) * (1.0 + 0x1p-40);
-      const double limit_adj = fma(1.002, limit, (double)(2 * vf) * ec.o2slack);
-      return s1 * fma(2e-12, tr, p.p3max2c * limit_adj) < 1.0;
-    };
-    // ---- 1. seeds: the block with the largest s1 (smallest bound) of every root is evaluated first
-    for (uint32_t b0 = 0; b0 < nblocks; b0 += T) {
-      const uint32_t b = b0 + (uint32_t)tid;
-      if (b < nblocks) {
-        const int r = root_of_block(b);
-        const uint32_t gh = b - boff[r];
-        double B[10], tr;
-        unsigned long long packed;
-        const int v = group_matrix(r, gh, bnl[r], B, packed);
-        float s1 = 0.0f;  // a one-view partial group carries no information: any block will do
-        if (v >= 2) s1 = (float)fmin(eigcut_s1_shifted(B, c0, tr), 3e38);
-        atomicMax(&seedkey[r], ((unsigned long long)__float_as_uint(s1) << 32) | (unsigned long long)(0xFFFFFFFFu - gh));
-      }
-    }
-    __syncthreads();
-    for (int r = tid; r < nroots; r += T) {
-      if (bnb[r]) {
-        const uint32_t gh = 0xFFFFFFFFu - (uint32_t)seedkey[r];
-        seedgh[r] = gh;
-        double B[10];
-        unsigned long long packed;
-        group_matrix(r, gh, bnl[r], B, packed);
-        push_block(r, gh, packed);
-      }
-    }
-    __syncthreads();
-    // ---- 2. the queued blocks' candidates (spread over all lanes, whatever root they belong to), then the next
-    // blocks' tests, until nothing is left
-    uint32_t b0 = 0;
-    while (true) {
-      const uint32_t cv_ = (uint32_t)*ctr;
-      const uint32_t ns = cv_ & 0x3FFu, ne = cv_ >> 10;
-      const bool blocks_left = b0 < nblocks;
-      if (ns && (!blocks_left || ne >= (uint32_t)p.bb_flush || ns > (uint32_t)T)) {
-        for (uint32_t i0 = 0; i0 < ne; i0 += T) {
-          const uint32_t i = i0 + (uint32_t)tid;
-          const bool have = i < ne;
-          double e = inf, X[3] = {0, 0, 0};
-          int r = 0;
-          uint32_t gl = 0;
-          if (have) {
-            double B[10];
-            unsigned long long packed;
-            const int v = expanded(i, ns, r, gl, B, packed);
-            auto obs_p = [&](int c, double& x, double& y) -> bool {
-              const uint32_t k = (uint32_t)(packed >> (8 * c)) & 0xFFu;
-              if (k == 0xFFu) return false;
-              const float2 w = bxy[(size_t)c * M + k];
-              x = (double)w.x;
-              y = (double)w.y;
-              return true;
-            };
-            const double bound = __longlong_as_double((long long)rbound[r]);
-            solve_and_score<true, true, F32R>(cv, B, v, obs_p, X, e, bound * (double)(2 * v) * (1.0 + 0x1p-40), ec);
-          }
-          // deliver: lexicographic minimum of (error bits, candidate index) in the (wave, root) slot; an error that is
-          // not finite counts as +inf (such a candidate only ever stands when the root has no finite error at all)
-          const bool fin = e < inf;
-          const unsigned long long key = fin ? (unsigned long long)__double_as_longlong(e) : kInfBits;
-          const int ss = wave * R + r;
-          if (fin) atomicMin(&rbound[r], key);
-          const bool want = have && (key < slot_key[ss] || (key == slot_key[ss] && gl < slot_g[ss]));
-          if (__ballot(want)) {
-            unsigned long long old = 0;
-            if (want) old = atomicMin(&slot_key[ss], key);
-            wave_lds_sync();
-            const bool holder = want && slot_key[ss] == key;
-            if (holder && old > key) slot_g[ss] = 0xFFFFFFFFu;  // the error went down in this round: any index is better
-            wave_lds_sync();
-            if (holder) atomicMin(&slot_g[ss], gl);
-            wave_lds_sync();
-            if (holder && slot_g[ss] == gl) {
-              slot_ea[ss] = e;
-              slot_x[3 * ss + 0] = X[0];
-              slot_x[3 * ss + 1] = X[1];
-              slot_x[3 * ss + 2] = X[2];
-            }
-            wave_lds_sync();
-          }
-        }
-        __syncthreads();
-        if (tid == 0) *ctr = 0;
-        __syncthreads();
-        continue;
-      }
-      if (!blocks_left) break;
-      const uint32_t b = b0 + (uint32_t)tid;
-      b0 += T;
-      if (b < nblocks) {
-        const int r = root_of_block(b);
-        const uint32_t gh = b - boff[r];
-        if (gh != seedgh[r]) {
-          double B[10], tr;
-          unsigned long long packed;
-          const int v = group_matrix(r, gh, bnl[r], B, packed);
-          bool survive = true;
-          if (v >= 2) {
-            const double s1 = eigcut_s1_shifted(B, c0, tr);
-            survive = !dropped(r, s1, tr);
-          }
-          if (survive) push_block(r, gh, packed);
-        }
-      }
-      __syncthreads();
-    }
-    __syncthreads();
-  }
-
-  // winner of root r after evaluate_bb: the (wave, root) slots merged
-  __device__ bool root_winner_bb(int r, double& eb, uint32_t& gb, double (&Xb)[3]) {
-    constexpr int W = T / 64;
-    if (!gcnt[r]) return false;
-    const unsigned long long* slot_key = (const unsigned long long*)seg_e;
-    unsigned long long kb = ~0ull;
-    int sb = r;
-    gb = 0xFFFFFFFFu;
-    for (int w = 0; w < W; w++) {
-      const int s = w * R + r;
-      const unsigned long long k = slot_key[s];
-      const uint32_t g = seg_g[s];
-      if (k < kb || (k == kb && g < gb)) {
-        kb = k;
-        gb = g;
-        sb = s;
-      }
-    }
-    if (kb == ~0ull) return false;
-    const double* slot_ea = seg_e + W * R;
-    const double* slot_x = slot_ea + W * R;
-    eb = slot_ea[sb];
-    Xb[0] = slot_x[3 * sb + 0];
-    Xb[1] = slot_x[3 * sb + 1];
-    Xb[2] = slot_x[3 * sb + 2];
-    return true;
-  }
-
   // first minimum over the (lane, root) segments of root r inside [g_lo, g_hi); false if the
   // root has no candidate in the range
   __device__ bool root_winner(int r, uint32_t g_lo, uint32_t g_hi, double& eb, uint32_t& gb, double (&Xb)[3]) {
@@ -1081,23 +703,7 @@ struct FrameState {
   // ---------------------------------------------------------------- phase E
   __device__ void write_point(int64_t frame, int r, double e, uint32_t gl, const double (&X)[3]) {
     const size_t o = (size_t)frame * R + outslot[r];
-    if (p.world) {
-      // world-coordinate epilogue of the frame loop (helpers.py:96-103), fused into the store:
-      // p' = diag(-1,-1,1) p ; h = W [p'; 1] ; q = h[:3] / h[3] ; swap y <-> z
-      ctab_t W = as_ctab(p.world);
-      const double x = -X[0], y = -X[1], z = X[2];
-      const double h0 = W[0] * x + W[1] * y + W[2] * z + W[3];
-      const double h1 = W[4] * x + W[5] * y + W[6] * z + W[7];
-      const double h2 = W[8] * x + W[9] * y + W[10] * z + W[11];
-      const double h3 = W[12] * x + W[13] * y + W[14] * z + W[15];
-      p.xyz[o * 3 + 0] = h0 / h3;
-      p.xyz[o * 3 + 1] = h2 / h3;
-      p.xyz[o * 3 + 2] = h1 / h3;
-    } else {
-      p.xyz[o * 3 + 0] = X[0];
-      p.xyz[o * 3 + 1] = X[1];
-      p.xyz[o * 3 + 2] = X[2];
-    }
+    store_point(p, o, X);  // incl. the fused world-coordinate epilogue (helpers.py:96-103)
     p.err[o] = e;
     uint32_t rem = gl;  // decode the winning group
     const int rc = root_cam[r];
@@ -1140,7 +746,6 @@ __global__ __launch_bounds__(T, MOCAP_FRAME_WAVES_PER_EU) void frame_kernel(Fram
   int chunk_next = 0, chunk_end = 0;  // lane 0 only: frames of the chunk it pulled last
   int done_local = 0;                 // lane 0 only: frames finished since the last count (MODE_ALL)
   if constexpr (MODE == MODE_ALL) {
-    const bool bb = decltype(st)::TABLE && p.eval_bb != 0;
     bool frames_left = true;  // lane 0 only
     while (true) {
       // ---------------------------------------------------------- pull a frame, else a slice ticket
@@ -1218,7 +823,7 @@ __global__ __launch_bounds__(T, MOCAP_FRAME_WAVES_PER_EU) void frame_kernel(Fram
       if (kind == 1) {
         if (tid == 0) {
           int defer = 0;
-          if (!bb && q.heavy_threshold && G > q.heavy_threshold) {  // (branch and bound: a frame's cost no longer follows G)
+          if (q.heavy_threshold && G > q.heavy_threshold) {
             uint32_t Sn = (G + q.slice_size - 1) / q.slice_size;
             if (Sn > 64) Sn = 64;
             const int hn = q_add(&q.counters[QC_N_HEAVY], 1);
@@ -1241,9 +846,6 @@ __global__ __launch_bounds__(T, MOCAP_FRAME_WAVES_PER_EU) void frame_kernel(Fram
         __syncthreads();
         st.write_frame_header(frame);  // n_out / status / n_cand are known after the match, whoever evaluates
       }
-      // the search pays its fixed cost (a dozen barrier-separated rounds) only on frames with enough candidates; small
-      // frames are walked exhaustively (same result either way)
-      const bool bb_frame = bb && G >= (uint32_t)p.bb_min_g;
       // candidate range of this item: the whole frame, nothing (deferred to its slices), or one slice
       uint32_t g_lo = 0, g_hi = G;
       if (kind == 1) {
@@ -1253,16 +855,7 @@ __global__ __launch_bounds__(T, MOCAP_FRAME_WAVES_PER_EU) void frame_kernel(Fram
         g_hi = (uint32_t)((uint64_t)G * (uint64_t)(sl + 1) / S);
       }
 #ifndef MOCAP_DEBUG_NO_EVAL  // timing experiments only: phases A-C without candidate evaluation
-      if (g_hi > g_lo) {
-        if constexpr (decltype(st)::TABLE) {
-          if (bb_frame)
-            st.evaluate_bb();
-          else
-            st.evaluate(g_lo, g_hi);
-        } else {
-          st.evaluate(g_lo, g_hi);
-        }
-      }
+      if (g_hi > g_lo) st.evaluate(g_lo, g_hi);
 #endif
       const int nroots = st.misc[MI_NROOTS];
       bool merge = false;
@@ -1273,12 +866,7 @@ __global__ __launch_bounds__(T, MOCAP_FRAME_WAVES_PER_EU) void frame_kernel(Fram
         uint32_t gl = 0;
         bool won = false;
 #ifndef MOCAP_DEBUG_NO_EVAL
-        if (g_hi > g_lo) {
-          if constexpr (decltype(st)::TABLE)
-            won = bb_frame ? st.root_winner_bb(r, e, gl, X) : st.root_winner(r, g_lo, g_hi, e, gl, X);
-          else
-            won = st.root_winner(r, g_lo, g_hi, e, gl, X);
-        }
+        if (g_hi > g_lo) won = st.root_winner(r, g_lo, g_hi, e, gl, X);
 #endif
         if (kind == 1) {
           if (won) st.write_point(frame, r, e, gl, X);

@@ -53,7 +53,7 @@ struct FrameArgs {
   int H;
   int wide;
   int prune;  // cut the reprojection of a group short once it cannot beat the best of its root (exact, see evaluate())
-  int eval_bb;  // table mode: branch-and-bound evaluation (frame_kernel.hip evaluate_bb)
+  int eval_bb;  // (host only) the batch goes to frame_bb.hip
   int bb_pl;    // ... candidates per block (at least)
   int bb_flush; // ... queued candidates that trigger their evaluation
   int bb_min_g; // ... frames with fewer candidates are walked exhaustively
@@ -66,8 +66,13 @@ constexpr int kWideThreads = 1024;  // workgroup size of the wide-frame variant 
 // table = identical intrinsics (CamView::uniformK): per-blob DLT contributions tabulated in LDS (narrow frames only)
 size_t frame_lds_bytes(int C, int M, int R, int T, int H, bool wide, bool table);
 size_t frame_ws_bytes(int C, int M, int R, int T, int H, bool wide, bool table);
-bool frame_bb_fits(int C, int M, int R, int T);
 hipError_t launch_frame_kernel(const FrameArgs& a, int mode, int threads, int grid, hipStream_t stream);
+// csrc/frame_bb.hip: identical plain intrinsics, C <= 16, M <= 64, K_max <= 255 -- its own kernel (256 lanes per frame)
+// and LDS layout, exact branch-and-bound selection; uses q.counters / q.frame_chunk of FrameArgs::q only
+bool frame_bb_fits(int C, int M, int R);
+size_t frame_bb_lds_bytes(int C, int M, int R);
+hipError_t launch_frame_bb(const FrameArgs& a, int grid, hipStream_t stream);
+int frame_bb_wg_per_cu_cap();  // workgroups per CU the kernel's register budget allows (its waves per SIMD)
 
 // object (drone) locator over the frame path's output (reference helpers.py:424-480), csrc/post_kernels.hip
 struct LocateArgs {

@@ -36,6 +36,7 @@ SIGNATURES = {
     "mocap_version": (ctypes.c_char_p, []),
     "mocap_set_stream": (_i32, [_vp, _vp]),
     "mocap_synchronize": (_i32, [_vp]),
+    "mocap_last_frame_kernel": (ctypes.c_char_p, [_vp]),
     "mocap_set_options": (_i32, [_vp, _u32]),
     "mocap_set_tuning": (_i32, [_vp, _i32, _i32, _i32]),
     "mocap_set_frame_limits": (_i32, [_vp, _i32, _i32]),
@@ -128,6 +129,10 @@ class MocapCore:
         if rc != MOCAP_OK and rc not in allow:
             raise MocapError(f"mocap_core error {rc}: {self.lib.mocap_last_error(self._h).decode()}")
         return rc
+
+    def last_frame_kernel(self):
+        """Name of the kernel the last frame batch went to (diagnostic; results never depend on it)."""
+        return self.lib.mocap_last_frame_kernel(self._h).decode()
 
     # ------------------------------------------------------------------ configuration
     def set_cameras(self, K, R, t):
