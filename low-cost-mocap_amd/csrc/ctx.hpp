@@ -31,7 +31,7 @@ struct mocap_ctx {
   int prune = 1;            // stop a candidate group's reprojection once it cannot beat its root's best (exact)
   int eval_bb = 1;          // branch-and-bound selection (csrc/frame_bb.hip) wherever it applies; 0: always the exhaustive walk
   int bb_pl = 16;           // ... candidates per block (at least)
-  int bb_min_g = 512;       // ... frames with fewer candidates are walked exhaustively
+  int bb_min_g = 0;         // ... frames with fewer candidates queue every block untested (swept: 0-512 equal, 2048 +13 %)
   int bb_flush = 0;         // ... queued candidates that trigger their evaluation (0 = one per lane)
   int eigcut = 1;           // ... and drop it before the null vector / the reprojection on an eigenvalue bound (EigCut)
   double eig_c0[3] = {0, 0, 0};  // ... origin for the branch-and-bound's bounds: the point closest to all optical axes

@@ -54,7 +54,8 @@ constexpr int kBBRecs = kBBThreads + 64;  // surviving blocks queued between two
 // arrays (block records, result slots, per-root block bookkeeping) are laid out behind the persistent frame state.
 struct BBLayout {
   size_t bxy, bxy_nx, cnt_nx, bt, rbound, seedkey, slot_key, slot_x, claimw, recs, rpk, scr, scr_bytes, goff, gcnt, outslot, boff, bnb, seedgh, slot_g, cnt,
-      misc, bpl, nh, hits, act, root_blob, root_cam, nact, bnl, bv, total;
+      misc, bpl, nh, hits, act, root_blob, root_cam, nact, bnl, bv, bcache, total;
+  int ncache;
   __host__ __device__ static size_t al(size_t x, size_t a) { return (x + a - 1) / a * a; }
   __host__ __device__ BBLayout(int C, int M, int R, int CW) {
     size_t o = 0;
@@ -96,15 +97,35 @@ struct BBLayout {
     nact = take((size_t)R, 1);
     bnl = take((size_t)R, 1);
     bv = take((size_t)R, 1);
+    // cache of the blocks' bounds (seed pass -> test pass: {s1, trace} rounded UP to float, 8 bytes per block): as many
+    // entries as fit below the next occupancy step of the 160 KB LDS (5, 4, 3, ... workgroups per CU), at most 1024
+    bcache = take(0, 8);
+    ncache = 0;
+    for (int per_cu = 5; per_cu >= 1; per_cu--) {
+      const size_t lim = ((size_t)160 * 1024 / per_cu - 2048) / 256 * 256;  // (slack: allocation granule, other LDS users)
+      if (lim >= o + 8 * 64) {
+        const size_t n = (lim - o) / 8;
+        ncache = (int)(n > 1024 ? 1024 : n);
+        break;
+      }
+    }
+#ifdef MOCAP_BB_NO_CACHE
+    ncache = 0;
+#endif
+    o += 8 * (size_t)ncache;
     total = al(o, 16);
   }
 };
 
 size_t frame_bb_lds_bytes(int C, int M, int R) { return BBLayout(C, M, R, C <= 8 ? 1 : 2).total; }
+static size_t frame_bb_lds_bytes_min(int C, int M, int R) {
+  const BBLayout L(C, M, R, C <= 8 ? 1 : 2);
+  return L.total - 8 * (size_t)L.ncache;
+}
 bool frame_bb_fits(int C, int M, int R) {
   // blob indices and root numbers are bytes (0xFF = none); a (root, blob) group is at most one wave; the expanded
   // candidate list of one evaluation round is counted in 22 bits (FrameArgs::bb_pl is lowered by the host if needed)
-  return C >= 2 && C <= 16 && M >= 1 && M <= 64 && R >= 1 && R <= 255 && frame_bb_lds_bytes(C, M, R) <= (size_t)64 * 1024;
+  return C >= 2 && C <= 16 && M >= 1 && M <= 64 && R >= 1 && R <= 255 && frame_bb_lds_bytes_min(C, M, R) <= (size_t)64 * 1024;
 }
 
 // blob indices of one (partial) group: one byte per camera, 0xFF = the camera is open or not in the group
@@ -126,12 +147,15 @@ struct Packed {
   }
 };
 
-template <bool F32R, int CW>
+// CT: the camera count when it is known at compile time (8: the headline rig -- camera loops unroll, their control
+// and address arithmetic leave the scalar unit, which the issue-bound kernel shares with the vector work), 0 = runtime
+template <bool F32R, int CW, int CT>
 struct BBState {
   static constexpr int T = kBBThreads, W = kBBWaves;
   const FrameArgs& p;
   const CamView& cv;
-  const int C, M, R, tid, lane, wave;
+  const int C_, M, R, tid, lane, wave;
+  __device__ __forceinline__ int cn() const { return CT > 0 ? CT : C_; }
   double* bt;
   float2 *bxy, *bxy_nx;
   int32_t* cnt_nx;
@@ -143,12 +167,15 @@ struct BBState {
   int32_t *outslot, *cnt, *misc;
   uint16_t* bpl;
   uint8_t *nh, *hits, *act, *root_blob, *root_cam, *nact, *bnl, *bv;
+  float2* bcache;      // [ncache] {s1, trace} of the first blocks, rounded up (BBLayout::bcache)
+  int ncache;
   unsigned char* scr;  // phase B scratch = the search's records and slots (BBLayout::scr)
   size_t scr_bytes;
   static constexpr unsigned long long kInfBits = 0x7ff0000000000000ull;
 
   __device__ BBState(const FrameArgs& p_, unsigned char* smem)
-      : p(p_), cv(p_.cv), C(p_.cv.C), M(p_.M), R(p_.K_max), tid(threadIdx.x), lane(threadIdx.x & 63), wave(threadIdx.x >> 6) {
+      : p(p_), cv(p_.cv), C_(p_.cv.C), M(p_.M), R(p_.K_max), tid(threadIdx.x), lane(threadIdx.x & 63), wave(threadIdx.x >> 6) {
+    const int C = cn();
     const BBLayout L(C, M, R, CW);
     bt = (double*)(smem + L.bt);
     bxy = (float2*)(smem + L.bxy);
@@ -181,6 +208,8 @@ struct BBState {
     bv = (uint8_t*)(smem + L.bv);
     scr = smem + L.scr;
     scr_bytes = L.scr_bytes;
+    bcache = (float2*)(smem + L.bcache);
+    ncache = L.ncache;
   }
 
   // ---------------------------------------------------------------- phase B building blocks
@@ -191,6 +220,7 @@ struct BBState {
   struct Line { double a, b, c, den, rden; };
   __device__ __forceinline__ Line epiline(int r, int i) const { return epiline_of(root_cam[r], root_blob[r], i); }
   __device__ __forceinline__ Line epiline_of(int rc, int rb, int i) const {
+    const int C = cn();
     const double* Fm = cv.F + 9 * ((size_t)rc * C + i);  // (per-lane camera pair: vector loads, L1/L2-resident table)
     const float2 rp = bxy[(size_t)rc * M + rb];
     const double x = (double)rp.x, y = (double)rp.y;
@@ -224,6 +254,7 @@ struct BBState {
   template <bool CHAIN>
   __device__ __forceinline__ unsigned long long match_pairs(const Line& mine, int pair_r, int pair_i, int n_pairs, int gs_shift,
                                                             int cam = 0, int Mi_chain = 0) {
+    const int C = cn();
     const int GS = 1 << gs_shift, PPS = 64 >> gs_shift;
     const int k = lane & (GS - 1), q = lane >> gs_shift;
     const int gl0 = lane & ~(GS - 1);
@@ -294,6 +325,7 @@ struct BBState {
     int n;
   };
   __device__ __forceinline__ void prefetch(int64_t frame, Pre& q) const {
+    const int C = cn();
     const float2* src = (const float2*)(p.blobs + (size_t)frame * C * M * 2);
     const int CM = C * M;
     q.b0 = tid < CM ? src[tid] : make_float2(0.f, 0.f);
@@ -303,6 +335,7 @@ struct BBState {
   // registers -> the spare blob buffer.  Called where the search's register pressure is low (after its seed pass): the
   // prefetched values must not stay live across the candidate evaluation.
   __device__ __forceinline__ void park(const Pre& q) {
+    const int C = cn();
     const int CM = C * M;
     if (tid < CM) bxy_nx[tid] = q.b0;
     if (tid + T < CM) bxy_nx[tid + T] = q.b1;
@@ -310,6 +343,7 @@ struct BBState {
   }
   // the parked frame becomes the current one (buffer swap; blobs beyond 512 are read here)
   __device__ __forceinline__ void stage(int64_t frame) {
+    const int C = cn();
     float2* t = bxy;
     bxy = bxy_nx;
     bxy_nx = t;
@@ -332,6 +366,7 @@ struct BBState {
   // next_item: lane 0's pull of the NEXT frame from the queue (issued by the caller before this call); it is dropped
   // into misc[MI_NEXT] here, between two barriers that exist anyway, so that every lane can prefetch that frame.
   __device__ void match(int next_item) {
+    const int C = cn();
     __syncthreads();
     int gs_shift = 0;
     while ((1 << gs_shift) < M) gs_shift++;
@@ -577,6 +612,7 @@ struct BBState {
   // group, rem = candidate index; skip = bnl[r]: the block's partial group, rem = block index).  Returns the views.
   template <bool WITH_B>
   __device__ __forceinline__ int group_matrix(int r, uint32_t rem, int skip, double (&B)[10], Packed<CW>& pk) const {
+    const int C = cn();
     const int rc = root_cam[r];
     const uint8_t* nhr = nh + (size_t)r * C;
     const uint8_t* hr = hits + (size_t)r * C * M;
@@ -618,6 +654,7 @@ struct BBState {
   }
 
   __device__ void search(bool bound_tests, const Pre& pre, bool have_pre) {
+    const int C = cn();
     const int nroots = misc[MI_NROOTS];
     int32_t* ctr = &misc[MI_BBCTR];  // queued blocks | their candidates << 10
     const double inf = __builtin_huge_val();
@@ -685,18 +722,26 @@ struct BBState {
     };
     if (!bound_tests && have_pre) park(pre);
     if (bound_tests) {
-      // ---- 1. seeds: the block with the largest s1 (smallest bound) of every root is evaluated first
-      for (uint32_t b0 = 0; b0 < nblocks; b0 += T) {
-        const uint32_t b = b0 + (uint32_t)tid;
-        if (b0 + (uint32_t)(wave * 64) >= nblocks) continue;  // wave-uniform
-        const int r = root_of_block(b0 + (uint32_t)(wave * 64), b < nblocks ? b : nblocks - 1);
+      // ---- 1. seeds: s1 of every block (cached for the tests); per root the block with the largest s1 (smallest
+      // bound) is evaluated first.  (Measured and dropped, round 3: evaluating candidate 0 of every root -- the closest
+      // hit in every camera, usually the true match -- before the seeds, to have bounds for them: 6.2 -> 7.1 ms per
+      // 100 k frames; the sparse extra round costs more than the cheaper seed evaluations return.)
+      for (uint32_t s0 = 0; s0 < nblocks; s0 += T) {
+        const uint32_t b = s0 + (uint32_t)tid;
+        if (s0 + (uint32_t)(wave * 64) >= nblocks) continue;  // wave-uniform
+        const int r = root_of_block(s0 + (uint32_t)(wave * 64), b < nblocks ? b : nblocks - 1);
         if (b < nblocks) {
           const uint32_t gh = b - boff[r];
-          double B[10], tr;
+          double B[10], tr = 0.0;
           Packed<CW> pk;
           const int v = group_matrix<true>(r, gh, bnl[r], B, pk);
-          float s1 = 0.0f;  // a one-view partial group carries no information: any block will do
-          if (v >= 2) s1 = (float)fmin(eigcut_s1_shifted(B, c0, tr), 3e38);
+          double s1d = __builtin_huge_val();  // a one-view partial group carries no information: never dropped, any seed
+          float s1 = 0.0f;
+          if (v >= 2) {
+            s1d = eigcut_s1_shifted(B, c0, tr);
+            s1 = (float)fmin(s1d, 3e38);
+          }
+          if (b < (uint32_t)ncache) bcache[b] = make_float2(__double2float_ru(s1d), __double2float_ru(tr));
           atomicMax(&seedkey[r], ((unsigned long long)__float_as_uint(s1) << 32) | (unsigned long long)(0xFFFFFFFFu - gh));
         }
       }
@@ -753,6 +798,7 @@ struct BBState {
             int v = 0;
 #pragma unroll
             for (int ee = 0; ee < 10; ee++) B[ee] = 0.0;
+#pragma unroll CT > 0 ? CT : 1
             for (int c = 0; c < C; c++) {  // cameras in ascending order: the one canonical rounding of B
               const uint32_t k = pk.get(c);
               if (k != 0xFFu) {
@@ -771,7 +817,10 @@ struct BBState {
               return true;
             };
             const double bound = __longlong_as_double((long long)rbound[r]);
-            solve_and_score<true, true, F32R>(cv, B, v, obs_p, X, e, bound * (double)(2 * v) * (1.0 + 0x1p-40), ec);
+            if constexpr (CT > 0)
+              solve_and_score<true, true, F32R>(CamViewFixed<CT>{cv}, B, v, obs_p, X, e, bound * (double)(2 * v) * (1.0 + 0x1p-40), ec);
+            else
+              solve_and_score<true, true, F32R>(cv, B, v, obs_p, X, e, bound * (double)(2 * v) * (1.0 + 0x1p-40), ec);
 #ifdef MOCAP_DEBUG_EIGCHECK  // self-check build: a candidate whose evaluation was cut short must not beat the bound it was cut against
             if (!(e < inf)) {
               double B2[10], X2[3], e2;
@@ -834,7 +883,12 @@ struct BBState {
           double B[10], tr;
           Packed<CW> pk;
           bool survive = true;
-          if (bound_tests) {
+          if (bound_tests && b < (uint32_t)ncache) {
+            // {s1, trace} from the seed pass, rounded up: a larger s1 or trace only ever keeps a block (safe side)
+            const float2 sc = bcache[b];
+            survive = !dropped(r, (double)sc.x, (double)sc.y);
+            if (survive) group_matrix<false>(r, gh, bnl[r], B, pk);
+          } else if (bound_tests) {
             const int v = group_matrix<true>(r, gh, bnl[r], B, pk);
             if (v >= 2) {
               const double s1 = eigcut_s1_shifted(B, c0, tr);
@@ -901,6 +955,7 @@ struct BBState {
 
   // ---------------------------------------------------------------- phase E
   __device__ void write_point(int64_t frame, int r, double e, uint32_t gl, const double (&X)[3]) const {
+    const int C = cn();
     const size_t o = (size_t)frame * R + outslot[r];
     store_point(p, o, X);  // incl. the fused world-coordinate epilogue (helpers.py:96-103)
     p.err[o] = e;
@@ -929,10 +984,10 @@ struct BBState {
 #define MOCAP_BB_WAVES_PER_EU 4
 #endif
 
-template <bool F32R, int CW>
+template <bool F32R, int CW, int CT>
 __global__ __launch_bounds__(kBBThreads, MOCAP_BB_WAVES_PER_EU) void frame_bb_kernel(FrameArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  BBState<F32R, CW> st(p, smem);
+  BBState<F32R, CW, CT> st(p, smem);
   const int tid = threadIdx.x;
   const FrameQueues& q = p.q;
   int chunk_next = 0, chunk_end = 0;  // lane 0 only: frames of the chunk it pulled last
@@ -949,7 +1004,7 @@ __global__ __launch_bounds__(kBBThreads, MOCAP_BB_WAVES_PER_EU) void frame_bb_ke
   if (tid == 0) st.misc[MI_ITEM] = pull();
   __syncthreads();
   int item = st.misc[MI_ITEM];
-  typename BBState<F32R, CW>::Pre pre = {make_float2(0.f, 0.f), make_float2(0.f, 0.f), 0};
+  typename BBState<F32R, CW, CT>::Pre pre = {make_float2(0.f, 0.f), make_float2(0.f, 0.f), 0};
   if (item >= 0) {
     st.prefetch(item, pre);
     st.park(pre);
@@ -997,10 +1052,15 @@ int frame_bb_wg_per_cu_cap() { return MOCAP_BB_WAVES_PER_EU; }
 hipError_t launch_frame_bb(const FrameArgs& a, int grid, hipStream_t stream) {
   const size_t lds = frame_bb_lds_bytes(a.cv.C, a.M, a.K_max);
   void (*k)(FrameArgs);
-  if (a.cv.C <= 8)
-    k = a.cv.f32_rounding ? frame_bb_kernel<true, 1> : frame_bb_kernel<false, 1>;
+#ifndef MOCAP_BB_NO_CT
+  if (a.cv.C == 8)
+    k = a.cv.f32_rounding ? frame_bb_kernel<true, 1, 8> : frame_bb_kernel<false, 1, 8>;
   else
-    k = a.cv.f32_rounding ? frame_bb_kernel<true, 2> : frame_bb_kernel<false, 2>;
+#endif
+  if (a.cv.C <= 8)
+    k = a.cv.f32_rounding ? frame_bb_kernel<true, 1, 0> : frame_bb_kernel<false, 1, 0>;
+  else
+    k = a.cv.f32_rounding ? frame_bb_kernel<true, 2, 0> : frame_bb_kernel<false, 2, 0>;
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;

@@ -64,6 +64,17 @@ struct LdsCamView {
   __device__ __forceinline__ ctab_t k4(size_t off) const { return as_ctab(K4 + off); }
 };
 
+// CamView with the camera count as a compile-time constant (frame_bb.hip's 8-camera instantiation): the geometry
+// core's loops over the cameras then unroll.
+template <int CT>
+struct CamViewFixed {
+  const CamView& v;
+  static constexpr int C = CT;
+  __device__ __forceinline__ ctab_t pq(size_t off) const { return v.pq(off); }
+  __device__ __forceinline__ ctab_t rt(size_t off) const { return v.rt(off); }
+  __device__ __forceinline__ ctab_t k4(size_t off) const { return v.k4(off); }
+};
+
 // ---- packed symmetric 4x4: (0,0)=0 (0,1)=1 (0,2)=2 (0,3)=3 (1,1)=4 (1,2)=5 (1,3)=6 (2,2)=7 (2,3)=8 (3,3)=9
 __host__ __device__ constexpr int sidx(int i, int j) {
   return i <= j ? (i == 0 ? j : i == 1 ? 3 + j : i == 2 ? 5 + j : 9)
