@@ -45,6 +45,10 @@ namespace mocap {
 
 // register budget: 4 waves per SIMD (<= 128 VGPRs); the LDS footprint at 8 x 16 allows 4 workgroups
 // of 256 lanes per CU, so both limits meet at 16 waves per CU
+// timing experiments only (results invalid): wide frames without the camera-0 pairs (1) / the chain's pairs (2)
+#ifndef MOCAP_WIDE_DEBUG_SKIP
+#define MOCAP_WIDE_DEBUG_SKIP 0
+#endif
 #ifndef MOCAP_FRAME_WAVES_PER_EU
 #define MOCAP_FRAME_WAVES_PER_EU 4
 #endif
@@ -56,13 +60,12 @@ namespace mocap {
 // place from the input batch.  Same code either way: the arrays are reached through pointers.
 struct FrameLayout {
   // byte offsets, computed identically on host (sizes) and device (carving)
-  size_t line, dist, seg_e, seg_x, seg_g, goff, gcnt, outslot, hcount, root_blob, root_cam, claimed, nact,
+  size_t line, dist, seg_e, seg_x, seg_g, goff, gcnt, outslot, root_blob, root_cam, claimed, claimw, nact,
       cnt, misc, rbound, lds_total;                  // always LDS
-  size_t bxy, cxy, hits, dig, nh, act, hb_d, hb_k;   // LDS when narrow, workspace when wide
+  size_t bxy, cxy, hits, dig, nh, act;               // LDS when narrow, workspace when wide
   size_t bt;                                          // table mode: DLT contribution per (camera, blob)
   size_t ws_total;
   int Hs;  // hit-list capacity per (root, camera): M when narrow (no cap), H when wide
-  bool hb_lds;  // wide: hit buffers in LDS
   __host__ __device__ static size_t align(size_t x, size_t a) { return (x + a - 1) / a * a; }
   // table: identical intrinsics and narrow -> the per-lane group column holds blob INDICES (1 byte per camera)
   // and the DLT contribution of every (camera, blob) is tabulated once per frame: [C][M][10] doubles
@@ -82,7 +85,6 @@ struct FrameLayout {
     goff = o;      o += sizeof(uint32_t) * (R + 1);
     gcnt = o;      o += sizeof(uint32_t) * R;
     outslot = o;   o += sizeof(int32_t) * R;
-    hcount = o;    o += wide ? sizeof(int32_t) * R : 0;
     cnt = o;       o += sizeof(int32_t) * C;
     misc = o;      o += sizeof(int32_t) * 8;
     root_blob = o; o += sizeof(uint16_t) * R;
@@ -90,25 +92,20 @@ struct FrameLayout {
     claimed = o;   o += M;
     nact = o;      o += R;
     o = align(o, 16);
-    // wide: the per-root hit buffers of the camera being matched are touched by a serial insertion sort per
-    // root: in LDS when they fit (64 x 256 at H = 16: 55 KB), else in the workspace (re-submits with H = M)
-    hb_lds = wide && o + align(sizeof(double) * (size_t)R * H, 16) + align((size_t)R * H, 16) <= (size_t)150 * 1024;
-    if (hb_lds) {
-      hb_d = o;    o += align(sizeof(double) * (size_t)R * H, 16);
-      hb_k = o;    o += align((size_t)R * H, 16);
-    }
+    // wide: blobs claimed so far per camera, 64 per word (match_wide)
+    o = align(o, 8);
+    claimw = o;    o += wide ? sizeof(unsigned long long) * (size_t)C * ((M + 63) / 64) : 0;
+    o = align(o, 16);
     size_t w = wide ? 0 : o;  // the movable arrays continue in LDS, or start a workspace
     cxy = w;       w += table ? (size_t)C * T : sizeof(float2) * (size_t)C * T;
     w = align(w, 16);
     bt = w;        w += table ? sizeof(double) * 10 * (size_t)C * M : 0;
-    if (!hb_lds) { hb_d = w; w += wide ? sizeof(double) * (size_t)R * H : 0; }
     bxy = w;       w += wide ? 0 : sizeof(float2) * (size_t)C * M;
     nh = w;        w += sizeof(uint16_t) * (size_t)R * C;
     hits = w;      w += (size_t)R * C * Hs;
     w = align(w, 8);  // (the branch-and-bound variant keeps doubles here)
     dig = w;       w += (size_t)C * T;
     act = w;       w += (size_t)R * C;
-    if (!hb_lds) { hb_k = w; w += wide ? (size_t)R * H : 0; }
     w = align(w, 256);
     lds_total = wide ? o : align(w, 16);
     ws_total = wide ? w : 0;
@@ -137,9 +134,7 @@ struct FrameState {
   uint8_t *hits;  // [R][C][M] blob indices of the gated hits, ascending distance (M <= 256)
   uint8_t *dig;   // [C][T]    this lane's odometer digits
   uint8_t *root_cam, *claimed, *act, *nact;  // act [R][C]: cameras of root r with >= 2 hits
-  int32_t *hcount;  // wide: [R] hits found so far for the camera being matched
-  double *hb_d;     // wide: [R][H] unsorted hit distances ...
-  uint8_t *hb_k;    // wide: [R][H] ... and blob indices
+  unsigned long long* claimw;  // wide: [C][ceil(M / 64)] blobs claimed so far (match_wide)
 
   __device__ FrameState(const FrameArgs& p_, unsigned char* smem)
       : p(p_), cv(p_.cv), C(p_.cv.C), M(p_.M), R(p_.K_max), tid(threadIdx.x) {
@@ -154,7 +149,6 @@ struct FrameState {
     goff = (uint32_t*)(smem + L.goff);
     gcnt = (uint32_t*)(smem + L.gcnt);
     outslot = (int32_t*)(smem + L.outslot);
-    hcount = (int32_t*)(smem + L.hcount);
     cnt = (int32_t*)(smem + L.cnt);
     misc = (int32_t*)(smem + L.misc);
     root_blob = (uint16_t*)(smem + L.root_blob);
@@ -171,20 +165,16 @@ struct FrameState {
     dig = (uint8_t*)(big + L.dig) + tid;
     nh = (uint16_t*)(big + L.nh);
     act = (uint8_t*)(big + L.act);
-    hb_d = (double*)((L.hb_lds ? smem : big) + L.hb_d);
-    hb_k = (uint8_t*)((L.hb_lds ? smem : big) + L.hb_k);
+    claimw = (unsigned long long*)(smem + L.claimw);
   }
 
   // ---------------------------------------------------------------- phases A-C
-  // Leaves roots / hit lists / candidate offsets in LDS; returns with all lanes synchronised.
+  // Leaves roots / hit lists / candidate offsets in LDS; returns with all lanes synchronised.  (Narrow frames; wide
+  // frames take match_wide.)
   __device__ void match(int64_t frame, int skip = 0 /* timing experiments: 1 = no table build, 2 = no camera loop */) {
     {
       const float2* src = (const float2*)(p.blobs + (size_t)frame * C * M * 2);
-      if (WIDE) {
-        bxy = const_cast<float2*>(src);  // read in place (L1/L2), never written
-      } else {
-        for (int i = tid; i < C * M; i += T) bxy[i] = src[i];
-      }
+      for (int i = tid; i < C * M; i += T) bxy[i] = src[i];
       if (tid < C) {
         int n = p.counts[(size_t)frame * C + tid];
         cnt[tid] = n < 0 ? 0 : (n > M ? M : n);
@@ -239,7 +229,7 @@ struct FrameState {
     // trips through the whole workgroup, only wave-level ballots
     int gs_shift = 0;
     while ((1 << gs_shift) < M) gs_shift++;
-    const bool fused = !WIDE && gs_shift <= 6;
+    const bool fused = gs_shift <= 6;
 
     for (int i = 1; i < ((skip & 2) ? 1 : C); i++) {
       const int Mi = cnt[i];
@@ -247,10 +237,9 @@ struct FrameState {
       // B1 (wave 0, which also owns B5: no workgroup barrier between B5 of camera i-1 and this):
       // epipolar line of every root in camera i.  cv.computeCorrespondEpilines on a float32
       // point: double math, scale by 1/sqrt(a^2+b^2), float32 result (helpers.py:363-364).
-      if (WIDE) __syncthreads();  // B5 of the previous camera (wave 0) -> B1 on every lane
-      if (WIDE || tid < 64) {
+      if (tid < 64) {
         const int nr = misc[MI_NROOTS];
-        for (int r = tid; r < nr; r += (WIDE ? T : 64)) {
+        for (int r = tid; r < nr; r += 64) {
           const int rc = root_cam[r], rb = root_blob[r];
           ctab_t Fm = as_ctab(cv.F + 9 * ((size_t)rc * C + i));
           const float2 rp = bxy[(size_t)rc * M + rb];
@@ -275,9 +264,8 @@ struct FrameState {
           line[kLineStride * r + 3] = den;
           line[kLineStride * r + 4] = recip_refined(den);  // shared by the M quotients of B2
           nh[(size_t)r * C + i] = 0;
-          if (WIDE) hcount[r] = 0;
         }
-        for (int k = tid; k < M; k += (WIDE ? T : 64)) claimed[k] = 0;
+        for (int k = tid; k < M; k += 64) claimed[k] = 0;
       }
       __syncthreads();
       const int nroots = misc[MI_NROOTS];
@@ -326,66 +314,6 @@ struct FrameState {
             }
           }
           wave_lds_sync();  // dist[] is reused by the next pass
-        }
-      } else if (WIDE) {
-        // wide path: hits are rare among the R x M pairs, so lanes append them to a small per-root
-        // buffer (LDS counter, any order) and one lane per root then orders its few hits by
-        // (distance, index) -- the same total order, whatever order the appends landed in
-        const int GS = 1 << gs_shift;
-        const int k = tid & (GS - 1);
-        const int roots_per_pass = T >> gs_shift;
-        const int H = p.H;
-        double px = 0.0, py = 0.0;
-        if (k < Mi) {
-          px = (double)pts[k].x;
-          py = (double)pts[k].y;
-        }
-        for (int r = tid >> gs_shift; r < nroots; r += roots_per_pass) {
-          if (k < Mi) {
-            const double* ln = line + kLineStride * r;
-            const double d = div_by(fabs(ln[0] * px + ln[1] * py + ln[2]), ln[3], ln[4]);
-            if (d < p.gate_px) {
-              const int pos = atomicAdd(&hcount[r], 1);
-              if (pos < H) {
-                hb_d[(size_t)r * H + pos] = d;
-                hb_k[(size_t)r * H + pos] = (uint8_t)k;
-              }
-            }
-          }
-        }
-        __syncthreads();
-        for (int r = tid; r < nroots; r += T) {
-          int n = hcount[r];
-          if (n > H) {
-            atomicOr(&misc[MI_STATUS], MOCAP_ST_HIT_OVERFLOW_);
-            n = H;
-          }
-          double* hd = hb_d + (size_t)r * H;
-          uint8_t* hk = hb_k + (size_t)r * H;
-          for (int a = 1; a < n; a++) {  // insertion sort, n is a handful
-            const double da = hd[a];
-            const uint8_t ka = hk[a];
-            int b = a - 1;
-            while (b >= 0 && (hd[b] > da || (hd[b] == da && hk[b] > ka))) {
-              hd[b + 1] = hd[b];
-              hk[b + 1] = hk[b];
-              b--;
-            }
-            hd[b + 1] = da;
-            hk[b + 1] = ka;
-          }
-          uint8_t* dst = hits + ((size_t)r * C + i) * Hs;
-          for (int a = 0; a < n; a++) dst[a] = hk[a];
-          nh[(size_t)r * C + i] = (uint16_t)n;
-          if (n > 0) {
-            // removal by value (helpers.py:391): a blob with the closest hit's coordinates has its
-            // distance, so it is one of this root's hits
-            const float2 p0 = pts[hk[0]];
-            for (int a = 0; a < n; a++) {
-              const float2 q = pts[hk[a]];
-              if (q.x == p0.x && q.y == p0.y) claimed[hk[a]] = 1;
-            }
-          }
         }
       } else {
         // generic path (a root's blobs span several waves): same steps through LDS + barriers
@@ -454,7 +382,307 @@ struct FrameState {
     }
     __syncthreads();
 
-    // C: candidate counts per root
+    count_candidates();
+  }
+
+  // ---------------------------------------------------------------- phases A-B, wide frames (round 3)
+  // The reference matches camera after camera (helpers.py:359-406) because a blob no root claims becomes a new root
+  // for the cameras after it; only THAT is sequential.  A root's lines, gates, orders and claims in all the cameras
+  // after its own are independent of everything else, so they are computed the moment the root exists:
+  //   B0   camera-0 roots x cameras 1 .. C-1, all waves, no barrier inside;
+  //   B1   for camera j = 1 .. C-1: wave 0 turns the unclaimed blobs of camera j into roots (helpers.py:402-406);
+  //        if there are any, all waves match THEM against cameras j+1 .. C-1.
+  // (Round 2 ran 63 x [lines | barrier | 4.3 M distances spread as (root, blob) lanes + LDS appends | barrier | one
+  // lane per root sorts | barrier | new roots]: 1.83 ms per 64 x 256 frame, VALU 31 % busy, the rest barrier waits.)
+  // Work unit = one camera i (a wave takes cameras clo + wave, + W, ...): its blobs are read ONCE, coalesced, four per
+  // lane, and stay in registers while the roots [rlo, rhi) are walked.  The roots' epipolar lines in camera i are
+  // computed 64 at a time (one per lane, the expressions of match() phase B1 in the same order) and broadcast one
+  // after the other; a (root, camera) pair then costs ~25 wave instructions for its 256 distances: float32 pre-test
+  //     |fl(a x + b y + c)| <= gate den + E,   E = 2.5 * 2^-24 (2 omax + |c|)  (a rigorous bound on the float32
+  // evaluation: with F32R a, b, c ARE float32 values, helpers.py:364, x, y are float32 input, only the two fused
+  // multiply-adds round; omax = largest coordinate of the frame), and whatever passes is decided by the exact double
+  // expression of helpers.py:373.  The rare hits go through a 64-entry list of the wave in LDS and come out in
+  // (distance, index) order.
+  __device__ void match_pairs_wide(int rlo, int rhi, int clo) {
+    constexpr int W = T / 64;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int H = p.H, MW = (M + 63) / 64;
+    const double om = (double)__int_as_float(misc[MI_OMAX]);
+    double* hbd = line + (size_t)wave * 64;                                  // [64] this wave's hit distances ...
+    uint8_t* hbk = (uint8_t*)(line + (size_t)W * 64) + (size_t)wave * 64;    // ... and blob indices (the `line` array is free in wide frames)
+    for (int i = clo + wave; i < C; i += W) {  // wave-uniform
+      const int Mi = cnt[i];
+      const float2* row = bxy + (size_t)i * M;
+      float2 bl[4];
+      bool ok[4];
+#pragma unroll
+      for (int sg = 0; sg < 4; sg++) {
+        const int k = 64 * sg + lane;
+        ok[sg] = k < Mi;
+        bl[sg] = ok[sg] ? row[k] : make_float2(0.f, 0.f);
+      }
+      for (int rb = rlo; rb < rhi; rb += 64) {
+        const int r = rb + lane;
+        const bool have = r < rhi;
+        double la = 0, lb = 0, lc = 0, lden = 1, lrden = 1;
+        if (have) {
+          // cv.computeCorrespondEpilines on a float32 point: double math, scale by 1/sqrt(a^2+b^2), float32 result
+          // (helpers.py:363-364)
+          const int rc = root_cam[r], rbl = root_blob[r];
+          const double* Fm = cv.F + 9 * ((size_t)rc * C + i);
+          const float2 rp = bxy[(size_t)rc * M + rbl];
+          const double x = (double)rp.x, y = (double)rp.y;
+          double a = Fm[0] * x + Fm[1] * y + Fm[2];
+          double bb = Fm[3] * x + Fm[4] * y + Fm[5];
+          double c = Fm[6] * x + Fm[7] * y + Fm[8];
+          double nu = a * a + bb * bb;
+          nu = nu != 0.0 ? 1.0 / sqrt(nu) : 1.0;
+          a *= nu;
+          bb *= nu;
+          c *= nu;
+          if (F32R) {
+            a = (double)(float)a;
+            bb = (double)(float)bb;
+            c = (double)(float)c;
+          }
+          la = a;
+          lb = bb;
+          lc = c;
+          lden = sqrt(a * a + bb * bb);  // helpers.py:373 divides by it again
+          lrden = recip_refined(lden);
+        }
+        // pre-test threshold, rounded up; +inf (everything goes to the exact test) without the float32 line
+        const float a32 = (float)la, b32 = (float)lb, c32 = (float)lc;
+        float thr = __int_as_float(0x7f800000);
+        if (F32R) thr = __double2float_ru(p.gate_px * lden * (1.0 + 1e-12) + (2.5 * 0x1p-24) * (2.0 * om + fabs(lc)) * (1.0 + 1e-6));
+        int my_nh = 0;
+        // the usual outcome of a (root, camera) pair: ONE blob passes the pre-test (the marker's own blob).  It is handed
+        // to the lane that holds the root's line (its coordinates travel, not the line), and the exact decision is
+        // taken for the batch's 64 roots at once after the loop.
+        float cand_x = 0.f, cand_y = 0.f;
+        int cand_k = -1;
+        const int nb = rhi - rb < 64 ? rhi - rb : 64;
+        for (int q = 0; q < nb; q++) {  // wave-uniform: root rb + q against the camera's blobs
+          const float fa = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a32), q));
+          const float fb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b32), q));
+          const float fc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c32), q));
+          const float ft = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(thr), q));
+          bool pm[4];
+          unsigned long long pmask[4];
+#pragma unroll
+          for (int sg = 0; sg < 4; sg++) {
+            pm[sg] = ok[sg] && fabsf(fmaf(fa, bl[sg].x, fmaf(fb, bl[sg].y, fc))) <= ft;
+            pmask[sg] = __ballot(pm[sg]);
+          }
+          const int npass = __popcll(pmask[0]) + __popcll(pmask[1]) + __popcll(pmask[2]) + __popcll(pmask[3]);
+          if (!npass) continue;
+          if (npass == 1) {
+            float cx, cy;
+            int ck;
+            if (pmask[0]) {
+              const int l1 = __ffsll((long long)pmask[0]) - 1;
+              cx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bl[0].x), l1));
+              cy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bl[0].y), l1));
+              ck = l1;
+            } else if (pmask[1]) {
+              const int l1 = __ffsll((long long)pmask[1]) - 1;
+              cx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bl[1].x), l1));
+              cy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bl[1].y), l1));
+              ck = 64 + l1;
+            } else if (pmask[2]) {
+              const int l1 = __ffsll((long long)pmask[2]) - 1;
+              cx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bl[2].x), l1));
+              cy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bl[2].y), l1));
+              ck = 128 + l1;
+            } else {
+              const int l1 = __ffsll((long long)pmask[3]) - 1;
+              cx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bl[3].x), l1));
+              cy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bl[3].y), l1));
+              ck = 192 + l1;
+            }
+            if (lane == q) {
+              cand_x = cx;
+              cand_y = cy;
+              cand_k = ck;
+            }
+            continue;
+          }
+          // ---- rare: several blobs within reach of the gate; the line in double, the decision of helpers.py:373,375
+          auto bcast = [&](double v) {
+            const long long bits = __double_as_longlong(v);
+            return __longlong_as_double(((long long)__builtin_amdgcn_readlane((int)(bits >> 32), q) << 32) |
+                                        (unsigned int)__builtin_amdgcn_readlane((int)bits, q));
+          };
+          const double qa = bcast(la), qb = bcast(lb), qc = bcast(lc), qden = bcast(lden), qrden = bcast(lrden);
+          double dd[4] = {0.0, 0.0, 0.0, 0.0};
+          bool hit[4] = {false, false, false, false};
+          unsigned long long hmask[4] = {0ull, 0ull, 0ull, 0ull};
+          int nhits = 0;
+#pragma unroll
+          for (int sg = 0; sg < 4; sg++) {
+            if (!__ballot(pm[sg])) continue;  // wave-uniform: usually one segment of the four has a candidate
+            if (pm[sg]) {
+              dd[sg] = div_by(fabs(qa * (double)bl[sg].x + qb * (double)bl[sg].y + qc), qden, qrden);
+              hit[sg] = dd[sg] < p.gate_px;  // strict <, helpers.py:375,383
+            }
+            hmask[sg] = __ballot(hit[sg]);
+            nhits += __popcll(hmask[sg]);
+          }
+          if (!nhits) continue;
+          if (nhits > H) atomicOr(&misc[MI_STATUS], MOCAP_ST_HIT_OVERFLOW_);
+          uint8_t* hl = hits + ((size_t)(rb + q) * C + i) * Hs;
+          if (lane == q) my_nh = nhits < H ? nhits : H;
+          if (nhits == 1) {
+            // the usual case: the one blob inside the gate is the closest hit and claims itself (helpers.py:391)
+#pragma unroll
+            for (int sg = 0; sg < 4; sg++)
+              if (hit[sg]) {
+                hl[0] = (uint8_t)(64 * sg + lane);
+                atomicOr(&claimw[(size_t)i * MW + sg], 1ull << lane);
+              }
+            continue;
+          }
+          // several hits: through the wave's list, out in (distance, blob index) order -- stable where NumPy's default
+          // argsort is not (helpers.py:384; documented deviation)
+          int base = 0;
+#pragma unroll
+          for (int sg = 0; sg < 4; sg++) {
+            if (hit[sg]) {
+              const int pos = base + __popcll(hmask[sg] & ((1ull << lane) - 1ull));
+              if (pos < 64) {
+                hbd[pos] = dd[sg];
+                hbk[pos] = (uint8_t)(64 * sg + lane);
+              }
+            }
+            base += __popcll(hmask[sg]);
+          }
+          const int n = nhits < 64 ? nhits : 64;
+          wave_lds_sync();
+          int k = 0, rank = 0;
+          if (lane < n) {
+            const double d = hbd[lane];
+            k = hbk[lane];
+            for (int m2 = 0; m2 < n; m2++) {
+              const double d2 = hbd[m2];
+              const int k2 = hbk[m2];
+              rank += (d2 < d || (d2 == d && k2 < k)) ? 1 : 0;
+            }
+            if (rank < H) hl[rank] = (uint8_t)k;
+          }
+          // the closest hit's coordinates claim every blob that has them (helpers.py:391): such a blob has the same
+          // distance, so it is among the hits; the coordinates come from the registers that hold the camera's blobs
+          const unsigned long long first = __ballot(lane < n && rank == 0);
+          const int k0 = __builtin_amdgcn_readlane(k, __ffsll((long long)first) - 1);  // wave-uniform
+          float p0x = 0.f, p0y = 0.f;
+#pragma unroll
+          for (int sg = 0; sg < 4; sg++)
+            if ((k0 >> 6) == sg) {
+              p0x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bl[sg].x), k0 & 63));
+              p0y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bl[sg].y), k0 & 63));
+            }
+#pragma unroll
+          for (int sg = 0; sg < 4; sg++) {
+            const unsigned long long cm = __ballot(hit[sg] && bl[sg].x == p0x && bl[sg].y == p0y);
+            if (cm && lane == 0) atomicOr(&claimw[(size_t)i * MW + sg], cm);
+          }
+          wave_lds_sync();  // the list is reused by the next root
+        }
+        if (cand_k >= 0) {  // single candidates: helpers.py:373 in double, strict < (helpers.py:375,383); a lone hit claims itself
+          if (div_by(fabs(la * (double)cand_x + lb * (double)cand_y + lc), lden, lrden) < p.gate_px) {
+            hits[((size_t)r * C + i) * Hs] = (uint8_t)cand_k;
+            atomicOr(&claimw[(size_t)i * MW + (cand_k >> 6)], 1ull << (cand_k & 63));
+            my_nh = 1;
+          }
+        }
+        if (have) nh[(size_t)r * C + i] = (uint16_t)my_nh;
+      }
+    }
+  }
+
+  __device__ void match_wide(int64_t frame) {
+    const int MW = (M + 63) / 64;
+    {
+      bxy = const_cast<float2*>((const float2*)(p.blobs + (size_t)frame * C * M * 2));  // read in place, never written
+      if (tid < C) {
+        int n = p.counts[(size_t)frame * C + tid];
+        cnt[tid] = n < 0 ? 0 : (n > M ? M : n);
+      }
+      for (int i = tid; i < C * MW; i += T) claimw[i] = 0ull;
+      if (tid == 0) {
+        misc[MI_STATUS] = 0;
+        misc[MI_OMAX] = 0;
+      }
+    }
+    __syncthreads();
+    {  // largest coordinate: the float32 pre-test's error bound and EigCut's allowance scale with it
+      float om = 0.0f;
+      for (int i = tid; i < C * M; i += T) {
+        const int c = i / M, k = i - c * M;
+        if (k < cnt[c]) {
+          const float2 v = bxy[i];
+          om = fmaxf(om, fmaxf(fabsf(v.x), fabsf(v.y)));
+        }
+      }
+      if (om > 0.0f) atomicMax(&misc[MI_OMAX], __float_as_int(om));
+    }
+    const int n0 = cnt[0] < R ? cnt[0] : R;
+    {  // roots from camera 0 (helpers.py:349,357)
+      for (int r = tid; r < n0; r += T) {
+        root_cam[r] = 0;
+        root_blob[r] = (uint16_t)r;
+      }
+      if (tid == 0) {
+        misc[MI_NROOTS] = n0;
+        if (cnt[0] > R) misc[MI_STATUS] |= MOCAP_ST_ROOT_OVERFLOW_;
+      }
+    }
+    __syncthreads();
+#if !(MOCAP_WIDE_DEBUG_SKIP & 1)
+    match_pairs_wide(0, n0, 1);
+#endif
+    __syncthreads();
+    int n_roots = n0;
+    for (int j = 1; j < C; j++) {
+      // unclaimed blobs of camera j become new roots, in blob order (helpers.py:402-406); wave 0 compacts
+      if (tid < 64) {
+        const int Mj = cnt[j];
+        int base_root = n_roots;
+        for (int w = 0; w * 64 < Mj; w++) {
+          const int k = 64 * w + tid;
+          const unsigned long long cl = claimw[(size_t)j * MW + w];
+          const bool flag = k < Mj && !((cl >> tid) & 1ull);
+          const unsigned long long mask = __ballot(flag);
+          const int pos = __popcll(mask & ((1ull << tid) - 1ull));
+          if (flag) {
+            const int rr = base_root + pos;
+            if (rr < R) {
+              root_cam[rr] = (uint8_t)j;
+              root_blob[rr] = (uint16_t)k;
+            }
+          }
+          base_root += __popcll(mask);
+        }
+        if (tid == 0) {
+          if (base_root > R) {
+            misc[MI_STATUS] |= MOCAP_ST_ROOT_OVERFLOW_;
+            base_root = R;
+          }
+          misc[MI_NROOTS] = base_root;
+        }
+      }
+      __syncthreads();
+      const int now = misc[MI_NROOTS];
+      if (now > n_roots && j + 1 < C && !(MOCAP_WIDE_DEBUG_SKIP & 2)) {  // workgroup-uniform
+        match_pairs_wide(n_roots, now, j + 1);
+        __syncthreads();
+      }
+      n_roots = now;
+    }
+    count_candidates();
+  }
+
+  // C: candidate counts per root (all lanes; the roots and hit lists are in place and the workgroup is synchronised)
+  __device__ void count_candidates() {
     const int nroots = misc[MI_NROOTS];
     for (int r = tid; r < nroots; r += T) {
       const int rc = root_cam[r];
@@ -479,20 +707,28 @@ struct FrameState {
       gcnt[r] = (views > 1 && !over) ? (uint32_t)total : 0u;  // helpers.py:413-414 drops 1-view roots
     }
     __syncthreads();
-    if (tid == 0) {
-      uint32_t acc = 0;
-      int slot = 0;
-      for (int r = 0; r < nroots; r++) {
-        goff[r] = acc;
-        outslot[r] = gcnt[r] ? slot : -1;
-        slot += gcnt[r] ? 1 : 0;
-        const uint32_t nxt = acc + gcnt[r];
-        if (nxt < acc) misc[MI_STATUS] |= MOCAP_ST_CAND_OVERFLOW_;
-        acc = nxt;
+    if (tid < 64) {  // candidate offsets and output slots: wave scans over the roots, 64 at a time
+      const int lane = tid;
+      unsigned long long carry = 0;
+      int slots = 0;
+      for (int base = 0; base < nroots; base += 64) {
+        const int r = base + lane;
+        const uint32_t g = r < nroots ? gcnt[r] : 0u;
+        const uint32_t incl = wave_inclusive_scan(g, lane);  // (64 x 2^24 < 2^32: a chunk cannot overflow)
+        const unsigned long long nz = __ballot(g != 0u);
+        if (r < nroots) {
+          goff[r] = (uint32_t)carry + incl - g;
+          outslot[r] = g ? slots + __popcll(nz & ((1ull << lane) - 1ull)) : -1;
+        }
+        carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        slots += __popcll(nz);
       }
-      goff[nroots] = acc;
-      misc[MI_NOUT] = slot;
-      misc[MI_G] = misc[MI_STATUS] ? 0 : (int32_t)acc;
+      if (lane == 0) {
+        if (carry >> 32) misc[MI_STATUS] |= MOCAP_ST_CAND_OVERFLOW_;  // 32-bit candidate offsets per frame
+        goff[nroots] = (uint32_t)carry;
+        misc[MI_NOUT] = slots;
+        misc[MI_G] = misc[MI_STATUS] ? 0 : (int32_t)(uint32_t)carry;
+      }
     }
     __syncthreads();
   }
@@ -812,7 +1048,7 @@ __global__ __launch_bounds__(T, MOCAP_FRAME_WAVES_PER_EU) void frame_kernel(Fram
         S = q_load(&q.heavy[4 * h + 2]);
         sl = item - base;
       }
-      st.match(frame);
+      if constexpr (WIDE) st.match_wide(frame); else st.match(frame);
 #ifdef MOCAP_DEBUG_DOUBLE_MATCH  // timing experiments only: what phases A-C cost INSIDE the mix: an extra, possibly
       __syncthreads();             // partial (skip mask = the macro's value) pass before the real one is repeated
       st.match(frame, MOCAP_DEBUG_DOUBLE_MATCH);
@@ -956,7 +1192,7 @@ __global__ __launch_bounds__(T, MOCAP_FRAME_WAVES_PER_EU) void frame_kernel(Fram
 
     if (MODE == MODE_MAIN) {
       const int64_t frame = item;
-      st.match(frame);
+      if constexpr (WIDE) st.match_wide(frame); else st.match(frame);
       const uint32_t G = (uint32_t)st.misc[MI_G];
       // heavy frame: hand its candidate space to the slice pass instead of evaluating here
       if (tid == 0) {
@@ -1004,7 +1240,7 @@ __global__ __launch_bounds__(T, MOCAP_FRAME_WAVES_PER_EU) void frame_kernel(Fram
       const int64_t frame = q.heavy[4 * h + 0];
       const int base = q.heavy[4 * h + 1], S = q.heavy[4 * h + 2];
       const int sl = item - base;
-      st.match(frame);
+      if constexpr (WIDE) st.match_wide(frame); else st.match(frame);
       const uint64_t G = (uint32_t)st.misc[MI_G];
       const uint32_t g_lo = (uint32_t)(G * (uint64_t)sl / S), g_hi = (uint32_t)(G * (uint64_t)(sl + 1) / S);
       if (g_hi > g_lo) st.evaluate(g_lo, g_hi);
@@ -1028,7 +1264,7 @@ __global__ __launch_bounds__(T, MOCAP_FRAME_WAVES_PER_EU) void frame_kernel(Fram
       if (q.heavy[4 * h + 0] < 0) continue;
       const int64_t frame = q.heavy[4 * h + 0];
       const int base = q.heavy[4 * h + 1], S = q.heavy[4 * h + 2];
-      st.match(frame);
+      if constexpr (WIDE) st.match_wide(frame); else st.match(frame);
       st.write_frame_header(frame);
       const int nroots = st.misc[MI_NROOTS];
       for (int r = tid; r < nroots; r += T) {
