@@ -415,7 +415,7 @@ def ba_parity(core):
     from mocap_core import helpers
     out = {}
     gdir = os.path.join(ROOT, "tests", "golden")
-    for name in ("ba_c3_n24", "ba_c4_n60_solved", "ba_c8_n100_solved"):
+    for name in ("ba_c3_n24", "ba_c4_n60_solved", "ba_c6_n80_solved", "ba_c8_n100_solved"):
         path = os.path.join(gdir, name + ".npz")
         if not os.path.exists(path):
             continue
@@ -431,7 +431,7 @@ def ba_parity(core):
             try:
                 poses, info = helpers.bundle_adjustment(synth.obs_to_reference_array(g["obs"]), poses0, None, return_info=True)
             finally:
-                helpers.set_bundle_adjustment_mode("resident")
+                helpers.set_bundle_adjustment_mode(helpers.DEFAULT_BA_MODE)
             R = np.array([np.asarray(p["R"], dtype=np.float64) for p in poses])
             t = np.array([np.asarray(p["t"], dtype=np.float64).reshape(3) for p in poses])
             row[mode] = {"nfev": int(info["nfev"]), "njev": int(info["njev"]), "dR_max": float(np.abs(R - g["R_ba"]).max()),

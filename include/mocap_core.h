@@ -79,7 +79,7 @@ int mocap_set_options(mocap_ctx* ctx, uint32_t flags);
 int mocap_set_tuning(mocap_ctx* ctx, int frame_threads, int heavy_threshold, int slice_size);
 /* Frames whose state does not fit the 160 KB of LDS (e.g. 64 cameras x 256 blobs) run through a
  * "wide" variant that keeps hit lists and per-lane group columns in an HBM workspace and caps the
- * gated hits kept per (root, camera) at hit_cap (default 16, 0 = keep; the reference has no cap:
+ * gated hits kept per (root, camera) at hit_cap (default 32, 0 = keep; the reference has no cap:
  * overflow sets MOCAP_ST_HIT_OVERFLOW and the frame is re-submitted with a larger cap).
  * force_wide != 0 routes every batch through that variant (tests).  Results are identical. */
 int mocap_set_frame_limits(mocap_ctx* ctx, int hit_cap, int force_wide);

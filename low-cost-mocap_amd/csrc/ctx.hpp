@@ -21,7 +21,7 @@ struct mocap_ctx {
   int frame_threads = 0;    // workgroup size of the frame kernel, 0 = automatic (MOCAP_FRAME_THREADS=64|128|256)
   int heavy_threshold = -1; // -1 = automatic; 0 = never split heavy frames (MOCAP_HEAVY_THRESHOLD)
   int slice_size = 0;       // 0 = automatic (MOCAP_SLICE_SIZE)
-  int hit_cap = 16;         // wide frames: hits kept per (root, camera) (mocap_set_frame_limits)
+  int hit_cap = 32;         // wide frames: hits kept per (root, camera) (mocap_set_frame_limits)
   int force_wide = 0;       // route every frame batch through the wide (HBM workspace) variant
   int32_t frame_gen = 0;    // generation of the last frame-path launch (tags the slices it publishes)
   int frame_q_cap = 0;      // W_cap the work-queue buffer was laid out for

@@ -317,43 +317,31 @@ struct BBState {
     return claims;
   }
 
-  // The next frame's blobs and counts travel from HBM into registers while the current frame is searched (the loads
-  // are issued before the search, consumed after it): neither the queue atomic nor the first touch of a frame sits on
-  // the per-frame critical path.  A lane holds blobs tid and tid + 256 (C M <= 512; more are read in stage()).
-  struct Pre {
-    float2 b0, b1;
-    int n;
-  };
-  __device__ __forceinline__ void prefetch(int64_t frame, Pre& q) const {
+  // The next frame's blobs and counts travel from HBM straight into the spare LDS buffer while the current frame is
+  // searched (global_load_lds: no VGPR is held -- a register prefetch was spilled to scratch by the compiler, i.e. went
+  // to HBM and back): neither the queue atomic nor the first touch of a frame sits on the per-frame critical path.
+  // The loads complete before the frame's last barrier (wait_own_stores: vmcnt(0) counts them).
+  __device__ __forceinline__ void prefetch_lds(int64_t frame) const {
     const int C = cn();
-    const float2* src = (const float2*)(p.blobs + (size_t)frame * C * M * 2);
-    const int CM = C * M;
-    q.b0 = tid < CM ? src[tid] : make_float2(0.f, 0.f);
-    q.b1 = tid + T < CM ? src[tid + T] : make_float2(0.f, 0.f);
-    q.n = tid < C ? p.counts[(size_t)frame * C + tid] : 0;
+    const float* src = p.blobs + (size_t)frame * C * M * 2;
+    const int n_dw = C * M * 2;
+    for (int base = wave * 64; base < n_dw; base += T)  // a wave writes 64 consecutive dwords at its LDS base + 4 lane
+      if (base + lane < n_dw)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + base + lane),
+                                         (__attribute__((address_space(3))) void*)((float*)bxy_nx + base), 4, 0, 0);
+    if (wave == 0 && lane < C)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.counts + (size_t)frame * C + lane),
+                                       (__attribute__((address_space(3))) void*)cnt_nx, 4, 0, 0);
   }
-  // registers -> the spare blob buffer.  Called where the search's register pressure is low (after its seed pass): the
-  // prefetched values must not stay live across the candidate evaluation.
-  __device__ __forceinline__ void park(const Pre& q) {
-    const int C = cn();
-    const int CM = C * M;
-    if (tid < CM) bxy_nx[tid] = q.b0;
-    if (tid + T < CM) bxy_nx[tid + T] = q.b1;
-    if (tid < C) cnt_nx[tid] = q.n < 0 ? 0 : (q.n > M ? M : q.n);
-  }
-  // the parked frame becomes the current one (buffer swap; blobs beyond 512 are read here)
+  // the prefetched frame becomes the current one (buffer swap)
   __device__ __forceinline__ void stage(int64_t frame) {
     const int C = cn();
     float2* t = bxy;
     bxy = bxy_nx;
     bxy_nx = t;
-    const int CM = C * M;
-    if (CM > 2 * T) {
-      const float2* src = (const float2*)(p.blobs + (size_t)frame * C * M * 2);
-      for (int i = tid + 2 * T; i < CM; i += T) bxy[i] = src[i];
-    }
     if (tid < C) {
-      cnt[tid] = cnt_nx[tid];
+      const int n = cnt_nx[tid];
+      cnt[tid] = n < 0 ? 0 : (n > M ? M : n);
       claimw[tid] = 0ull;
     }
     if (tid == 0) {
@@ -363,9 +351,9 @@ struct BBState {
   }
 
   // ---------------------------------------------------------------- phases B-C (the frame is staged)
-  // next_item: lane 0's pull of the NEXT frame from the queue (issued by the caller before this call); it is dropped
-  // into misc[MI_NEXT] here, between two barriers that exist anyway, so that every lane can prefetch that frame.
-  __device__ void match(int next_item) {
+  // Also pulls the NEXT frame from the queue into misc[MI_NEXT] (one lane of wave 1, while wave 0 walks the cameras: the
+  // atomic's round trip to L2 is off everybody's critical path), so that every lane can prefetch that frame afterwards.
+  __device__ void match() {
     const int C = cn();
     __syncthreads();
     int gs_shift = 0;
@@ -553,6 +541,10 @@ struct BBState {
         }
       }
       if (om > 0.0f) atomicMax(&misc[MI_OMAX], __float_as_int(om));
+      if (tid == 64) {
+        const int it = q_add(&p.q.counters[QC_NEXT_FRAME], 1);
+        misc[MI_NEXT] = it < p.n_frames ? it : -1;
+      }
     }
     __syncthreads();
 
@@ -581,7 +573,6 @@ struct BBState {
       rbound[r] = kInfBits;
       gcnt[r] = (views > 1 && !over) ? (uint32_t)total : 0u;  // helpers.py:413-414 drops 1-view roots
     }
-    if (tid == 0) misc[MI_NEXT] = next_item;
     __syncthreads();
     if (wave == 0) {  // candidate offsets and output slots: scans over the roots, 64 at a time (sums stay below 2^32: 255 x 2^24)
       uint32_t carry = 0;
@@ -653,7 +644,7 @@ struct BBState {
     return v;
   }
 
-  __device__ void search(bool bound_tests, const Pre& pre, bool have_pre) {
+  __device__ void search(bool bound_tests) {
     const int C = cn();
     const int nroots = misc[MI_NROOTS];
     int32_t* ctr = &misc[MI_BBCTR];  // queued blocks | their candidates << 10
@@ -720,7 +711,6 @@ struct BBState {
       const double limit_adj = fma(1.002, limit, (double)(2 * vf) * ec.o2slack);
       return s1 * fma(2e-12, tr, p.p3max2c * limit_adj) < 1.0;
     };
-    if (!bound_tests && have_pre) park(pre);
     if (bound_tests) {
       // ---- 1. seeds: s1 of every block (cached for the tests); per root the block with the largest s1 (smallest
       // bound) is evaluated first.  (Measured and dropped, round 3: evaluating candidate 0 of every root -- the closest
@@ -745,7 +735,6 @@ struct BBState {
           atomicMax(&seedkey[r], ((unsigned long long)__float_as_uint(s1) << 32) | (unsigned long long)(0xFFFFFFFFu - gh));
         }
       }
-      if (have_pre) park(pre);  // the next frame's blobs have arrived by now: out of the registers before the evaluation rounds
       __syncthreads();
       for (int r = tid; r < nroots; r += T) {
         if (bnb[r]) {
@@ -990,34 +979,24 @@ __global__ __launch_bounds__(kBBThreads, MOCAP_BB_WAVES_PER_EU) void frame_bb_ke
   BBState<F32R, CW, CT> st(p, smem);
   const int tid = threadIdx.x;
   const FrameQueues& q = p.q;
-  int chunk_next = 0, chunk_end = 0;  // lane 0 only: frames of the chunk it pulled last
-  auto pull = [&]() -> int {          // lane 0 only: next frame of the batch, or -1
-    if (chunk_next >= chunk_end) {
-      chunk_next = q_add(&q.counters[QC_NEXT_FRAME], q.frame_chunk);
-      chunk_end = chunk_next + q.frame_chunk;
-    }
-    const int item = chunk_next++;
-    return item < p.n_frames ? item : -1;
-  };
-  // software pipeline over the frames: while frame k is searched, frame k + 1 is already pulled from the queue and on
-  // its way from HBM into registers
-  if (tid == 0) st.misc[MI_ITEM] = pull();
+  // software pipeline over the frames: while frame k is searched, frame k + 1 has been pulled from the queue (one frame
+  // per pull: frames of this size are never cheap enough for the queue atomic to matter) and is on its way from HBM
+  // into the spare LDS buffer
+  if (tid == 0) {
+    const int it = q_add(&q.counters[QC_NEXT_FRAME], 1);
+    st.misc[MI_ITEM] = it < p.n_frames ? it : -1;
+  }
   __syncthreads();
   int item = st.misc[MI_ITEM];
-  typename BBState<F32R, CW, CT>::Pre pre = {make_float2(0.f, 0.f), make_float2(0.f, 0.f), 0};
-  if (item >= 0) {
-    st.prefetch(item, pre);
-    st.park(pre);
-  }
+  if (item >= 0) st.prefetch_lds(item);
+  wait_own_stores();
   __syncthreads();
   while (item >= 0) {
     const int64_t frame = item;
     st.stage(frame);
-    int next_item = -1;
-    if (tid == 0) next_item = pull();  // (the atomic's result is first needed inside match(), a few barriers later)
-    st.match(next_item);
+    st.match();
     const int next = st.misc[MI_NEXT];
-    if (next >= 0) st.prefetch(next, pre);  // in flight during the first part of the search
+    if (next >= 0) st.prefetch_lds(next);  // in flight during the search
     if (tid == 0) {
       const int status = st.misc[MI_STATUS];
       p.n_out[frame] = status ? 0 : st.misc[MI_NOUT];
@@ -1028,7 +1007,7 @@ __global__ __launch_bounds__(kBBThreads, MOCAP_BB_WAVES_PER_EU) void frame_bb_ke
     if (G) {
       // the bound tests pay their fixed cost (seed pass + a test per block) only on frames with enough candidates;
       // smaller frames queue every block -- same evaluation rounds, same result
-      st.search(G >= (uint32_t)p.bb_min_g, pre, next >= 0);
+      st.search(G >= (uint32_t)p.bb_min_g);
       const int nroots = st.misc[MI_NROOTS];
       for (int r = tid; r < nroots; r += kBBThreads) {
         if (st.outslot[r] < 0) continue;
@@ -1036,9 +1015,8 @@ __global__ __launch_bounds__(kBBThreads, MOCAP_BB_WAVES_PER_EU) void frame_bb_ke
         uint32_t gl;
         if (st.root_winner(r, e, gl, X)) st.write_point(frame, r, e, gl, X);
       }
-    } else if (next >= 0) {
-      st.park(pre);
     }
+    wait_own_stores();  // ... and loads: the next frame's blobs are in LDS
     __syncthreads();  // the frame's LDS state is dead: the next one may be staged
     item = next;
   }

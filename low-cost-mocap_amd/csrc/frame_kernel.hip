@@ -60,7 +60,7 @@ namespace mocap {
 // place from the input batch.  Same code either way: the arrays are reached through pointers.
 struct FrameLayout {
   // byte offsets, computed identically on host (sizes) and device (carving)
-  size_t line, dist, seg_e, seg_x, seg_g, goff, gcnt, outslot, root_blob, root_cam, claimed, claimw, nact,
+  size_t line, dist, seg_e, seg_x, seg_g, goff, gcnt, outslot, root_blob, root_cam, claimed, claimw, hl_d, hl_k, nact,
       cnt, misc, rbound, lds_total;                  // always LDS
   size_t bxy, cxy, hits, dig, nh, act;               // LDS when narrow, workspace when wide
   size_t bt;                                          // table mode: DLT contribution per (camera, blob)
@@ -95,6 +95,10 @@ struct FrameLayout {
     // wide: blobs claimed so far per camera, 64 per word (match_wide)
     o = align(o, 8);
     claimw = o;    o += wide ? sizeof(unsigned long long) * (size_t)C * ((M + 63) / 64) : 0;
+    // wide: one list of gated blobs per wave (distance, index) for the (root, camera) pairs with several hits; holds a
+    // whole camera (kMaxBlobs), so a re-submit with an uncapped hit list (H = M) never truncates
+    hl_d = o;      o += wide ? sizeof(double) * (size_t)(T / 64) * kMaxBlobs : 0;
+    hl_k = o;      o += wide ? (size_t)(T / 64) * kMaxBlobs : 0;
     o = align(o, 16);
     size_t w = wide ? 0 : o;  // the movable arrays continue in LDS, or start a workspace
     cxy = w;       w += table ? (size_t)C * T : sizeof(float2) * (size_t)C * T;
@@ -135,6 +139,8 @@ struct FrameState {
   uint8_t *dig;   // [C][T]    this lane's odometer digits
   uint8_t *root_cam, *claimed, *act, *nact;  // act [R][C]: cameras of root r with >= 2 hits
   unsigned long long* claimw;  // wide: [C][ceil(M / 64)] blobs claimed so far (match_wide)
+  double* hl_d;                // wide: [T / 64][kMaxBlobs] a wave's list of gated blobs: distances ...
+  uint8_t* hl_k;               // ... and blob indices
 
   __device__ FrameState(const FrameArgs& p_, unsigned char* smem)
       : p(p_), cv(p_.cv), C(p_.cv.C), M(p_.M), R(p_.K_max), tid(threadIdx.x) {
@@ -166,6 +172,8 @@ struct FrameState {
     nh = (uint16_t*)(big + L.nh);
     act = (uint8_t*)(big + L.act);
     claimw = (unsigned long long*)(smem + L.claimw);
+    hl_d = (double*)(smem + L.hl_d);
+    hl_k = (uint8_t*)(smem + L.hl_k);
   }
 
   // ---------------------------------------------------------------- phases A-C
@@ -408,8 +416,8 @@ struct FrameState {
     const int lane = tid & 63, wave = tid >> 6;
     const int H = p.H, MW = (M + 63) / 64;
     const double om = (double)__int_as_float(misc[MI_OMAX]);
-    double* hbd = line + (size_t)wave * 64;                                  // [64] this wave's hit distances ...
-    uint8_t* hbk = (uint8_t*)(line + (size_t)W * 64) + (size_t)wave * 64;    // ... and blob indices (the `line` array is free in wide frames)
+    double* hbd = hl_d + (size_t)wave * kMaxBlobs;  // this wave's list of gated blobs
+    uint8_t* hbk = hl_k + (size_t)wave * kMaxBlobs;
     for (int i = clo + wave; i < C; i += W) {  // wave-uniform
       const int Mi = cnt[i];
       const float2* row = bxy + (size_t)i * M;
@@ -549,30 +557,33 @@ struct FrameState {
           for (int sg = 0; sg < 4; sg++) {
             if (hit[sg]) {
               const int pos = base + __popcll(hmask[sg] & ((1ull << lane) - 1ull));
-              if (pos < 64) {
-                hbd[pos] = dd[sg];
-                hbk[pos] = (uint8_t)(64 * sg + lane);
-              }
+              hbd[pos] = dd[sg];  // (pos < kMaxBlobs: a camera has no more blobs)
+              hbk[pos] = (uint8_t)(64 * sg + lane);
             }
             base += __popcll(hmask[sg]);
           }
-          const int n = nhits < 64 ? nhits : 64;
+          const int n = nhits;
           wave_lds_sync();
-          int k = 0, rank = 0;
-          if (lane < n) {
-            const double d = hbd[lane];
-            k = hbk[lane];
-            for (int m2 = 0; m2 < n; m2++) {
-              const double d2 = hbd[m2];
-              const int k2 = hbk[m2];
-              rank += (d2 < d || (d2 == d && k2 < k)) ? 1 : 0;
+          int k0 = 0;
+          for (int e0 = 0; e0 < n; e0 += 64) {  // wave-uniform; one pass unless a pair has more than 64 hits
+            const int e = e0 + lane;
+            int rank = -1, k = 0;
+            if (e < n) {
+              const double d = hbd[e];
+              k = hbk[e];
+              rank = 0;
+              for (int m2 = 0; m2 < n; m2++) {
+                const double d2 = hbd[m2];
+                const int k2 = hbk[m2];
+                rank += (d2 < d || (d2 == d && k2 < k)) ? 1 : 0;
+              }
+              if (rank < H) hl[rank] = (uint8_t)k;
             }
-            if (rank < H) hl[rank] = (uint8_t)k;
+            const unsigned long long first = __ballot(rank == 0);
+            if (first) k0 = __builtin_amdgcn_readlane(k, __ffsll((long long)first) - 1);  // wave-uniform
           }
           // the closest hit's coordinates claim every blob that has them (helpers.py:391): such a blob has the same
           // distance, so it is among the hits; the coordinates come from the registers that hold the camera's blobs
-          const unsigned long long first = __ballot(lane < n && rank == 0);
-          const int k0 = __builtin_amdgcn_readlane(k, __ffsll((long long)first) - 1);  // wave-uniform
           float p0x = 0.f, p0y = 0.f;
 #pragma unroll
           for (int sg = 0; sg < 4; sg++)

@@ -112,7 +112,7 @@ class MocapCore:
         self._h = h
         self.device_id = int(device_id)
         self.C = 0
-        self._hit_cap, self._force_wide = 16, False
+        self._hit_cap, self._force_wide = 32, False
 
     def close(self):
         if getattr(self, "_h", None):

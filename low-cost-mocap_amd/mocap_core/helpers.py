@@ -24,12 +24,21 @@ import numpy as np
 
 from . import capi
 
+# Bundle adjustment through the reference's seam (helpers.bundle_adjustment, index.py:272) defaults to the mode that
+# reproduces the reference's poses BIT FOR BIT: its own scipy.optimize.least_squares call, residuals evaluated on the GPU
+# (seconds per calibration; the reference takes minutes).  "resident" -- the whole trust-region loop inside the core,
+# milliseconds, the mode the BA iterations/s metric measures -- lands inside the reference's own run-to-run spread but
+# not inside north_star's 1e-5 on rigs where the reference itself is not reproducible to 1e-5 (8 cameras: the reference
+# moves 1.7e-3 under a 1e-15 nudge of its start vector, resident mode 2.3e-3 from it).  Opt in with
+# set_bundle_adjustment_mode("resident").
+DEFAULT_BA_MODE = "scipy"
+
 _state = {
     "core": None,
     "camera_params": None,   # list of dicts like api/camera-params.json
     "cam_key": None,         # bytes of (K, R, t) currently uploaded
     "lock": threading.Lock(),
-    "ba_mode": "resident",   # "resident" (LM loop in the core) | "scipy" (reference optimizer, GPU residuals)
+    "ba_mode": DEFAULT_BA_MODE,   # "scipy" (reference optimizer, GPU residuals) | "resident" (LM loop in the core)
     "img_key": None,         # (rows, cols, K, dist, rot) of the lens model currently uploaded
     "to_world": None,        # last Cameras.to_world_coords_matrix handed to set_to_world_coords_matrix
 }
@@ -161,7 +170,18 @@ def pack_frame(image_points, M_max=None):
     counts = np.zeros((1, C), dtype=np.int32)
     for c, pts in enumerate(image_points):
         if pts:
-            blobs[0, c, :len(pts)] = np.asarray(pts, dtype=np.float32)
+            exact = np.asarray(pts, dtype=np.float64)
+            as_f32 = exact.astype(np.float32)
+            # The C ABI carries blob coordinates as float32.  The reference measures point-line distances on whatever
+            # image_points holds (helpers.py:367-373: int64 for _find_dot's int() centroids, float64 for floats), so a
+            # coordinate that float32 cannot represent would be silently rounded before the 5 px gate.  Integer
+            # centroids (the reference's own, |x| < 2^24) and float32-valued sub-pixel centroids pass; anything else is
+            # refused rather than rounded.
+            if not np.array_equal(as_f32.astype(np.float64), exact):
+                bad = exact[as_f32.astype(np.float64) != exact][0]
+                raise ValueError(f"image point coordinate {bad!r} (camera {c}) is not representable in float32: the core's "
+                                 "blob arrays are float32 (include/mocap_core.h); round sub-pixel centroids to float32 first")
+            blobs[0, c, :len(pts)] = as_f32
         counts[0, c] = len(pts)
     return blobs, counts
 
@@ -315,8 +335,10 @@ def camera_pose_to_serializable(camera_poses):
 def bundle_adjustment(image_points, camera_poses, socketio, return_info=False):
     """helpers.py:244-290: least_squares(residual_function, x0, loss="cauchy", ftol=1e-2).
 
-    mode "resident" (default): the whole trust-region loop runs in the core (mocap_ba_solve).
-    mode "scipy": the reference's optimizer call verbatim, only the residual evaluations are GPU.
+    mode "scipy" (default): the reference's optimizer call verbatim, only the residual evaluations are GPU -- poses
+    bit-identical to the reference's on the solver goldens.
+    mode "resident": the whole trust-region loop runs in the core (mocap_ba_solve), milliseconds instead of seconds;
+    inside the reference's own reproducibility, see DEFAULT_BA_MODE above.
     `socketio.emit("camera-pose", ...)`: the reference streams one per residual evaluation (helpers.py:274; the UI
     animates the cameras while calibrating, App.tsx:255).  Mode "scipy" does exactly that; mode "resident" has no
     per-evaluation host round trip and emits once per accepted step (1 / (n + 2) as often), then the final poses."""

@@ -398,6 +398,7 @@ def main_ba():
     golden_ba("ba_c4_n40", 4, 40, seed=8, run_solver=False)
     golden_ba("ba_c3_n24", 3, 24, seed=9, run_solver=True)
     golden_ba("ba_c4_n60_solved", 4, 60, seed=16, run_solver=True)
+    golden_ba("ba_c6_n80_solved", 6, 80, seed=18, run_solver=True)        # between the two: where does the reference stop reproducing itself?
     golden_ba("ba_c8_n100_solved", 8, 100, seed=17, run_solver=True)      # ~2-3 min of reference CPU
 
 

@@ -273,7 +273,7 @@ def test_solve_tight_mode_matches_scipy(core, C, N, budget):
         np.testing.assert_allclose(canon(x_gpu), canon(truth), rtol=1e-5, atol=1e-6)
 
 
-SOLVED_GOLDENS = ("ba_c3_n24", "ba_c4_n60_solved", "ba_c8_n100_solved")
+SOLVED_GOLDENS = ("ba_c3_n24", "ba_c4_n60_solved", "ba_c6_n80_solved", "ba_c8_n100_solved")
 
 
 def _reference_mode(core, name, mode):
@@ -287,7 +287,7 @@ def _reference_mode(core, name, mode):
     try:
         poses, info = helpers.bundle_adjustment(synth.obs_to_reference_array(g["obs"]), poses0, None, return_info=True)
     finally:
-        helpers.set_bundle_adjustment_mode("resident")
+        helpers.set_bundle_adjustment_mode(helpers.DEFAULT_BA_MODE)
     R = np.array([np.asarray(p["R"], dtype=np.float64) for p in poses])
     t = np.array([np.asarray(p["t"], dtype=np.float64).reshape(3) for p in poses])
     return g, R, t, info
@@ -375,7 +375,7 @@ def test_helpers_bundle_adjustment_api(core):
         out = helpers.bundle_adjustment(synth.obs_to_reference_array(obs), poses0, Sock())
         assert len(out) == 4 and np.array_equal(out[0]["R"], np.eye(3))
         assert all(np.asarray(p["R"]).shape == (3, 3) and np.asarray(p["t"]).size == 3 for p in out)
-    helpers.set_bundle_adjustment_mode("resident")
+    helpers.set_bundle_adjustment_mode(helpers.DEFAULT_BA_MODE)
     assert Sock.n >= 2            # progress events: tests/test_gpu_boundary.py counts them
 
 

@@ -146,7 +146,7 @@ def test_bundle_adjustment_streams_camera_poses(core):
         out, info = helpers.bundle_adjustment(synth.obs_to_reference_array(obs), poses0, s, return_info=True)
         counts[mode] = (s.n, info)
         np.testing.assert_allclose(np.array(s.last["camera_poses"][1]["R"]), np.asarray(out[1]["R"]), atol=0)
-    helpers.set_bundle_adjustment_mode("resident")
+    helpers.set_bundle_adjustment_mode(helpers.DEFAULT_BA_MODE)
     n_res, info_res = counts["resident"]
     assert n_res == int(info_res["njev"]) - 1 + 1                           # accepted steps + the final emit
     n_sp, info_sp = counts["scipy"]

@@ -222,3 +222,19 @@ def test_record_pack_roundtrip():
     assert rec.shape == (F, mdist.record_bytes(C, K))
     back = mdist.unpack_records(rec, C, K)
     assert all(np.array_equal(back[k], v) for k, v in (("n_out", n_out), ("xyz", xyz), ("err", err), ("corr", corr)))
+
+
+def test_pack_frame_refuses_coordinates_float32_cannot_carry():
+    """helpers.py:367-373 computes distances on image_points as given (int64 / float64); the C ABI's blob arrays are
+    float32.  Integer centroids (the reference's own, helpers.py:153-154) and float32-valued sub-pixel centroids go
+    through unchanged; a float64 coordinate that would be rounded is refused, not silently changed."""
+    import pytest
+    from mocap_core import helpers
+    b, c = helpers.pack_frame([[[12, 250], [319, 0]], [], [[1.5, 2.25]]])
+    assert b.dtype == np.float32 and c.tolist() == [[2, 0, 1]] and b[0, 2, 0].tolist() == [1.5, 2.25]
+    b, _ = helpers.pack_frame([[[float(np.float32(100.1)), 7.0]]])        # a float32 value held in a Python float
+    assert b[0, 0, 0, 0] == np.float32(100.1)
+    with pytest.raises(ValueError, match="float32"):
+        helpers.pack_frame([[[100.1, 7.0]]])                               # 100.1 is not a float32 value
+    with pytest.raises(ValueError, match="float32"):
+        helpers.pack_frame([[[2 ** 24 + 1, 0]]])                           # nor is this integer
