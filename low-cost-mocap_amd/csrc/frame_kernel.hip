@@ -759,6 +759,41 @@ struct FrameState {
     const uint8_t* hr = hits + (size_t)r * C * Hs;
     const float qn = __int_as_float(0x7fc00000);
     uint32_t rem = gl;
+    if constexpr (WIDE) {
+      // wide frames: hit counts, hit lists and blobs sit in device memory (workspace / input batch) -- eight cameras per
+      // step, each of the three dependent reads issued for all eight before any is used (one round trip per step and
+      // stage instead of one per camera and stage: 24 instead of 192 at 64 cameras)
+      for (int c0 = 0; c0 < C; c0 += 8) {
+        uint32_t n[8], dg[8];
+        uint16_t sl[8];
+        float2 ob[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) n[u] = (c0 + u < C && c0 + u > rc) ? nhr[c0 + u] : 0u;
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          dg[u] = 0;
+          if (n[u] && !FIRST) {
+            uint32_t qd;
+            divmod_small(rem, n[u], qd, dg[u]);
+            rem = qd;
+          }
+        }
+        uint8_t hv[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) hv[u] = n[u] ? hr[(size_t)(c0 + u) * Hs + dg[u]] : (uint8_t)0;
+#pragma unroll
+        for (int u = 0; u < 8; u++) sl[u] = (c0 + u == rc) ? rb : (n[u] ? (uint16_t)hv[u] : kNone);
+#pragma unroll
+        for (int u = 0; u < 8; u++) ob[u] = (c0 + u < C && sl[u] != kNone) ? bxy[(size_t)(c0 + u) * M + sl[u]] : make_float2(qn, qn);
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+          if (c0 + u < C) {
+            dig[(size_t)(c0 + u) * T] = (uint8_t)dg[u];
+            cxy[(size_t)(c0 + u) * T] = ob[u];
+          }
+      }
+      return;
+    }
     for (int c = 0; c < C; c++) {
       uint16_t s = kNone;
       uint32_t dgt = 0;
@@ -865,7 +900,7 @@ struct FrameState {
         if constexpr (TABLE)
           triangulate_and_score_tab<true, F32R>(cv, contrib, obs_ix, X, e, bound, ec);
         else
-          triangulate_and_score<UNIFORM_K, true, F32R>(cv, obs, obs, X, e, bound, ec);
+          triangulate_and_score<UNIFORM_K, true, F32R, (WIDE ? 4 : 1)>(cv, obs, obs, X, e, bound, ec);
 #ifdef MOCAP_DEBUG_EIGCHECK  // self-check of the cut-offs: a group that was cut must not beat the bound it was cut against
         if (!(e < inf)) {
           double X2[3], e2;

@@ -517,18 +517,36 @@ __device__ __forceinline__ void score_point(const View& cv, int v, Obs2&& obs2, 
   err = (seq <= limit) ? (pw ? spw : seq) / (double)(2 * v) : __builtin_huge_val();
 }
 
-template <bool UNIFORM_K, bool PAIRWISE, bool F32R, class View, class Obs1, class Obs2>
+// BATCH > 1: the observations of BATCH cameras are fetched before any of them is used -- for callers whose obs1 is a
+// read of device memory (wide frames keep a lane's group in an HBM-resident column: one dependent round trip per camera
+// otherwise); the views are still accumulated in camera order, so the result is the same to the bit.
+template <bool UNIFORM_K, bool PAIRWISE, bool F32R, int BATCH = 1, class View, class Obs1, class Obs2>
 __device__ __forceinline__ int triangulate_and_score(const View& cv, Obs1&& obs1, Obs2&& obs2,
                                                      double (&X)[3], double& err,
                                                      double limit_e = __builtin_huge_val(), const EigCut& ec = EigCut{}) {
   const int C = cv.C;
   double B[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   int v = 0;
-  for (int c = 0; c < C; c++) {
-    double x, y;
-    if (obs1(c, x, y)) {
-      dlt_accumulate(B, cv.pq(UNIFORM_K ? (size_t)12 * c : 12 * ((size_t)v * C + c)), x, y);
-      v++;
+  if constexpr (BATCH > 1) {
+    for (int c0 = 0; c0 < C; c0 += BATCH) {
+      double xs[BATCH], ys[BATCH];
+      bool on[BATCH];
+#pragma unroll
+      for (int u = 0; u < BATCH; u++) on[u] = c0 + u < C && obs1(c0 + u, xs[u], ys[u]);
+#pragma unroll
+      for (int u = 0; u < BATCH; u++)
+        if (on[u]) {
+          dlt_accumulate(B, cv.pq(UNIFORM_K ? (size_t)12 * (c0 + u) : 12 * ((size_t)v * C + (c0 + u))), xs[u], ys[u]);
+          v++;
+        }
+    }
+  } else {
+    for (int c = 0; c < C; c++) {
+      double x, y;
+      if (obs1(c, x, y)) {
+        dlt_accumulate(B, cv.pq(UNIFORM_K ? (size_t)12 * c : 12 * ((size_t)v * C + c)), x, y);
+        v++;
+      }
     }
   }
   if (v <= 1) return v;  // helpers.py:300

@@ -146,6 +146,15 @@ def test_half_the_blobs_missing(searchers):
     _check(searchers, rig, blobs, counts, K_max=64)
 
 
+@pytest.mark.parametrize("C,M,K_max", [(2, 20, 40), (3, 16, 48), (2, 64, 128), (5, 33, 200)])
+def test_few_cameras_many_blobs(searchers, C, M, K_max):
+    """Two cameras (no chain at all: a root of camera 1 has nothing after it), blob counts that are not powers of two,
+    a full wave of blobs per camera, root capacities up to 200."""
+    rig = synth.ring_rig(C)
+    blobs, counts, _ = synth.make_blob_stream(rig, 150, M, seed=330 + C + M)
+    _check(searchers, rig, blobs, counts, K_max=K_max, oracle_frames=15)
+
+
 @pytest.mark.parametrize("C,M", [(12, 8), (16, 6), (9, 10)])
 def test_more_than_eight_cameras(searchers, C, M):
     """Groups of more than 8 cameras carry their blob indices in two 64-bit words (frame_bb_kernel<CW=2>)."""
