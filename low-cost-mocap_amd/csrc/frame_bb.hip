@@ -125,7 +125,7 @@ static size_t frame_bb_lds_bytes_min(int C, int M, int R) {
 bool frame_bb_fits(int C, int M, int R) {
   // blob indices and root numbers are bytes (0xFF = none); a (root, blob) group is at most one wave; the expanded
   // candidate list of one evaluation round is counted in 22 bits (FrameArgs::bb_pl is lowered by the host if needed)
-  return C >= 2 && C <= 16 && M >= 1 && M <= 64 && R >= 1 && R <= 255 && frame_bb_lds_bytes_min(C, M, R) <= (size_t)64 * 1024;
+  return C >= 2 && C <= 16 && M >= 1 && M <= 64 && R >= 1 && R <= 255 && frame_bb_lds_bytes_min(C, M, R) <= (size_t)128 * 1024;
 }
 
 // blob indices of one (partial) group: one byte per camera, 0xFF = the camera is open or not in the group
