@@ -5,30 +5,36 @@
 // like frame_kernel.hip does (which keeps the general case: per-camera intrinsics, wide frames, tiny frames, and
 // the exhaustive walk every result of this file is tested against, MOCAP_EVAL_BB=0).
 //
-// What is different from frame_kernel.hip, and why (round 3):
+// What is different from frame_kernel.hip, and why (round 3; measurements in DESIGN.md 3.1c):
 //  * its own kernel and LDS layout.  The round-2 search lived inside the all-in-one kernel (match + odometer walk +
-//    search + slice merge in one function: 128 VGPRs with 18 spilled, 217 SGPR spills) and borrowed its arrays from
-//    the odometer walk, which capped it at K_max <= 48, C <= 8.  Here: C <= 16 (blob indices of a group in one or two
-//    64-bit words), any K_max <= 255 that fits LDS (the reference seam's default K_max = min(C M, 64) included).
+//    search + slice merge in one function: 128 VGPRs with 18 spilled) and borrowed its arrays from the odometer walk,
+//    which capped it at K_max <= 48, C <= 8.  Here: C <= 16 (blob indices of a group in one or two 64-bit words), any
+//    K_max <= 255 that fits LDS -- the reference seam's default K_max = min(C M, 64) and the re-submit's C M included.
 //  * phase B without the per-camera barrier chain.  The reference matches camera after camera (helpers.py:359-406)
 //    because a blob no root claims becomes a new root for the cameras after it.  Only THAT is sequential: the roots of
 //    camera 0 exist from the start, their lines, gates, orders and claims in all C - 1 other cameras are independent
-//    of each other -> one barrier-free parallel pass over (root, camera) pairs on all four waves.  What remains is a
-//    short chain over the cameras that involves only the roots created on the way (a few per frame): one wave, no
-//    workgroup barriers, wave-level ballots.  (Round 2: 7 x [lines | barrier | gate-rank-claim | barrier | new roots]
-//    = 19 us per frame = 29 % of the kernel, most of it three waves waiting for one.)
-//  * one evaluation path: a frame below the search threshold queues all its blocks unconditionally (no seed pass, no
-//    bound tests) and takes the same evaluation rounds -- no second copy of the geometry core in the kernel.
+//    of each other -> one barrier-free pass over (root, camera) pairs.  What remains is a short chain over the cameras
+//    that involves only the roots created on the way (a few per frame): one wave, state in registers, ballots.
+//  * written for instruction issue, which is what binds it (PMC: the SIMDs issue an instruction in ~90-100 % of
+//    their cycles, 40 % of them scalar / branch / LDS): one lane per (root, camera) pair with the camera's blobs walked
+//    serially instead of a lane per (pair, blob); an instantiation with the camera count at compile time (8); the
+//    blocks' bounds cached between seed and test pass; branch-free accumulation of the DLT matrix.
+//  * a software pipeline over the frames: frame k + 1 is pulled from the queue and fetched straight into a spare LDS
+//    buffer (global_load_lds, no registers) while frame k is searched.
+//  * one evaluation path: a frame below the search threshold (MOCAP_BB_MIN_G, default 0 = never) queues all its blocks
+//    unconditionally and takes the same evaluation rounds -- no second copy of the geometry core in the kernel.
 //
 // Phases per frame (256 lanes = 4 waves):
-//   A   blobs / counts -> LDS; largest coordinate (float32 allowance of the bounds)
-//   B0  roots of camera 0; every (camera-0 root, camera) pair: epipolar line (helpers.py:362-364), point-line
-//       distances (helpers.py:373), 5 px gate + stable (distance, index) order (helpers.py:375-385), claim of the
-//       closest hit BY VALUE (helpers.py:391) -- lanes = (pair, blob), groups of 2^ceil(log2 M) lanes, ballots only
-//   B1  wave 0: for camera i = 1 .. C-1: the roots created at cameras < i against camera i (same code), then the
-//       unclaimed blobs of camera i become roots (helpers.py:402-406); meanwhile waves 1-3 tabulate the DLT
-//       contribution of every blob (mocap_device.hpp dlt_contribution)
-//   C   per-root candidate counts (helpers.py:394-400), offsets, output slots
+//   A   the prefetched frame becomes the current one (buffer swap)
+//   B0  roots of camera 0; every (camera-0 root, camera) pair on its own lane: epipolar line (helpers.py:362-364),
+//       the camera's blobs walked serially -- point-line distance (helpers.py:373), 5 px gate (helpers.py:375,383), hits
+//       as a bit mask, written in stable (distance, index) order by repeated minimum (helpers.py:384), claim of the
+//       closest hit BY VALUE (helpers.py:391) as a mask; speculative lines of every blob that might become a root
+//   B1  wave 0: for camera i = 1 .. C-1: the roots created at cameras < i against camera i (lanes = (root, blob) groups
+//       of 2^ceil(log2 M), ballots), then the unclaimed blobs of camera i become roots (helpers.py:402-406); meanwhile
+//       waves 1-3 tabulate the DLT contribution of every blob (mocap_device.hpp dlt_contribution), one lane pulls the
+//       next frame from the queue
+//   C   per-root candidate counts (helpers.py:394-400), offsets, output slots (wave scans)
 //   D   branch and bound over blocks of the Cartesian product: seeds, block tests, evaluation of the
 //       survivors' candidates spread over all lanes; per (wave, root) slot = lexicographic minimum of (error bits,
 //       candidate index) = np.argmin's first minimum (helpers.py:418) whatever the evaluation order
@@ -49,9 +55,9 @@ constexpr int kBBThreads = 256;
 constexpr int kBBWaves = kBBThreads / 64;
 constexpr int kBBRecs = kBBThreads + 64;  // surviving blocks queued between two evaluation rounds (flush above 64)
 
-// LDS carving, identical on host (size) and device (pointers).  Arrays that are live only while matching (none at
-// M <= 64: gate / order / claim run in registers and ballots) could share the search's region; the search's own
-// arrays (block records, result slots, per-root block bookkeeping) are laid out behind the persistent frame state.
+// LDS carving, identical on host (size) and device (pointers): the frame's persistent state (blobs, per-blob DLT table,
+// roots, hit lists), the search's arrays (block records, result slots -- dead while matching, which keeps its speculative
+// lines there), the spare blob buffer of the frame pipeline and the cache of block bounds.
 struct BBLayout {
   size_t bxy, bxy_nx, cnt_nx, bt, rbound, seedkey, slot_key, slot_x, claimw, recs, rpk, scr, scr_bytes, goff, gcnt, outslot, boff, bnb, seedgh, slot_g, cnt,
       misc, bpl, nh, hits, act, root_blob, root_cam, nact, bnl, bv, bcache, total;

@@ -13,6 +13,9 @@
 //        B3 rank-by-counting sort of the gated hits (helpers.py:375-385), stable (distance, index)
 //        B4 mark blobs equal (by value) to a root's closest hit (helpers.py:391)
 //        B5 ballot-compaction of the unclaimed blobs into new roots (helpers.py:402-406)
+//      (wide frames -- state beyond LDS, 1 024 lanes -- take match_wide instead: camera-0 roots against all cameras
+//      in one barrier-free pass, then a chain over the cameras that involves only the roots created on the way;
+//      realistic rigs with identical plain intrinsics never come here: csrc/frame_bb.hip)
 //   C  per-root candidate counts (Cartesian product sizes, helpers.py:394-400), offsets
 //   D  a range [g_lo, g_hi) of the flat candidate space is split into T contiguous runs; each lane
 //      walks its run with a mixed-radix odometer (only the digits that change are re-read), keeps
