@@ -18,7 +18,7 @@
 //  * written for instruction issue, which is what binds it (PMC: the SIMDs issue an instruction in ~90-100 % of
 //    their cycles, 40 % of them scalar / branch / LDS): one lane per (root, camera) pair with the camera's blobs walked
 //    serially instead of a lane per (pair, blob); an instantiation with the camera count at compile time (8); the
-//    blocks' bounds cached between seed and test pass; branch-free accumulation of the DLT matrix.
+//    blocks' bounds cached between seed and test pass.
 //  * a software pipeline over the frames: frame k + 1 is pulled from the queue and fetched straight into a spare LDS
 //    buffer (global_load_lds, no registers) while frame k is searched.
 //  * one evaluation path: a frame below the search threshold (MOCAP_BB_MIN_G, default 0 = never) queues all its blocks
@@ -71,7 +71,7 @@ struct BBLayout {
       o += bytes;
       return at;
     };
-    bt = take(sizeof(double) * 10 * ((size_t)C * M + 1), 16);  // DLT contribution per (camera, blob): five b128 reads; + one row of zeros
+    bt = take(sizeof(double) * 10 * (size_t)C * M, 16);      // DLT contribution per (camera, blob): five b128 reads
     bxy = take(sizeof(float2) * (size_t)C * M, 8);
     bxy_nx = take(sizeof(float2) * (size_t)C * M, 8);  // the NEXT frame's blobs, parked here while this one is searched
     cnt_nx = take(4 * (size_t)C, 4);
@@ -795,14 +795,13 @@ struct BBState {
             for (int ee = 0; ee < 10; ee++) B[ee] = 0.0;
 #pragma unroll CT > 0 ? CT : 1
             for (int c = 0; c < C; c++) {  // cameras in ascending order: the one canonical rounding of B
-              // no branch per camera: a camera that is not in the group adds the table's row of zeros (x + (+0.0) = x for
-              // every x that can occur: the sums start at +0.0, so they are never -0.0)
               const uint32_t k = pk.get(c);
-              const bool on = k != 0xFFu;
-              const double* t = bt + (on ? (size_t)c * M + k : (size_t)C * M) * 10;
+              if (k != 0xFFu) {
+                const double* t = bt + ((size_t)c * M + k) * 10;
 #pragma unroll
-              for (int ee = 0; ee < 10; ee++) B[ee] = B[ee] + t[ee];
-              v += on ? 1 : 0;
+                for (int ee = 0; ee < 10; ee++) B[ee] = B[ee] + t[ee];
+                v++;
+              }
             }
             auto obs_p = [&](int c, double& x, double& y) -> bool {
               const uint32_t k = pk.get(c);
@@ -993,7 +992,6 @@ __global__ __launch_bounds__(kBBThreads, MOCAP_BB_WAVES_PER_EU) void frame_bb_ke
     const int it = q_add(&q.counters[QC_NEXT_FRAME], 1);
     st.misc[MI_ITEM] = it < p.n_frames ? it : -1;
   }
-  if (tid < 10) st.bt[(size_t)st.cn() * st.M * 10 + tid] = 0.0;  // the row of zeros of the contribution table
   __syncthreads();
   int item = st.misc[MI_ITEM];
   if (item >= 0) st.prefetch_lds(item);
