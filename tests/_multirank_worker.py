@@ -1,0 +1,69 @@
+"""Worker of tests/test_gpu_multirank.py: one rank of a frame-sharded run whose ranks share ONE GPU (gloo; RCCL refuses
+two ranks on a device).  Every rank runs the frame kernel on its contiguous shard, compacts its tracks on the device
+and takes part in the count-first point-to-point exchange; rank 0 also runs the whole batch alone and compares the
+gathered payload with it bit for bit."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "low-cost-mocap_amd")]
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+from mocap_core import capi, dist as mdist, synth  # noqa: E402
+
+
+def run_shard(core, dev, blobs, counts, K):
+    F, C, M, _ = blobs.shape
+    d_b, d_c = torch.from_numpy(blobs).to(dev), torch.from_numpy(counts).to(dev)
+    out = dict(xyz=torch.empty((F, K, 3), dtype=torch.float64, device=dev), err=torch.empty((F, K), dtype=torch.float64, device=dev),
+               corr=torch.empty((F, K, C), dtype=torch.int16, device=dev), n_out=torch.zeros(F, dtype=torch.int32, device=dev),
+               status=torch.zeros(F, dtype=torch.int32, device=dev))
+    core.match_triangulate_dev(F, M, d_b.data_ptr(), d_c.data_ptr(), 5.0, K, 1 << 20, out["xyz"].data_ptr(), out["err"].data_ptr(),
+                               out["corr"].data_ptr(), out["n_out"].data_ptr(), out["status"].data_ptr())
+    return out
+
+
+def main():
+    rank, _, world = mdist.init_process_group(backend="gloo")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    C, M, K, F = 8, 16, 48, 1003                          # 1003 frames over the ranks: uneven shards
+    rig = synth.ring_rig(C)
+    blobs, counts, _ = synth.make_blob_stream(rig, F, M, seed=77)
+    core = capi.MocapCore(0)
+    core.set_cameras(rig["K"], rig["R"], rig["t"])
+    stream = torch.cuda.current_stream(dev)
+    core.set_stream(stream.cuda_stream)
+    lo, hi = mdist.shard_bounds(F, rank, world)
+    frames_per_rank = [b - a for a, b in (mdist.shard_bounds(F, r, world) for r in range(world))]
+    comp = mdist.TrackCompactor(core, hi - lo, K, C, dev)
+    handles = []
+    for step in range(3):                                  # three exchanges, two of them in flight: buffers are reused
+        mine = run_shard(core, dev, blobs[lo:hi], counts[lo:hi], K)
+        i = comp.compact(mine["n_out"], mine["xyz"], mine["err"], mine["corr"], stream)
+        n = comp.count(i)
+        handles.append(comp.attach(i, mdist.gather_compact_async(comp.n_out[i], comp.records[i], n, frames_per_rank, dst=0)))
+    results = [h.result() for h in handles]
+    if rank == 0:
+        whole = run_shard(core, dev, blobs, counts, K)
+        torch.cuda.synchronize(dev)
+        assert core.last_frame_kernel().startswith("frame_bb_kernel")
+        base = {k: v.cpu().numpy() for k, v in whole.items()}
+        assert not base["status"].any()
+        valid = np.arange(K)[None, :] < base["n_out"][:, None]
+        for n_all, r_all in results:
+            got = mdist.unpack_compact(n_all.cpu().numpy(), r_all.cpu().numpy(), C, K)
+            assert np.array_equal(got["n_out"], base["n_out"])
+            for key in ("xyz", "err", "corr"):
+                assert np.array_equal(got[key][valid], base[key][valid]), key
+        print(f"MULTIRANK OK world {world} frames {F} shards {frames_per_rank} records {int(base['n_out'].sum())}", flush=True)
+    else:
+        assert all(r is None for r in results)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
