@@ -688,7 +688,8 @@ def main():
     n_out = d_nout.cpu().numpy()
     status = d_status.cpu().numpy()
     n_cand = d_ncand.cpu().numpy()
-    local = torch.tensor([float(n_out.sum()), elapsed, float(status.astype(bool).sum())], dtype=torch.float64, device=dev)
+    local = torch.tensor([float(n_out.sum()), elapsed, float(status.astype(bool).sum()), float((status & 1).astype(bool).sum()),
+                          float((status & 2).astype(bool).sum()), float((status & 4).astype(bool).sum())], dtype=torch.float64, device=dev)
     if world > 1:
         allv = [torch.zeros_like(local) for _ in range(world)]
         dist.all_gather(allv, local)
@@ -721,6 +722,10 @@ def main():
                        "parallelism": f"frame-shard x{world}", "frames_per_s": F * world * args.steps / t_max,
                        "markers_per_frame": total_markers / (F * world),
                        "candidates_per_frame": float(n_cand.mean()), "overflow_frames": int(allv[:, 2].sum()),
+                       "overflow_by_cap": {"roots_K_max": int(allv[:, 3].sum()), "candidates_G_cap": int(allv[:, 4].sum()),
+                                           "hits_per_root_and_camera": int(allv[:, 5].sum()),
+                                           "note": "frames whose status bit is set leave the kernel empty and are re-submitted with "
+                                                   "larger caps by match_triangulate_auto in the product path"},
                        "exchange": ({"format": "compact records (32 + 2C bytes per valid point) + n_out per frame, count-first "
                                                "point-to-point gather on rank 0",
                                      "bytes_per_rank_per_step": exchanged["bytes"] / max(args.steps, 1),
