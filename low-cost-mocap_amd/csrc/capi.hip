@@ -502,8 +502,18 @@ static int match_dev_locked(mocap_ctx* ctx, int64_t n_frames, int M_max, const f
   const int hit_cap = ctx->hit_cap < 1 ? 1 : (ctx->hit_cap > M_max ? M_max : ctx->hit_cap);
   // (a narrow frame with identical intrinsics keeps blob indices in one byte with 0xFF = none: 256 slots go wide)
   bool wide = ctx->force_wide != 0 || (M_max > 255 && ctx->cv.uniformK);
+  // The realistic rigs go to their own kernel (csrc/frame_bb.hip: exact branch and bound): identical plain intrinsics
+  // (the eigenvalue bounds need K = [[fx,0,cx],[0,fy,cy],[0,0,1]]), <= 16 cameras, <= 64 blobs per camera, <= 255 roots,
+  // frames big enough for a 256-lane workgroup.  Everything else -- and MOCAP_EVAL_BB=0 -- takes the exhaustive walk.
+  // (Decided before narrow / wide: its layout has no odometer columns and fits where the general narrow one does not.)
+  const bool use_bb = ctx->eval_bb && !wide && ctx->cv.uniformK && ctx->prune && ctx->eigcut && ctx->p3max2 > 0.0 && ctx->p3max2c > 0.0 &&
+                      (ctx->frame_threads == 0 || ctx->frame_threads == 256) && ctx->C * M_max > 32 && ctx->frame_launches != 3 &&
+                      frame_bb_fits(ctx->C, M_max, K_max);
   size_t lds = 0;
-  if (!wide) {
+  if (use_bb) {
+    T = 256;
+    lds = frame_bb_lds_bytes(ctx->C, M_max, K_max);
+  } else if (!wide) {
     lds = frame_lds_bytes(ctx->C, M_max, K_max, T, hit_cap, false, ctx->cv.uniformK != 0);
     while (lds > 160 * 1024 && T > 64) {
       T /= 2;
@@ -524,12 +534,6 @@ static int match_dev_locked(mocap_ctx* ctx, int64_t n_frames, int M_max, const f
   a.prune = ctx->prune;
   a.p3max2 = ctx->prune && ctx->eigcut ? ctx->p3max2 : 0.0;
   if (!wide && ctx->frame_threads == 0 && T == 64) a.p3max2 = 0.0;  // tiny frames (a handful of candidates): the cut-offs cost more than they save
-  // The realistic rigs go to their own kernel (csrc/frame_bb.hip: exact branch and bound): identical plain intrinsics
-  // (the eigenvalue bounds need K = [[fx,0,cx],[0,fy,cy],[0,0,1]]), <= 16 cameras, <= 64 blobs per camera, <= 255 roots,
-  // frames big enough for a 256-lane workgroup.  Everything else -- and MOCAP_EVAL_BB=0 -- takes the exhaustive walk.
-  const bool use_bb = ctx->eval_bb && !wide && ctx->cv.uniformK && a.p3max2 > 0.0 && ctx->p3max2c > 0.0 &&
-                      (ctx->frame_threads == 0 || ctx->frame_threads == 256) && ctx->C * M_max > 32 && ctx->frame_launches != 3 &&
-                      frame_bb_fits(ctx->C, M_max, K_max);
   a.eval_bb = use_bb ? 1 : 0;
   a.bb_pl = ctx->bb_pl;
   for (int i = 0; i < 3; i++) a.bb_c0[i] = ctx->eig_c0[i];
@@ -537,10 +541,6 @@ static int match_dev_locked(mocap_ctx* ctx, int64_t n_frames, int M_max, const f
   a.bb_flush = ctx->bb_flush > 0 ? ctx->bb_flush : 256;
   a.bb_min_g = ctx->bb_min_g;
   while (a.bb_pl > 1 && (size_t)a.bb_pl * M_max * 2 * 256 >= ((size_t)1 << 22)) a.bb_pl /= 2;  // expanded-list counter: 22 bits
-  if (use_bb) {
-    T = 256;
-    lds = frame_bb_lds_bytes(ctx->C, M_max, K_max);
-  }
   a.ws = nullptr;
   a.ws_stride = 0;
   // persistent grid: enough workgroups to fill every CU at the LDS-limited occupancy

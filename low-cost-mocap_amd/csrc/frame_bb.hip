@@ -71,10 +71,11 @@ struct BBLayout {
       o += bytes;
       return at;
     };
-    bt = take(sizeof(double) * 10 * (size_t)C * M, 16);      // DLT contribution per (camera, blob): five b128 reads
-    bxy = take(sizeof(float2) * (size_t)C * M, 8);
-    bxy_nx = take(sizeof(float2) * (size_t)C * M, 8);  // the NEXT frame's blobs, parked here while this one is searched
+    // the two blob buffers come first: global_load_lds addresses LDS through M0, keep its targets in the low 64 KB
+    bxy = take(sizeof(float2) * (size_t)C * M, 16);
+    bxy_nx = take(sizeof(float2) * (size_t)C * M, 16);  // the NEXT frame's blobs land here while this one is searched
     cnt_nx = take(4 * (size_t)C, 4);
+    bt = take(sizeof(double) * 10 * (size_t)C * M, 16);      // DLT contribution per (camera, blob): five b128 reads
     rbound = take(8 * (size_t)R, 8);
     claimw = take(8 * (size_t)C, 8);
     // the search's block records and result slots: dead while matching -> phase B keeps the speculative epipolar

@@ -155,6 +155,15 @@ def test_few_cameras_many_blobs(searchers, C, M, K_max):
     _check(searchers, rig, blobs, counts, K_max=K_max, oracle_frames=15)
 
 
+def test_largest_layout_16_cameras_48_blobs(searchers):
+    """16 cameras x 48 blobs per camera: the per-blob DLT table alone is 61 KB, the workgroup's LDS layout ~ 100 KB (one
+    workgroup per CU); the prefetch buffers must stay addressable (low 64 KB)."""
+    rig = synth.ring_rig(16, K=[[640.0, 0, 320.0], [0, 640.0, 240.0], [0, 0, 1]], image_size=(640, 480))
+    blobs, counts, _ = synth.make_blob_stream(rig, 40, 48, seed=340, dropout=0.3)
+    _check(searchers, rig, blobs, counts, K_max=100, gate=1.0, oracle_frames=6)
+    assert searchers["forced"].last_frame_kernel() == "frame_bb_kernel<CW=2>"
+
+
 @pytest.mark.parametrize("C,M", [(12, 8), (16, 6), (9, 10)])
 def test_more_than_eight_cameras(searchers, C, M):
     """Groups of more than 8 cameras carry their blob indices in two 64-bit words (frame_bb_kernel<CW=2>)."""
