@@ -504,10 +504,10 @@ static int match_dev_locked(mocap_ctx* ctx, int64_t n_frames, int M_max, const f
   bool wide = ctx->force_wide != 0 || (M_max > 255 && ctx->cv.uniformK);
   // The realistic rigs go to their own kernel (csrc/frame_bb.hip: exact branch and bound): identical plain intrinsics
   // (the eigenvalue bounds need K = [[fx,0,cx],[0,fy,cy],[0,0,1]]), <= 16 cameras, <= 64 blobs per camera, <= 255 roots,
-  // frames big enough for a 256-lane workgroup.  Everything else -- and MOCAP_EVAL_BB=0 -- takes the exhaustive walk.
-  // (Decided before narrow / wide: its layout has no odometer columns and fits where the general narrow one does not.)
+  // frames big enough for a 256-lane workgroup (or 256 lanes asked for: MOCAP_FRAME_THREADS / mocap_set_tuning).  Everything
+  // else -- and MOCAP_EVAL_BB=0 -- takes the exhaustive walk.  (Decided before narrow / wide: its layout has no odometer columns and fits where the general narrow one does not.)
   const bool use_bb = ctx->eval_bb && !wide && ctx->cv.uniformK && ctx->prune && ctx->eigcut && ctx->p3max2 > 0.0 && ctx->p3max2c > 0.0 &&
-                      (ctx->frame_threads == 0 || ctx->frame_threads == 256) && ctx->C * M_max > 32 && ctx->frame_launches != 3 &&
+                      (ctx->frame_threads == 256 || (ctx->frame_threads == 0 && ctx->C * M_max > 32)) && ctx->frame_launches != 3 &&
                       frame_bb_fits(ctx->C, M_max, K_max);
   size_t lds = 0;
   if (use_bb) {

@@ -49,6 +49,42 @@ def test_frame_path_vs_reference_golden(core, name):
             np.testing.assert_allclose(res["err"][f, :k], g["ref_err"][f, :k], rtol=ERR_RTOL, atol=1e-12)
 
 
+@pytest.mark.parametrize("name", golden_names("frames_"))
+def test_frame_goldens_through_the_search_kernel(name):
+    """The same reference-run fixtures with EVERY frame set -- the 2 x 1 and 4 x 4 ones too, which a default context hands
+    to the one-wave kernel -- forced through csrc/frame_bb.hip with the bound tests on (256 lanes asked for,
+    MOCAP_BB_MIN_G=0): the exact branch and bound against what the reference itself returned."""
+    import os
+    from mocap_core import capi
+    old = {k: os.environ.get(k) for k in ("MOCAP_FRAME_THREADS", "MOCAP_BB_MIN_G")}
+    os.environ.update(MOCAP_FRAME_THREADS="256", MOCAP_BB_MIN_G="0")
+    try:
+        c = capi.MocapCore(0)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    try:
+        g = load_golden(name)
+        uniform_plain = all(np.array_equal(g["K"][0], k) for k in g["K"]) and g["K"][0][0, 1] == 0
+        c.set_cameras(g["K"], g["R"], g["t"])
+        res = c.match_triangulate_auto(g["blobs"], g["counts"])
+        if uniform_plain and g["blobs"].shape[2] <= 64:
+            assert c.last_frame_kernel().startswith("frame_bb_kernel"), c.last_frame_kernel()
+        assert not res["status"].any()
+        assert np.array_equal(res["n_out"], g["ref_n"])
+        for f in range(g["blobs"].shape[0]):
+            k = int(g["ref_n"][f])
+            assert np.array_equal(_corr_xy(g["blobs"][f], res["corr"][f, :k]), g["ref_corr_xy"][f, :k], equal_nan=True)
+            if k:
+                np.testing.assert_allclose(res["xyz"][f, :k], g["ref_xyz"][f, :k], rtol=XYZ_RTOL, atol=0)
+                np.testing.assert_allclose(res["err"][f, :k], g["ref_err"][f, :k], rtol=ERR_RTOL, atol=1e-12)
+    finally:
+        c.close()
+
+
 @pytest.mark.parametrize("name", golden_names("dlt_"))
 def test_triangulate_vs_reference_golden(core, name):
     g = load_golden(name)
