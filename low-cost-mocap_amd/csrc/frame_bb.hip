@@ -814,9 +814,9 @@ struct BBState {
             };
             const double bound = __longlong_as_double((long long)rbound[r]);
             if constexpr (CT > 0)
-              solve_and_score<true, true, F32R>(CamViewFixed<CT>{cv}, B, v, obs_p, X, e, bound * (double)(2 * v) * (1.0 + 0x1p-40), ec);
+              solve_and_score<true, true, F32R, false>(CamViewFixed<CT>{cv}, B, v, obs_p, X, e, bound * (double)(2 * v) * (1.0 + 0x1p-40), ec);
             else
-              solve_and_score<true, true, F32R>(cv, B, v, obs_p, X, e, bound * (double)(2 * v) * (1.0 + 0x1p-40), ec);
+              solve_and_score<true, true, F32R, false>(cv, B, v, obs_p, X, e, bound * (double)(2 * v) * (1.0 + 0x1p-40), ec);
 #ifdef MOCAP_DEBUG_EIGCHECK  // self-check build: a candidate whose evaluation was cut short must not beat the bound it was cut against
             if (!(e < inf)) {
               double B2[10], X2[3], e2;

@@ -420,7 +420,11 @@ __device__ __forceinline__ void score_point(const View& cv, int v, Obs2&& obs2, 
 // the best one so far, and the residuals are a sum of non-negative terms -- once the running left-to-right sum
 // exceeds `limit` the group cannot win, and the remaining views are skipped (err = +inf).  The callers put a safety
 // factor on the limit, so a group within rounding distance of the best is never cut short.
-template <bool UNIFORM_K, bool PAIRWISE, bool F32R, class View, class Obs2>
+// DEPTH_CUT: after the null vector, the bound is taken again with the depths of the point that would be reprojected
+// (EigCut's second form).  It pays in the exhaustive walk, where every candidate comes this far; behind the block search
+// of frame_bb.hip, whose survivors are mostly near-winners, it costs more than it cuts (5.77 vs 6.00 ms per 100 k
+// frames, round 3) and is compiled out there.
+template <bool UNIFORM_K, bool PAIRWISE, bool F32R, bool DEPTH_CUT = true, class View, class Obs2>
 __device__ __forceinline__ void solve_and_score(const View& cv, double (&B)[10], int v, Obs2&& obs2,
                                                 double (&X)[3], double& err,
                                                 double limit = __builtin_huge_val(), const EigCut& ec = EigCut{}) {
@@ -438,7 +442,7 @@ __device__ __forceinline__ void solve_and_score(const View& cv, double (&B)[10],
   X[0] = div_by(vec[0], vec[3], rw);  // helpers.py:321
   X[1] = div_by(vec[1], vec[3], rw);
   X[2] = div_by(vec[2], vec[3], rw);
-  if (cut) {
+  if (cut && DEPTH_CUT) {
     double Xp[3] = {X[0], X[1], X[2]};
     if (F32R) {
       Xp[0] = (double)(float)X[0];
