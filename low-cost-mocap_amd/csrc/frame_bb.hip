@@ -17,8 +17,10 @@
 //    that involves only the roots created on the way (a few per frame): one wave, state in registers, ballots.
 //  * written for instruction issue, which is what binds it (PMC: the SIMDs issue an instruction in ~90-100 % of
 //    their cycles, 40 % of them scalar / branch / LDS): one lane per (root, camera) pair with the camera's blobs walked
-//    serially instead of a lane per (pair, blob); an instantiation with the camera count at compile time (8); the
-//    blocks' bounds cached between seed and test pass.
+//    serially instead of a lane per (pair, blob); an instantiation with the camera count at compile time (8), and for
+//    8 cameras x 16 blob slots with K_max <= 48 / <= 64 the whole LDS layout at compile time (every array at a constant
+//    address: no base registers, no spills of them, no address arithmetic -- 5.72 -> 5.39 ms per 100 k frames, K_max 64:
+//    7.28 -> 5.47); the blocks' bounds cached between seed and test pass; the camera tables behind one base pointer.
 //  * a software pipeline over the frames: frame k + 1 is pulled from the queue and fetched straight into a spare LDS
 //    buffer (global_load_lds, no registers) while frame k is searched.
 //  * one evaluation path: a frame below the search threshold (MOCAP_BB_MIN_G, default 0 = never) queues all its blocks
@@ -41,6 +43,8 @@
 //   E   one lane per kept root: merge the four waves' slots, decode the winning group, write xyz / err / corr
 #include "mocap_device.hpp"
 #include "kernels.hpp"
+#include <cstdlib>
+
 #include "frame_common.hpp"
 
 // timing experiments only (results invalid): bit 0 = no search / no output, bit 1 = no chain over the cameras,
@@ -58,6 +62,9 @@ constexpr int kBBRecs = kBBThreads + 64;  // surviving blocks queued between two
 // LDS carving, identical on host (size) and device (pointers): the frame's persistent state (blobs, per-blob DLT table,
 // roots, hit lists), the search's arrays (block records, result slots -- dead while matching, which keeps its speculative
 // lines there), the spare blob buffer of the frame pipeline and the cache of block bounds.
+#ifndef MOCAP_BB_LDS_SLACK
+#define MOCAP_BB_LDS_SLACK 1024  // (measured: 512 keeps the occupancy step as well, 0 does not)
+#endif
 struct BBLayout {
   size_t bxy, bxy_nx, cnt_nx, bt, rbound, seedkey, slot_key, slot_x, claimw, recs, rpk, scr, scr_bytes, goff, gcnt, outslot, boff, bnb, seedgh, slot_g, cnt,
       misc, bpl, nh, hits, act, root_blob, root_cam, nact, bnl, bv, bcache, total;
@@ -109,7 +116,7 @@ struct BBLayout {
     bcache = take(0, 8);
     ncache = 0;
     for (int per_cu = 5; per_cu >= 1; per_cu--) {
-      const size_t lim = ((size_t)160 * 1024 / per_cu - 2048) / 256 * 256;  // (slack: allocation granule, other LDS users)
+      const size_t lim = ((size_t)160 * 1024 / per_cu - MOCAP_BB_LDS_SLACK) / 256 * 256;  // (slack: allocation granule, other LDS users)
       if (lim >= o + 8 * 64) {
         const size_t n = (lim - o) / 8;
         ncache = (int)(n > 1024 ? 1024 : n);
@@ -124,9 +131,24 @@ struct BBLayout {
   }
 };
 
-size_t frame_bb_lds_bytes(int C, int M, int R) { return BBLayout(C, M, R, C <= 8 ? 1 : 2).total; }
+// Root slots the launch lays out for a frame shape: the 8-camera, 16-blob shape has instantiations with the whole
+// layout fixed at compile time (48 or 64 slots, 0 = none applies); every other shape is laid out for K_max itself.
+static int bb_fixed_slots(int C, int M, int R) {
+#ifndef MOCAP_BB_NO_CT
+  const char* e = getenv("MOCAP_BB_FIXED_LAYOUT");  // 0: the runtime-layout instantiation for every shape (tests, A/B timing)
+  if (e && e[0] == '0') return 0;
+  if (C == 8 && M == 16 && R <= 48) return 48;
+  if (C == 8 && M == 16 && R <= 64) return 64;
+#endif
+  return 0;
+}
+static int frame_bb_root_slots(int C, int M, int R) {
+  const int f = bb_fixed_slots(C, M, R);
+  return f ? f : R;
+}
+size_t frame_bb_lds_bytes(int C, int M, int R) { return BBLayout(C, M, frame_bb_root_slots(C, M, R), C <= 8 ? 1 : 2).total; }
 static size_t frame_bb_lds_bytes_min(int C, int M, int R) {
-  const BBLayout L(C, M, R, C <= 8 ? 1 : 2);
+  const BBLayout L(C, M, frame_bb_root_slots(C, M, R), C <= 8 ? 1 : 2);
   return L.total - 8 * (size_t)L.ncache;
 }
 bool frame_bb_fits(int C, int M, int R) {
@@ -156,12 +178,42 @@ struct Packed {
 
 // CT: the camera count when it is known at compile time (8: the headline rig -- camera loops unroll, their control
 // and address arithmetic leave the scalar unit, which the issue-bound kernel shares with the vector work), 0 = runtime
-template <bool F32R, int CW, int CT>
+// The camera tables as ONE base pointer plus offsets fixed by the camera count (mocap_set_cameras lays its block out as
+// Pq | RT | K4 | F, capi.hip; identical intrinsics: Pq is [C][12]; launch_frame_bb checks the pointers against this).
+// Through a CamView the compiler re-read the four table pointers from the kernel arguments before every table read --
+// per reprojected view: arguments -> RT -> arguments -> K4, four dependent scalar-cache round trips around 42 vector
+// instructions.  The base is kept in registers (its value is hidden from the optimiser once, at the start of the
+// kernel), so a view costs one round trip, and K4 (one entry: identical intrinsics) is read once per candidate.
+template <int CT>
+struct BBCamTables {
+  const double* base;
+  static constexpr int C = CT;
+  __device__ __forceinline__ ctab_t pq(size_t off) const { return as_ctab(base + off); }
+  __device__ __forceinline__ ctab_t rt(size_t off) const { return as_ctab(base + 12 * CT + off); }
+  __device__ __forceinline__ ctab_t k4(size_t off) const { return as_ctab(base + 24 * CT + off); }
+  __device__ __forceinline__ const double* f() const { return base + 28 * CT; }
+};
+template <>
+struct BBCamTables<0> {
+  const double* base;
+  int C;
+  __device__ __forceinline__ ctab_t pq(size_t off) const { return as_ctab(base + off); }
+  __device__ __forceinline__ ctab_t rt(size_t off) const { return as_ctab(base + 12 * C + off); }
+  __device__ __forceinline__ ctab_t k4(size_t off) const { return as_ctab(base + 24 * C + off); }
+  __device__ __forceinline__ const double* f() const { return base + 28 * C; }
+};
+
+// ML, RL: the layout's blobs per camera and root slots when they are known at compile time (with CT: every LDS array
+// sits at a constant address, which takes the base registers, their spills to vector lanes and the address arithmetic
+// out of every phase -- 5.72 -> 5.39 ms per 100 k frames of 8 x 16), 0 = runtime.  ML is the frame's M_max itself (the
+// blob buffers are copied flat); RL only has to hold K_max roots: the slot arrays are laid out for RL, the root limit
+// and the output stride stay K_max.
+template <bool F32R, int CW, int CT, int ML, int RL>
 struct BBState {
   static constexpr int T = kBBThreads, W = kBBWaves;
   const FrameArgs& p;
-  const CamView& cv;
-  const int C_, M, R, tid, lane, wave;
+  BBCamTables<CT> cv;
+  const int C_, M, R, RS, tid, lane, wave;  // R = K_max (root limit, output stride), RS = root slots of the layout
   __device__ __forceinline__ int cn() const { return CT > 0 ? CT : C_; }
   double* bt;
   float2 *bxy, *bxy_nx;
@@ -181,9 +233,19 @@ struct BBState {
   static constexpr unsigned long long kInfBits = 0x7ff0000000000000ull;
 
   __device__ BBState(const FrameArgs& p_, unsigned char* smem)
-      : p(p_), cv(p_.cv), C_(p_.cv.C), M(p_.M), R(p_.K_max), tid(threadIdx.x), lane(threadIdx.x & 63), wave(threadIdx.x >> 6) {
+      : p(p_), C_(p_.cv.C), M(ML > 0 ? ML : p_.M), R(p_.K_max), RS(RL > 0 ? RL : p_.K_max), tid(threadIdx.x), lane(threadIdx.x & 63), wave(threadIdx.x >> 6) {
     const int C = cn();
-    const BBLayout L(C, M, R, CW);
+    {
+      const unsigned long long ta = (unsigned long long)(uintptr_t)p_.cv.Pq;
+      uint32_t tlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ta);
+      uint32_t thi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(ta >> 32));
+#ifndef MOCAP_BB_TABLES_FROM_ARGS  // (timing experiments: the round trip through the kernel arguments back)
+      asm volatile("" : "+s"(tlo), "+s"(thi));
+#endif
+      cv.base = (const double*)(uintptr_t)(((unsigned long long)thi << 32) | tlo);
+      if constexpr (CT == 0) cv.C = C;
+    }
+    const BBLayout L(C, M, RS, CW);
     bt = (double*)(smem + L.bt);
     bxy = (float2*)(smem + L.bxy);
     bxy_nx = (float2*)(smem + L.bxy_nx);
@@ -228,7 +290,7 @@ struct BBState {
   __device__ __forceinline__ Line epiline(int r, int i) const { return epiline_of(root_cam[r], root_blob[r], i); }
   __device__ __forceinline__ Line epiline_of(int rc, int rb, int i) const {
     const int C = cn();
-    const double* Fm = cv.F + 9 * ((size_t)rc * C + i);  // (per-lane camera pair: vector loads, L1/L2-resident table)
+    const double* Fm = cv.f() + 9 * ((size_t)rc * C + i);  // (per-lane camera pair: vector loads, L1/L2-resident table)
     const float2 rp = bxy[(size_t)rc * M + rb];
     const double x = (double)rp.x, y = (double)rp.y;
     double a = Fm[0] * x + Fm[1] * y + Fm[2];
@@ -542,7 +604,7 @@ struct BBState {
           const float2 v = bxy[i];
           om = fmaxf(om, fmaxf(fabsf(v.x), fabsf(v.y)));
           double Bc[10];
-          dlt_contribution(Bc, as_ctab(cv.Pq + 12 * c), (double)v.x, (double)v.y);
+          dlt_contribution(Bc, cv.pq(12 * c), (double)v.x, (double)v.y);
 #pragma unroll
           for (int e = 0; e < 10; e++) bt[(size_t)i * 10 + e] = Bc[e];
         }
@@ -677,7 +739,7 @@ struct BBState {
       seedkey[r] = 0ull;
       seedgh[r] = 0xFFFFFFFFu;
     }
-    for (int s = tid; s < W * R; s += T) {
+    for (int s = tid; s < W * RS; s += T) {
       slot_key[s] = ~0ull;
       slot_g[s] = 0xFFFFFFFFu;
     }
@@ -813,10 +875,7 @@ struct BBState {
               return true;
             };
             const double bound = __longlong_as_double((long long)rbound[r]);
-            if constexpr (CT > 0)
-              solve_and_score<true, true, F32R, false>(CamViewFixed<CT>{cv}, B, v, obs_p, X, e, bound * (double)(2 * v) * (1.0 + 0x1p-40), ec);
-            else
-              solve_and_score<true, true, F32R, false>(cv, B, v, obs_p, X, e, bound * (double)(2 * v) * (1.0 + 0x1p-40), ec);
+            solve_and_score<true, true, F32R, false>(cv, B, v, obs_p, X, e, bound * (double)(2 * v) * (1.0 + 0x1p-40), ec);
 #ifdef MOCAP_DEBUG_EIGCHECK  // self-check build: a candidate whose evaluation was cut short must not beat the bound it was cut against
             if (!(e < inf)) {
               double B2[10], X2[3], e2;
@@ -842,7 +901,7 @@ struct BBState {
           const bool fin = e < inf;
           const unsigned long long key = fin ? (unsigned long long)__double_as_longlong(e) : kInfBits;
           const uint32_t gword = (gl << 1) | ((e != e) ? 1u : 0u);
-          const int ss = wave * R + r;
+          const int ss = wave * RS + r;
           if (fin) atomicMin(&rbound[r], key);
           const bool want = have && (key < slot_key[ss] || (key == slot_key[ss] && gword < slot_g[ss]));
           if (__ballot(want)) {
@@ -930,7 +989,7 @@ struct BBState {
     uint32_t gw = 0xFFFFFFFFu;
     int sb = r;
     for (int w = 0; w < W; w++) {
-      const int s = w * R + r;
+      const int s = w * RS + r;
       const unsigned long long k = slot_key[s];
       const uint32_t g = slot_g[s];
       if (k < kb || (k == kb && g < gw)) {
@@ -980,10 +1039,10 @@ struct BBState {
 #define MOCAP_BB_WAVES_PER_EU 4
 #endif
 
-template <bool F32R, int CW, int CT>
+template <bool F32R, int CW, int CT, int ML, int RL>
 __global__ __launch_bounds__(kBBThreads, MOCAP_BB_WAVES_PER_EU) void frame_bb_kernel(FrameArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  BBState<F32R, CW, CT> st(p, smem);
+  BBState<F32R, CW, CT, ML, RL> st(p, smem);
   const int tid = threadIdx.x;
   const FrameQueues& q = p.q;
   // software pipeline over the frames: while frame k is searched, frame k + 1 has been pulled from the queue (one frame
@@ -1036,16 +1095,26 @@ int frame_bb_wg_per_cu_cap() { return MOCAP_BB_WAVES_PER_EU; }
 
 hipError_t launch_frame_bb(const FrameArgs& a, int grid, hipStream_t stream) {
   const size_t lds = frame_bb_lds_bytes(a.cv.C, a.M, a.K_max);
+  // the kernel addresses the tables from one base (BBCamTables): identical intrinsics, the block layout of mocap_set_cameras
+  if (!a.cv.uniformK || a.cv.RT != a.cv.Pq + 12 * a.cv.C || a.cv.K4 != a.cv.Pq + 24 * a.cv.C || a.cv.F != a.cv.Pq + 28 * a.cv.C)
+    return hipErrorInvalidValue;
   void (*k)(FrameArgs);
+  const bool f32 = a.cv.f32_rounding != 0;
+  const int fixed = bb_fixed_slots(a.cv.C, a.M, a.K_max);
+  if (fixed == 48)
+    k = f32 ? frame_bb_kernel<true, 1, 8, 16, 48> : frame_bb_kernel<false, 1, 8, 16, 48>;
+  else if (fixed == 64)
+    k = f32 ? frame_bb_kernel<true, 1, 8, 16, 64> : frame_bb_kernel<false, 1, 8, 16, 64>;
+  else if (fixed)
+    return hipErrorInvalidValue;
 #ifndef MOCAP_BB_NO_CT
-  if (a.cv.C == 8)
-    k = a.cv.f32_rounding ? frame_bb_kernel<true, 1, 8> : frame_bb_kernel<false, 1, 8>;
-  else
+  else if (a.cv.C == 8)
+    k = f32 ? frame_bb_kernel<true, 1, 8, 0, 0> : frame_bb_kernel<false, 1, 8, 0, 0>;
 #endif
-  if (a.cv.C <= 8)
-    k = a.cv.f32_rounding ? frame_bb_kernel<true, 1, 0> : frame_bb_kernel<false, 1, 0>;
+  else if (a.cv.C <= 8)
+    k = f32 ? frame_bb_kernel<true, 1, 0, 0, 0> : frame_bb_kernel<false, 1, 0, 0, 0>;
   else
-    k = a.cv.f32_rounding ? frame_bb_kernel<true, 2, 0> : frame_bb_kernel<false, 2, 0>;
+    k = f32 ? frame_bb_kernel<true, 2, 0, 0, 0> : frame_bb_kernel<false, 2, 0, 0, 0>;
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;

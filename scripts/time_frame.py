@@ -1,12 +1,12 @@
 """Timing probe (GPU box): ms per pass of the frame path over F resident frames of the 8 x 16 bench stream.
-   python scripts/time_frame.py [frames] [reps]   (honours the MOCAP_* environment knobs)"""
+   python scripts/time_frame.py [frames] [reps] [K_max]   (honours the MOCAP_* environment knobs)"""
 import os, sys, time, numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "low-cost-mocap_amd"))
 from mocap_core import capi, synth
 F = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
-C, M, K = 8, 16, 48
+C, M, K = 8, 16, (int(sys.argv[3]) if len(sys.argv) > 3 else 48)
 rig = synth.ring_rig(C)
 cache = f"/tmp/stream_{F}.npz"
 if os.path.exists(cache):
@@ -32,5 +32,5 @@ for _ in range(reps):
     a.record(); run(); b.record(); torch.cuda.synchronize()
     ts.append(a.elapsed_time(b))
 valid = (torch.arange(K, device=dev)[None, :] < d_n[:, None])
-print("frames", F, "ms", round(sorted(ts)[len(ts) // 2], 4), "per100k", round(sorted(ts)[len(ts) // 2] * 1e5 / F, 3),
+print("frames", F, "K_max", K, core.last_frame_kernel(), "ms", round(sorted(ts)[len(ts) // 2], 4), "per100k", round(sorted(ts)[len(ts) // 2] * 1e5 / F, 3),
       "cands/frame", float(d_g.double().mean()), "errsum", float(d_err[valid].nan_to_num(posinf=0).sum()), {k: v for k, v in os.environ.items() if k.startswith("MOCAP_")})

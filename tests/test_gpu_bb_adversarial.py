@@ -268,3 +268,59 @@ print("CHECKED", tot[0], tot[1])
     assert "EIGCHECK" not in p.stdout, p.stdout[:2000]
     checked = [ln for ln in p.stdout.splitlines() if ln.startswith("CHECKED")][-1].split()
     assert int(checked[1]) > 10000 and int(checked[2]) > 100000, checked   # cut candidates, candidates of dropped blocks
+
+
+@pytest.mark.parametrize("K_max", [40, 48, 57, 64, 65])
+def test_fixed_layout_instantiations_equal_the_runtime_layout(searchers, K_max):
+    """8 cameras x 16 blob slots with K_max <= 48 / <= 64 go to instantiations whose LDS layout is a compile-time
+    constant (laid out for 48 / 64 roots; the root limit and the output stride stay K_max); MOCAP_BB_FIXED_LAYOUT=0 sends
+    the same batch to the runtime-layout instantiation.  Same bits either way, and the same as the exhaustive walk --
+    also with fewer output slots than roots (root overflow status) and at K_max = 65, which no fixed layout takes."""
+    rig = synth.ring_rig(8)
+    blobs, counts, _ = synth.make_blob_stream(rig, 300, 16, seed=11)
+    assert blobs.shape[2] == 16
+    base = _check(searchers, rig, blobs, counts, K_max=K_max, min_cand=1000)
+    old = os.environ.get("MOCAP_BB_FIXED_LAYOUT")
+    os.environ["MOCAP_BB_FIXED_LAYOUT"] = "0"
+    try:
+        c = searchers["default"]
+        res = c.match_triangulate(blobs, counts, gate_px=5.0, K_max=K_max)
+        assert c.last_frame_kernel().startswith("frame_bb_kernel")
+    finally:
+        if old is None:
+            del os.environ["MOCAP_BB_FIXED_LAYOUT"]
+        else:
+            os.environ["MOCAP_BB_FIXED_LAYOUT"] = old
+    valid = np.arange(base["err"].shape[1])[None, :] < base["n_out"][:, None]
+    for key in ("n_out", "status", "n_cand"):
+        assert np.array_equal(res[key], base[key]), key
+    assert np.array_equal(res["corr"][valid], base["corr"][valid])
+    for key in ("xyz", "err"):
+        assert np.array_equal(res[key][valid], base[key][valid], equal_nan=True), key
+
+
+def test_fixed_layout_with_more_roots_than_output_slots(searchers):
+    """K_max = 20 < roots of a 16-marker frame: the frame is flagged (root overflow) by both layouts and by the
+    exhaustive walk alike; frames that fit are unaffected."""
+    rig = synth.ring_rig(8)
+    blobs, counts, _ = synth.make_blob_stream(rig, 200, 16, seed=12)
+    outs = {}
+    for name in ("default", "exhaustive"):
+        c = searchers[name]
+        c.set_cameras(rig["K"], rig["R"], rig["t"])
+        outs[name] = c.match_triangulate(blobs, counts, gate_px=5.0, K_max=20)
+    os.environ["MOCAP_BB_FIXED_LAYOUT"] = "0"
+    try:
+        outs["runtime"] = searchers["default"].match_triangulate(blobs, counts, gate_px=5.0, K_max=20)
+    finally:
+        del os.environ["MOCAP_BB_FIXED_LAYOUT"]
+    base = outs["exhaustive"]
+    assert base["status"].any() and not base["status"].all()
+    for name in ("default", "runtime"):
+        assert np.array_equal(outs[name]["status"], base["status"]), name
+        assert np.array_equal(outs[name]["n_out"], base["n_out"]), name
+        ok = base["status"] == 0
+        valid = (np.arange(20)[None, :] < base["n_out"][:, None]) & ok[:, None]
+        assert np.array_equal(outs[name]["corr"][valid], base["corr"][valid]), name
+        assert np.array_equal(outs[name]["err"][valid], base["err"][valid], equal_nan=True), name
+        assert np.array_equal(outs[name]["xyz"][valid], base["xyz"][valid], equal_nan=True), name
