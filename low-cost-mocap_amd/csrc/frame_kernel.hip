@@ -44,11 +44,15 @@
 #include "kernels.hpp"
 #include "frame_common.hpp"
 
+#ifndef MOCAP_WIDE_BATCH
+#define MOCAP_WIDE_BATCH 8  // wide frames: observations fetched ahead per pass of the candidate evaluation (4: 214.6 k, 8: 216.7 k frames/s)
+#endif
+
 namespace mocap {
 
 // register budget: 4 waves per SIMD (<= 128 VGPRs); the LDS footprint at 8 x 16 allows 4 workgroups
 // of 256 lanes per CU, so both limits meet at 16 waves per CU
-// timing experiments only (results invalid): wide frames without the camera-0 pairs (1) / the chain's pairs (2)
+// timing experiments only (results invalid): wide frames without the camera-0 pairs (1) / the chain's pairs (2) / the geometry of the candidate evaluation (4: groups are still loaded, walked and merged)
 #ifndef MOCAP_WIDE_DEBUG_SKIP
 #define MOCAP_WIDE_DEBUG_SKIP 0
 #endif
@@ -860,13 +864,21 @@ struct FrameState {
       bool have = false;
       // a blob never has NaN coordinates inside a multi-view group (NaN fails the gate), so NaN
       // marks "camera not in the group"
-      auto obs = [&](int c, double& x, double& y) -> bool {
-        const float2 v = cxy[(size_t)c * T];
-        if (v.x != v.x) return false;
-        x = (double)v.x;
-        y = (double)v.y;
-        return true;
+      struct ColumnObs {
+        const float2* col;  // this lane's column: camera c at col[c * T]
+        __device__ __forceinline__ unsigned long long raw(int c) const {
+          return *reinterpret_cast<const unsigned long long*>(col + (size_t)c * T);
+        }
+        __device__ __forceinline__ bool decode(unsigned long long w, double& x, double& y) const {
+          const float fx = __uint_as_float((uint32_t)w), fy = __uint_as_float((uint32_t)(w >> 32));
+          if (fx != fx) return false;
+          x = (double)fx;
+          y = (double)fy;
+          return true;
+        }
+        __device__ __forceinline__ bool operator()(int c, double& x, double& y) const { return decode(raw(c), x, y); }
       };
+      const ColumnObs obs{cxy};
       // table mode: the column holds blob indices; 0xFF marks "camera not in the group"
       auto contrib = [&](int c, double (&B)[10]) -> bool {
         const uint32_t k = cix[(size_t)c * T];
@@ -900,10 +912,13 @@ struct FrameState {
       while (true) {
         double X[3], e;
         const double bound = prune ? __longlong_as_double((long long)rbound[r]) : inf;
-        if constexpr (TABLE)
+        if constexpr (WIDE && (MOCAP_WIDE_DEBUG_SKIP & 4)) {
+          e = 1.0 + (double)(g & 7u);
+          X[0] = X[1] = X[2] = 0.0;
+        } else if constexpr (TABLE)
           triangulate_and_score_tab<true, F32R>(cv, contrib, obs_ix, X, e, bound, ec);
         else
-          triangulate_and_score<UNIFORM_K, true, F32R, (WIDE ? 4 : 1)>(cv, obs, obs, X, e, bound, ec);
+          triangulate_and_score<UNIFORM_K, true, F32R, (WIDE ? MOCAP_WIDE_BATCH : 1)>(cv, obs, obs, X, e, bound, ec);
 #ifdef MOCAP_DEBUG_EIGCHECK  // self-check of the cut-offs: a group that was cut must not beat the bound it was cut against
         if (!(e < inf)) {
           double X2[3], e2;

@@ -412,7 +412,7 @@ __device__ __forceinline__ void reproject_sq(Tab RT, ctab_t K4, const double (&X
 //   F32R: reproduce OpenCV's float32 roundings (MOCAP_OPT_F32_ROUNDING).
 // Returns the number of views; X / err are valid when it is >= 2.
 // Second half of triangulate_and_score: null vector of B (v views accumulated), point, reprojection error.
-template <bool UNIFORM_K, bool PAIRWISE, bool F32R, class View, class Obs2>
+template <bool UNIFORM_K, bool PAIRWISE, bool F32R, int BATCH = 1, class View, class Obs2>
 __device__ __forceinline__ void score_point(const View& cv, int v, Obs2&& obs2, const double (&X)[3], double& err,
                                             double limit);
 
@@ -424,7 +424,8 @@ __device__ __forceinline__ void score_point(const View& cv, int v, Obs2&& obs2, 
 // (EigCut's second form).  It pays in the exhaustive walk, where every candidate comes this far; behind the block search
 // of frame_bb.hip, whose survivors are mostly near-winners, it costs more than it cuts (5.77 vs 6.00 ms per 100 k
 // frames, round 3) and is compiled out there.
-template <bool UNIFORM_K, bool PAIRWISE, bool F32R, bool DEPTH_CUT = true, class View, class Obs2>
+// BATCH > 1: obs2 is a functor with raw(c) / decode(raw, x, y) next to operator() -- see triangulate_and_score.
+template <bool UNIFORM_K, bool PAIRWISE, bool F32R, bool DEPTH_CUT = true, int BATCH = 1, class View, class Obs2>
 __device__ __forceinline__ void solve_and_score(const View& cv, double (&B)[10], int v, Obs2&& obs2,
                                                 double (&X)[3], double& err,
                                                 double limit = __builtin_huge_val(), const EigCut& ec = EigCut{}) {
@@ -451,12 +452,30 @@ __device__ __forceinline__ void solve_and_score(const View& cv, double (&B)[10],
     }
     const double n2 = fma(Xp[0], Xp[0], fma(Xp[1], Xp[1], fma(Xp[2], Xp[2], 1.0)));
     double zmax2 = 1e-14 * (n2 * ec.p3max2);  // rounding of the depths below
-    for (int c = 0; c < cv.C; c++) {
-      double ox, oy;
-      if (obs2(c, ox, oy)) {
-        const auto RT = cv.rt(12 * c);
-        const double z = fma(RT[6], Xp[0], fma(RT[7], Xp[1], fma(RT[8], Xp[2], RT[11])));
-        zmax2 = fmax(zmax2, z * z);
+    if constexpr (BATCH > 1) {
+      const int C = cv.C;
+      for (int c0 = 0; c0 < C; c0 += BATCH) {
+        unsigned long long rw[BATCH];
+#pragma unroll
+        for (int u = 0; u < BATCH; u++) rw[u] = obs2.raw(c0 + u < C ? c0 + u : C - 1);
+#pragma unroll
+        for (int u = 0; u < BATCH; u++) {
+          double ox, oy;
+          if (c0 + u < C && obs2.decode(rw[u], ox, oy)) {
+            const auto RT = cv.rt(12 * (c0 + u));
+            const double z = fma(RT[6], Xp[0], fma(RT[7], Xp[1], fma(RT[8], Xp[2], RT[11])));
+            zmax2 = fmax(zmax2, z * z);
+          }
+        }
+      }
+    } else {
+      for (int c = 0; c < cv.C; c++) {
+        double ox, oy;
+        if (obs2(c, ox, oy)) {
+          const auto RT = cv.rt(12 * c);
+          const double z = fma(RT[6], Xp[0], fma(RT[7], Xp[1], fma(RT[8], Xp[2], RT[11])));
+          zmax2 = fmax(zmax2, z * z);
+        }
       }
     }
     if (lam_lb * n2 > zmax2 * limit_adj) {
@@ -464,11 +483,11 @@ __device__ __forceinline__ void solve_and_score(const View& cv, double (&B)[10],
       return;
     }
   }
-  score_point<UNIFORM_K, PAIRWISE, F32R>(cv, v, obs2, X, err, limit);
+  score_point<UNIFORM_K, PAIRWISE, F32R, BATCH>(cv, v, obs2, X, err, limit);
 }
 
 // calculate_reprojection_error (helpers.py:214-241) of a GIVEN point X seen by v cameras.
-template <bool UNIFORM_K, bool PAIRWISE, bool F32R, class View, class Obs2>
+template <bool UNIFORM_K, bool PAIRWISE, bool F32R, int BATCH, class View, class Obs2>
 __device__ __forceinline__ void score_point(const View& cv, int v, Obs2&& obs2, const double (&X)[3], double& err,
                                             double limit) {
   const int C = cv.C;
@@ -487,10 +506,20 @@ __device__ __forceinline__ void score_point(const View& cv, int v, Obs2&& obs2, 
   int j = 0;
   for (int c0 = 0; c0 < C4; c0 += 4) {
     if (!(seq <= limit)) continue;  // cut short: whole waves skip the block once every lane is out
+    unsigned long long rw[4] = {0, 0, 0, 0};
+    if constexpr (BATCH > 1) {  // the four observations are fetched before any of them is used
+#pragma unroll
+      for (int u = 0; u < 4; u++) rw[u] = obs2.raw(c0 + u);
+    }
 #pragma unroll
     for (int u = 0; u < 4; u++) {
       double x, y;
-      if (obs2(c0 + u, x, y)) {
+      bool seen;
+      if constexpr (BATCH > 1)
+        seen = obs2.decode(rw[u], x, y);
+      else
+        seen = obs2(c0 + u, x, y);
+      if (seen) {
         double du2, dv2;
         reproject_sq<F32R>(cv.rt(12 * (c0 + u)), cv.k4(4 * (UNIFORM_K ? 0 : j)), Xp, x, y, du2, dv2);
         seq = seq + du2;
@@ -521,9 +550,12 @@ __device__ __forceinline__ void score_point(const View& cv, int v, Obs2&& obs2, 
   err = (seq <= limit) ? (pw ? spw : seq) / (double)(2 * v) : __builtin_huge_val();
 }
 
-// BATCH > 1: the observations of BATCH cameras are fetched before any of them is used -- for callers whose obs1 is a
-// read of device memory (wide frames keep a lane's group in an HBM-resident column: one dependent round trip per camera
-// otherwise); the views are still accumulated in camera order, so the result is the same to the bit.
+// BATCH > 1: the observations of BATCH cameras are fetched before any of them is used -- for callers whose observations
+// are reads of device memory (wide frames keep a lane's group in an HBM-resident column: one dependent round trip per
+// camera and pass otherwise, three passes per candidate).  The observation source is then a functor with
+//   raw(c) -> the camera's 8 bytes, loaded unconditionally;  decode(raw, x, y) -> seen?;  operator()(c, x, y)
+// (a lambda that tests x before it reads y compiles to two dependent loads per view, each followed by a wait -- measured).
+// The views are still accumulated in camera order, so the result is the same to the bit.
 template <bool UNIFORM_K, bool PAIRWISE, bool F32R, int BATCH = 1, class View, class Obs1, class Obs2>
 __device__ __forceinline__ int triangulate_and_score(const View& cv, Obs1&& obs1, Obs2&& obs2,
                                                      double (&X)[3], double& err,
@@ -533,16 +565,17 @@ __device__ __forceinline__ int triangulate_and_score(const View& cv, Obs1&& obs1
   int v = 0;
   if constexpr (BATCH > 1) {
     for (int c0 = 0; c0 < C; c0 += BATCH) {
-      double xs[BATCH], ys[BATCH];
-      bool on[BATCH];
+      unsigned long long rw[BATCH];
 #pragma unroll
-      for (int u = 0; u < BATCH; u++) on[u] = c0 + u < C && obs1(c0 + u, xs[u], ys[u]);
+      for (int u = 0; u < BATCH; u++) rw[u] = obs1.raw(c0 + u < C ? c0 + u : C - 1);
 #pragma unroll
-      for (int u = 0; u < BATCH; u++)
-        if (on[u]) {
-          dlt_accumulate(B, cv.pq(UNIFORM_K ? (size_t)12 * (c0 + u) : 12 * ((size_t)v * C + (c0 + u))), xs[u], ys[u]);
+      for (int u = 0; u < BATCH; u++) {
+        double x, y;
+        if (c0 + u < C && obs1.decode(rw[u], x, y)) {
+          dlt_accumulate(B, cv.pq(UNIFORM_K ? (size_t)12 * (c0 + u) : 12 * ((size_t)v * C + (c0 + u))), x, y);
           v++;
         }
+      }
     }
   } else {
     for (int c = 0; c < C; c++) {
@@ -554,7 +587,7 @@ __device__ __forceinline__ int triangulate_and_score(const View& cv, Obs1&& obs1
     }
   }
   if (v <= 1) return v;  // helpers.py:300
-  solve_and_score<UNIFORM_K, PAIRWISE, F32R>(cv, B, v, obs2, X, err, limit_e * (double)(2 * v) * (1.0 + 0x1p-40), ec);
+  solve_and_score<UNIFORM_K, PAIRWISE, F32R, true, BATCH>(cv, B, v, obs2, X, err, limit_e * (double)(2 * v) * (1.0 + 0x1p-40), ec);
   return v;
 }
 

@@ -16,6 +16,8 @@ else:
 dev = torch.device("cuda:0")
 core = capi.MocapCore(0)
 core.set_cameras(rig["K"], rig["R"], rig["t"])
+if os.environ.get("TW_HIT_CAP"):
+    core.set_frame_limits(hit_cap=int(os.environ["TW_HIT_CAP"]))
 core.set_stream(torch.cuda.current_stream(dev).cuda_stream)
 d_b = torch.from_numpy(blobs).to(dev); d_c = torch.from_numpy(counts).to(dev)
 d_xyz = torch.empty((F, K, 3), dtype=torch.float64, device=dev); d_err = torch.empty((F, K), dtype=torch.float64, device=dev)
@@ -31,4 +33,4 @@ for _ in range(reps):
     a.record(); run(); b.record(); torch.cuda.synchronize()
     ts.append(a.elapsed_time(b))
 print("frames", F, "ms", round(sorted(ts)[len(ts) // 2], 4), "frames/s", round(F / sorted(ts)[len(ts) // 2] * 1e3), "roots/frame", float(d_n.double().mean()),
-      "cands/frame", float(d_g.double().mean()), "overflow", int((d_s != 0).sum()), core.last_frame_kernel(), {k: v for k, v in os.environ.items() if k.startswith("MOCAP_")})
+      "cands/frame", float(d_g.double().mean()), "overflow", int((d_s != 0).sum()), core.last_frame_kernel(), {k: v for k, v in os.environ.items() if k.startswith(("MOCAP_", "TW_"))})
