@@ -32,3 +32,19 @@ def test_bench_gpus2_self_launches_and_prints_one_rank0_line():
 def test_bench_world_size_mismatch_is_an_error_not_a_silent_single_rank_run():
     p = _run({"MOCAP_BENCH_DRY": "1", "WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"}, "--gpus", "2")
     assert p.returncode != 0 and "WORLD_SIZE" in (p.stderr + p.stdout)
+
+
+def test_profile_figures_are_marked_stale_when_the_sources_moved(monkeypatch):
+    """roofline.traffic and roofline_fp64 are scaled from counter summaries under profiles/ (counters cannot be read inside
+    the timed run).  Each summary names the sources it was taken on; on any other sources bench.py must say `stale`."""
+    sys.path.insert(0, ROOT)
+    import bench
+    mix, stale, path = bench.load_profile("fp64_mix")
+    assert mix is not None and path.startswith("profiles/") and "kernel_source_sha16" in mix and "kernel" in mix
+    traffic, meta = bench.measured_traffic(1000)
+    assert traffic > 0 and meta["traffic_stale"] is bool(stale) and meta["traffic_measured_on"]["kernel_source_sha16"]
+    monkeypatch.setattr(bench, "kernel_source_hash", lambda: "0" * 16)
+    assert bench.load_profile("fp64_mix")[1] is True
+    assert bench.measured_traffic(1000)[1]["traffic_stale"] is True
+    fp = bench.executed_fp64(1_000_000, 1.0)
+    assert fp is None or fp.get("stale") is True
