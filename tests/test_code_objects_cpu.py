@@ -1,0 +1,64 @@
+"""The gfx950 code objects inside lib/libmocap_core.so, read without a GPU (llvm-objdump --offloading + llvm-readelf
+--notes): the kernels the path needs are there, for gfx950 only, and the headline kernel stays inside the register and
+LDS budget its occupancy is planned on (128 VGPRs = four workgroups per CU; spills only outside the frame
+loop).  A regression here costs a workgroup per CU long before any test notices."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "low-cost-mocap_amd", "lib", "libmocap_core.so")
+LLVM = "/opt/rocm/lib/llvm/bin"
+
+
+@pytest.fixture(scope="module")
+def kernels(tmp_path_factory):
+    if not (os.path.exists(LIB) and os.path.exists(os.path.join(LLVM, "llvm-objdump"))):
+        pytest.skip("library or LLVM tools not present")
+    d = tmp_path_factory.mktemp("co")
+    shutil.copy(LIB, d / "lib.so")
+    subprocess.run([os.path.join(LLVM, "llvm-objdump"), "--offloading", "lib.so"], cwd=d, check=True, capture_output=True)
+    objs = [f for f in os.listdir(d) if "amdgcn" in f]
+    assert objs and all(f.endswith("gfx950") for f in objs), objs   # one target, no fat multi-arch build
+    out = {}
+    for f in objs:
+        notes = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", f], cwd=d, check=True, capture_output=True,
+                               text=True).stdout
+        for block in notes.split("- .agpr_count:")[1:]:
+            name = re.search(r"\.name:\s+(\S+)", block).group(1)
+            out[name] = {k: int(re.search(r"\.%s:\s+(\d+)" % k, block).group(1))
+                         for k in ("vgpr_count", "vgpr_spill_count", "sgpr_spill_count", "private_segment_fixed_size",
+                                   "group_segment_fixed_size")}
+    return out
+
+
+def _find(kernels, *parts):
+    hits = [k for k in kernels if all(p in k for p in parts)]
+    assert len(hits) == 1, (parts, hits)
+    return kernels[hits[0]]
+
+
+def test_every_kernel_family_of_the_path_is_in_the_library(kernels):
+    for stem in ("frame_bb_kernel", "frame_kernel", "tri_kernel", "ba_fused_kernel", "blob_mask_kernel", "blob_contour_kernel",
+                 "blob_activity_kernel", "compact"):
+        assert any(stem in k for k in kernels), stem
+
+
+def test_headline_kernel_budget(kernels):
+    # frame_bb_kernel<F32R = true, CW = 1, CT = 8, ML = 16, RL = 48>: the instantiation bench.py's 8 x 16 workload takes
+    for rl in ("Li48E", "Li64E"):
+        k = _find(kernels, "frame_bb_kernelILb1ELi1ELi8ELi16E" + rl)
+        assert k["vgpr_count"] <= 128, k                      # 4 waves per SIMD
+        assert k["vgpr_spill_count"] <= 24 and k["private_segment_fixed_size"] <= 104, k   # round 3: 23 / 96-100 B, all outside the frame loop
+        assert k["group_segment_fixed_size"] == 0, k          # LDS is dynamic: sized by frame_bb_lds_bytes for the launch
+    general = _find(kernels, "frame_bb_kernelILb1ELi1ELi8ELi0ELi0E")
+    assert general["vgpr_count"] <= 128 and general["vgpr_spill_count"] <= 48, general
+
+
+def test_ba_and_blob_kernels_do_not_spill(kernels):
+    for parts in (("ba_fused_kernelILb1ELb1E",), ("blob_mask_kernel",), ("blob_activity_kernel",)):
+        k = _find(kernels, *parts)
+        assert k["vgpr_spill_count"] == 0 and k["private_segment_fixed_size"] == 0, (parts, k)
