@@ -141,6 +141,17 @@ int mocap_match_triangulate_dev(mocap_ctx* ctx, int64_t n_frames, int M_max, con
                                 double* d_xyz, double* d_err, int16_t* d_corr, int32_t* d_n_out,
                                 int32_t* d_status, int32_t* d_n_cand);
 
+/* mocap_match_triangulate_auto: mocap_match_triangulate, then every frame whose status is non-zero is re-submitted on the
+ * GPU with the largest caps the core has (root capacity C * M_max, G_cap = 2^24 groups per root, every gated hit of a
+ * (root, camera) pair kept) -- the reference enumerates the full product whatever its size (helpers.py:394-400).  After
+ * return a non-zero status means: MOCAP_ST_ROOT_OVERFLOW = the frame is fine but needs n_out[f] > K_max output slots
+ * (call again with a larger K_max); other bits = the frame exceeds even the largest caps.  *n_resubmitted (may be NULL)
+ * = frames that took the second pass. */
+int mocap_match_triangulate_auto(mocap_ctx* ctx, int64_t n_frames, int M_max, const float* blobs,
+                                 const int32_t* counts, double gate_px, int K_max, int64_t G_cap, double* xyz,
+                                 double* err, int16_t* corr, int32_t* n_out, int32_t* status, int32_t* n_cand,
+                                 int32_t* n_resubmitted);
+
 /* ---------------------------------------------------------------- before the path
  * Blob extraction: replaces the per-camera preprocessing of Cameras._camera_read (helpers.py:68-82:
  * np.rot90, make_square helpers.py:507-523, cv.undistort, cv.GaussianBlur (9,9), cv.filter2D with the 5x5
@@ -210,6 +221,37 @@ int mocap_locate_objects_dev(mocap_ctx* ctx, int64_t n_frames, int K_max, const 
                              const double* d_err, const int32_t* d_n_pts, int O_max, double* d_pos,
                              double* d_heading, double* d_oerr, int32_t* d_drone, int32_t* d_lead,
                              int32_t* d_n_obj);
+
+/* mocap_track_frame: the body of the reference's live loop in ONE call (Cameras._camera_read, helpers.py:94-133):
+ *   find_point_correspondance_and_object_points (helpers.py:94) -> world coordinates (helpers.py:96-103, needs
+ *   mocap_set_world_transform; without it the points stay in camera-0 coordinates) -> locate_objects (helpers.py:107-108,
+ *   when O_max > 0 = Cameras.is_locating_objects) -> everything the `object-points` event carries (helpers.py:128-133).
+ * One enqueue (frame kernel, then one wave per frame that runs the object search and exports the valid slots into pinned
+ * host memory), one event wait; frames that hit a candidate / hit-list cap are re-submitted with the core's largest caps
+ * before the call returns.  Meant for one or a few frames per call (host buffers; for batches use the _dev form).
+ *   blobs, counts, gate_px, K_max, G_cap, xyz, err, corr (may be NULL), status   as mocap_match_triangulate
+ *   n_pts [F]      points of the frame (mocap_match_triangulate's n_out)
+ *   O_max          object slots per frame; 0 = no object search (pos .. n_obj may then be NULL)
+ *   pos [F][O_max][3], heading [F][O_max], oerr [F][O_max], drone [F][O_max], n_obj [F]   as mocap_locate_objects
+ * status & MOCAP_ST_ROOT_OVERFLOW after return: K_max was too small for that frame (call again with K_max = C * M_max). */
+int mocap_track_frame(mocap_ctx* ctx, int64_t n_frames, int M_max, const float* blobs, const int32_t* counts,
+                      double gate_px, int K_max, int64_t G_cap, double* xyz, double* err, int16_t* corr,
+                      int32_t* n_pts, int32_t* status, int O_max, double* pos, double* heading, double* oerr,
+                      int32_t* drone, int32_t* n_obj);
+/* the same from RAW camera frames (helpers.py:68-133: _camera_read's preprocessing + _find_dot in front, needs
+ * mocap_set_image_params): images [F][C][rows][cols][3] uint8 RGB (host); additionally returns the image points
+ * (blobs [F][C][M_max][2], counts [F][C], blob_status [F][C] as mocap_find_blobs; the `image-points` event of
+ * helpers.py:92 reads them). */
+int mocap_track_frame_images(mocap_ctx* ctx, int64_t n_frames, const uint8_t* images, int M_max, double gate_px,
+                             int K_max, int64_t G_cap, float* blobs, int32_t* counts, int32_t* blob_status,
+                             double* xyz, double* err, int16_t* corr, int32_t* n_pts, int32_t* status, int O_max,
+                             double* pos, double* heading, double* oerr, int32_t* drone, int32_t* n_obj);
+/* device-pointer form for batches: frame kernel + object search enqueued on the context's stream (no re-submission:
+ * check d_status). */
+int mocap_track_frame_dev(mocap_ctx* ctx, int64_t n_frames, int M_max, const float* d_blobs, const int32_t* d_counts,
+                          double gate_px, int K_max, int64_t G_cap, double* d_xyz, double* d_err, int16_t* d_corr,
+                          int32_t* d_n_pts, int32_t* d_status, int O_max, double* d_pos, double* d_heading,
+                          double* d_oerr, int32_t* d_drone, int32_t* d_n_obj);
 
 /* ---------------------------------------------------------------- initial poses
  * The pose-chaining loop of the `calculate-camera-pose` handler (index.py:229-270), i.e. the caller of

@@ -166,6 +166,12 @@ int find_blobs_dev_locked(mocap_ctx* ctx, int64_t n_frames, const uint8_t* d_ima
 
 }  // namespace
 
+// internal (ctx.hpp): the blob stage enqueued on device pointers, context lock held by the caller (mocap_track_frame_images)
+int mocap_blob_stage_locked(mocap_ctx* ctx, int64_t n_frames, const uint8_t* d_images, int M_max, float* d_blobs,
+                            int32_t* d_counts, int32_t* d_status) {
+  return find_blobs_dev_locked(ctx, n_frames, d_images, M_max, d_blobs, d_counts, d_status, nullptr, nullptr);
+}
+
 extern "C" int mocap_set_image_params(mocap_ctx* ctx, int C, int rows, int cols, const double* K, const double* dist,
                                       const int32_t* rotation) {
   if (!ctx) return MOCAP_E_ARG;
@@ -383,7 +389,8 @@ extern "C" int mocap_find_blobs_dev(mocap_ctx* ctx, int64_t n_frames, const uint
   if (!ctx) return MOCAP_E_ARG;
   std::lock_guard<std::mutex> lk(ctx->mu);
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  return find_blobs_dev_locked(ctx, n_frames, d_images, M_max, d_blobs, d_counts, d_status, d_processed, nullptr);
+  const int rc = find_blobs_dev_locked(ctx, n_frames, d_images, M_max, d_blobs, d_counts, d_status, d_processed, nullptr);
+  return rc ? rc : ctx->mark_enqueued();
 }
 
 extern "C" int mocap_find_blobs(mocap_ctx* ctx, int64_t n_frames, const uint8_t* images, int M_max, float* blobs,

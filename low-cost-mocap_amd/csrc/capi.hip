@@ -38,6 +38,18 @@ int mocap_ctx::hip_fail(hipError_t e, const char* what) {
   return fail(MOCAP_E_HIP, "%s: %s", what, hipGetErrorString(e));
 }
 
+// after a "_dev" entry point enqueued work that is still running when it returns
+int mocap_ctx::mark_enqueued() {
+  if (!handover_event) {
+    hipError_t e = hipEventCreateWithFlags(&handover_event, hipEventDisableTiming);
+    if (e != hipSuccess) return hip_fail(e, "hipEventCreateWithFlags(handover)");
+  }
+  hipError_t e = hipEventRecord(handover_event, stream);
+  if (e != hipSuccess) return hip_fail(e, "hipEventRecord(handover)");
+  dev_outstanding = true;
+  return MOCAP_OK;
+}
+
 #define HIP_TRY(ctx, expr)                                  \
   do {                                                      \
     hipError_t e__ = (expr);                                \
@@ -124,6 +136,7 @@ extern "C" void mocap_destroy(mocap_ctx* ctx) {
   if (ctx->ba_pin) (void)hipHostFree(ctx->ba_pin);
   if (ctx->ba_stage) (void)hipHostFree(ctx->ba_stage);
   if (ctx->ba_event) (void)hipEventDestroy(ctx->ba_event);
+  if (ctx->handover_event) (void)hipEventDestroy(ctx->handover_event);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
 }
@@ -145,11 +158,18 @@ extern "C" int mocap_set_stream(mocap_ctx* ctx, void* hip_stream) {
   if (!ctx) return MOCAP_E_ARG;
   std::lock_guard<std::mutex> lk(ctx->mu);
   hipStream_t ns = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
-  // the frame path's work queues clean themselves at the END of a launch: a launch still running on the previous
-  // stream has not done so yet, and nothing orders the next launch (on the new stream) behind it
-  if (ns != ctx->stream) {
-    (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);  // per-context workspaces (queues, scratch) are shared by whatever stream is current
+  // The per-context workspaces (work queues that clean themselves at the END of a launch, scratch) are shared by whatever
+  // stream is current: work a "_dev" entry point left running on the previous stream must finish before the first launch
+  // on the new one.  Ordered on the DEVICE (the new stream waits for the event recorded behind that work): the previous
+  // stream belongs to the caller and may be destroyed by now, the host does not block under the context lock, and the
+  // calling thread's current device is put back.
+  if (ns != ctx->stream && ctx->dev_outstanding) {
+    int prev_dev = -1;
+    (void)hipGetDevice(&prev_dev);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const hipError_t e = hipStreamWaitEvent(ns, ctx->handover_event, 0);
+    if (prev_dev >= 0 && prev_dev != ctx->device) (void)hipSetDevice(prev_dev);
+    if (e != hipSuccess) return ctx->hip_fail(e, "hipStreamWaitEvent(handover)");
     ctx->frame_q_clean = false;
   }
   ctx->stream = ns;
@@ -167,6 +187,7 @@ extern "C" int mocap_synchronize(mocap_ctx* ctx) {
   std::lock_guard<std::mutex> lk(ctx->mu);
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->dev_outstanding = false;
   return MOCAP_OK;
 }
 
@@ -408,7 +429,8 @@ extern "C" int mocap_triangulate_dev(mocap_ctx* ctx, int64_t N, const double* d_
   if (!ctx) return MOCAP_E_ARG;
   std::lock_guard<std::mutex> lk(ctx->mu);
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  return triangulate_dev_locked(ctx, N, d_obs, d_xyz, d_err);
+  const int rc = triangulate_dev_locked(ctx, N, d_obs, d_xyz, d_err);
+  return rc ? rc : ctx->mark_enqueued();
 }
 
 extern "C" int mocap_triangulate(mocap_ctx* ctx, int64_t N, const double* obs, double* xyz, double* err) {
@@ -642,8 +664,9 @@ extern "C" int mocap_match_triangulate_dev(mocap_ctx* ctx, int64_t n_frames, int
   if (!ctx) return MOCAP_E_ARG;
   std::lock_guard<std::mutex> lk(ctx->mu);
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  return match_dev_locked(ctx, n_frames, M_max, d_blobs, d_counts, gate_px, K_max, G_cap, d_xyz, d_err, d_corr,
-                          d_n_out, d_status, d_n_cand);
+  const int rc = match_dev_locked(ctx, n_frames, M_max, d_blobs, d_counts, gate_px, K_max, G_cap, d_xyz, d_err, d_corr,
+                                  d_n_out, d_status, d_n_cand);
+  return rc ? rc : ctx->mark_enqueued();
 }
 
 extern "C" int mocap_match_triangulate(mocap_ctx* ctx, int64_t n_frames, int M_max, const float* blobs,
@@ -761,7 +784,17 @@ static int locate_dev_locked(mocap_ctx* ctx, int64_t n_frames, int K_max, const 
   a.obj_drone = d_drone;
   a.obj_lead = d_lead;
   a.n_obj = d_n_obj;
-  HIP_TRY(ctx, launch_locate_objects(a, ctx->stream));
+  // small batches: one wave per frame (latency); big ones: one lane per frame (throughput).  Same results (tested);
+  // MOCAP_LOCATE_KERNEL=lane|wave forces one.
+  bool wave = n_frames < 16384;
+  if (const char* k = getenv("MOCAP_LOCATE_KERNEL")) wave = k[0] == 'w';
+  if (wave) {
+    TrackExportArgs e;
+    memset(&e, 0, sizeof e);
+    HIP_TRY(ctx, launch_track_export(a, e, ctx->stream));
+  } else {
+    HIP_TRY(ctx, launch_locate_objects(a, ctx->stream));
+  }
   return MOCAP_OK;
 }
 
@@ -795,7 +828,7 @@ extern "C" int mocap_compact_tracks_dev(mocap_ctx* ctx, int64_t n_frames, int K_
   a.capacity = capacity;
   a.total = d_total;
   HIP_TRY(ctx, launch_compact_tracks(a, ctx->stream));
-  return MOCAP_OK;
+  return ctx->mark_enqueued();
 }
 
 extern "C" int mocap_locate_objects_dev(mocap_ctx* ctx, int64_t n_frames, int K_max, const double* d_xyz,
@@ -805,8 +838,9 @@ extern "C" int mocap_locate_objects_dev(mocap_ctx* ctx, int64_t n_frames, int K_
   if (!ctx) return MOCAP_E_ARG;
   std::lock_guard<std::mutex> lk(ctx->mu);
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  return locate_dev_locked(ctx, n_frames, K_max, d_xyz, d_err, d_n_pts, O_max, d_pos, d_heading, d_oerr, d_drone,
-                           d_lead, d_n_obj);
+  const int rc = locate_dev_locked(ctx, n_frames, K_max, d_xyz, d_err, d_n_pts, O_max, d_pos, d_heading, d_oerr, d_drone,
+                                   d_lead, d_n_obj);
+  return rc ? rc : ctx->mark_enqueued();
 }
 
 extern "C" int mocap_locate_objects(mocap_ctx* ctx, int64_t n_frames, int K_max, const double* xyz, const double* err,
@@ -849,4 +883,291 @@ extern "C" int mocap_locate_objects(mocap_ctx* ctx, int64_t n_frames, int K_max,
   HIP_TRY(ctx, hipMemcpyAsync(n_obj, d_nobj, sizeof(int32_t) * F, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return MOCAP_OK;
+}
+
+// ------------------------------------------------------------------ C-level re-submit (uncapped enumeration)
+// The reference enumerates the full Cartesian product whatever its size (helpers.py:394-400); the frame path works under
+// caps (K_max roots, G_cap groups per root, hit_cap hits per pair of the wide variant) and reports per frame when one was
+// hit.  mocap_match_triangulate_auto gives every caller of the C ABI what mocap_core/capi.py used to do in Python: frames
+// whose status is non-zero are re-submitted, on the GPU, with the largest caps the core has.
+extern "C" int mocap_match_triangulate_auto(mocap_ctx* ctx, int64_t n_frames, int M_max, const float* blobs,
+                                            const int32_t* counts, double gate_px, int K_max, int64_t G_cap,
+                                            double* xyz, double* err, int16_t* corr, int32_t* n_out, int32_t* status,
+                                            int32_t* n_cand, int32_t* n_resubmitted) {
+  if (n_resubmitted) *n_resubmitted = 0;
+  int rc = mocap_match_triangulate(ctx, n_frames, M_max, blobs, counts, gate_px, K_max, G_cap, xyz, err, corr, n_out, status, n_cand);
+  if (rc) return rc;
+  std::vector<int64_t> bad;
+  for (int64_t f = 0; f < n_frames; f++)
+    if (status[f]) bad.push_back(f);
+  if (bad.empty()) return MOCAP_OK;
+  const int C = ctx->C;
+  const size_t nb = bad.size();
+  // worst-case root capacity: every blob its own root (never less than the caller asked for)
+  int K_big = C * M_max < 1024 ? C * M_max : 1024;
+  if (K_big < K_max) K_big = K_max;
+  const size_t fb = (size_t)C * M_max * 2;
+  std::vector<float> b2(nb * fb);
+  std::vector<int32_t> c2(nb * C), n2(nb), s2(nb), g2(nb);
+  std::vector<double> x2(nb * K_big * 3), e2(nb * K_big);
+  std::vector<int16_t> r2(nb * (size_t)K_big * C);
+  for (size_t j = 0; j < nb; j++) {
+    memcpy(&b2[j * fb], blobs + (size_t)bad[j] * fb, sizeof(float) * fb);
+    memcpy(&c2[j * C], counts + (size_t)bad[j] * C, sizeof(int32_t) * C);
+  }
+  int keep_cap;
+  {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    keep_cap = ctx->hit_cap;
+    ctx->hit_cap = M_max;  // wide frames: every gated hit of a (root, camera) pair is kept
+  }
+  rc = mocap_match_triangulate(ctx, (int64_t)nb, M_max, b2.data(), c2.data(), gate_px, K_big, (int64_t)1 << 24, x2.data(),
+                               e2.data(), r2.data(), n2.data(), s2.data(), g2.data());
+  {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    ctx->hit_cap = keep_cap;
+  }
+  if (rc) return rc;
+  for (size_t j = 0; j < nb; j++) {
+    const int64_t f = bad[j];
+    n_out[f] = n2[j];   // > K_max: the caller's arrays are too small for this frame -- status says so, n_out how many it needs
+    if (n_cand) n_cand[f] = g2[j];
+    if (s2[j] == 0 && n2[j] > K_max) {
+      status[f] = MOCAP_ST_ROOT_OVERFLOW;
+      continue;
+    }
+    status[f] = s2[j];
+    if (s2[j]) continue;
+    const size_t k = (size_t)n2[j];
+    memcpy(xyz + (size_t)f * K_max * 3, &x2[j * K_big * 3], sizeof(double) * 3 * k);
+    memcpy(err + (size_t)f * K_max, &e2[j * K_big], sizeof(double) * k);
+    memcpy(corr + (size_t)f * K_max * C, &r2[j * (size_t)K_big * C], sizeof(int16_t) * C * k);
+  }
+  if (n_resubmitted) *n_resubmitted = (int32_t)nb;
+  return MOCAP_OK;
+}
+
+// ------------------------------------------------------------------ the live loop in one call
+// helpers.py:94-133 per frame: find_point_correspondance_and_object_points -> world coordinates -> locate_objects ->
+// the `object-points` payload.  One enqueue: [blob stage ->] frame kernel (world epilogue fused in its store) -> one wave
+// per frame that runs locate_objects and exports everything into pinned host memory; the host waits for ONE event.
+namespace {
+
+struct TrackOut {
+  double* xyz; double* err; int16_t* corr; int32_t* n_pts; int32_t* status;
+  int O_max; double* pos; double* heading; double* oerr; int32_t* drone; int32_t* n_obj;
+  float* blobs; int32_t* counts; int32_t* blob_status;
+};
+
+int wait_live_event(mocap_ctx* ctx) {
+  HIP_TRY(ctx, hipEventRecord(ctx->live_event, ctx->stream));
+  for (long spins = 0;; spins++) {
+    const hipError_t e = hipEventQuery(ctx->live_event);
+    if (e == hipSuccess) break;
+    if (e != hipErrorNotReady) return ctx->hip_fail(e, "hipEventQuery");
+    if (spins > 2000000) {
+      HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+      break;
+    }
+  }
+  return MOCAP_OK;
+}
+
+// images != null: raw frames [F][C][rows][cols][3] (host); else blobs / counts (host) are the input
+int track_locked(mocap_ctx* ctx, int64_t n_frames, const uint8_t* images, int M_max, const float* blobs,
+                 const int32_t* counts, double gate_px, int K_max, int64_t G_cap, const TrackOut& o) {
+  if (!ctx->C) return ctx->fail(MOCAP_E_NOCAMS, "mocap_set_cameras has not been called");
+  if (n_frames < 0 || M_max < 1 || K_max < 1 || G_cap < 1 || o.O_max < 0)
+    return ctx->fail(MOCAP_E_ARG, "mocap_track_frame: bad size argument");
+  if (n_frames == 0) return MOCAP_OK;
+  if ((!images && (!blobs || !counts)) || !o.xyz || !o.err || !o.n_pts || !o.status)
+    return ctx->fail(MOCAP_E_ARG, "mocap_track_frame: null buffer");
+  if (o.O_max > 0 && (!o.pos || !o.heading || !o.oerr || !o.drone || !o.n_obj))
+    return ctx->fail(MOCAP_E_ARG, "mocap_track_frame: null object buffer");
+  if (o.O_max > 0 && K_max > 256) return ctx->fail(MOCAP_E_LIMIT, "mocap_track_frame: K_max=%d exceeds 256 with the object search on", K_max);
+  if (images && (!ctx->img_C || ctx->img_C != ctx->C))
+    return ctx->fail(MOCAP_E_NOCAMS, "mocap_set_image_params has not been called for this camera set");
+  if (images && (!o.blobs || !o.counts || !o.blob_status)) return ctx->fail(MOCAP_E_ARG, "mocap_track_frame_images: null blob buffer");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const int C = ctx->C, O = o.O_max > 0 ? o.O_max : 1;
+  const size_t F = (size_t)n_frames;
+  auto al = [](size_t x) { return (x + 255) / 256 * 256; };
+  const size_t b_blobs = al(sizeof(float) * F * C * M_max * 2), b_counts = al(sizeof(int32_t) * F * C),
+               b_xyz = al(sizeof(double) * F * K_max * 3), b_err = al(sizeof(double) * F * K_max),
+               b_corr = al(sizeof(int16_t) * F * K_max * C), b_i = al(sizeof(int32_t) * F),
+               b_pos = al(sizeof(double) * F * O * 3), b_o = al(sizeof(double) * F * O), b_oi = al(sizeof(int32_t) * F * O);
+  // caller-visible side (pinned host memory): inputs | frame outputs | objects
+  const size_t host_total = b_blobs + 2 * b_counts + b_xyz + b_err + b_corr + 3 * b_i + b_pos + 2 * b_o + b_oi + b_i;
+  if (host_total > ctx->live_pin_cap) {
+    if (ctx->live_pin) (void)hipHostFree(ctx->live_pin);
+    ctx->live_pin = nullptr;
+    ctx->live_pin_cap = 0;
+    const size_t want = host_total < (size_t)256 * 1024 ? (size_t)256 * 1024 : host_total + host_total / 4;
+    HIP_TRY(ctx, hipHostMalloc(&ctx->live_pin, want, hipHostMallocDefault));
+    ctx->live_pin_cap = want;
+  }
+  if (!ctx->live_event) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->live_event, hipEventDisableTiming));
+  char* p = (char*)ctx->live_pin;
+  float* h_blobs = (float*)p;          p += b_blobs;
+  int32_t* h_counts = (int32_t*)p;     p += b_counts;
+  int32_t* h_bstat = (int32_t*)p;      p += b_counts;
+  double* h_xyz = (double*)p;          p += b_xyz;
+  double* h_err = (double*)p;          p += b_err;
+  int16_t* h_corr = (int16_t*)p;       p += b_corr;
+  int32_t* h_n = (int32_t*)p;          p += b_i;
+  int32_t* h_status = (int32_t*)p;     p += b_i;
+  int32_t* h_ncand = (int32_t*)p;      p += b_i;
+  double* h_pos = (double*)p;          p += b_pos;
+  double* h_head = (double*)p;         p += b_o;
+  double* h_oerr = (double*)p;         p += b_o;
+  int32_t* h_drone = (int32_t*)p;      p += b_oi;
+  int32_t* h_nobj = (int32_t*)p;
+  // device side: [raw images | blobs | counts | blob status |] frame outputs
+  const size_t b_raw = images ? al(F * C * (size_t)ctx->img_rows * ctx->img_cols * 3) : 0;
+  const size_t dev_total = b_raw + (images ? b_blobs + 2 * b_counts : 0) + b_xyz + b_err + b_corr + 3 * b_i;
+  DevBuf& s = ctx->scratch[0];
+  if (s.reserve(dev_total)) return ctx->fail(MOCAP_E_HIP, "hipMalloc(%zu) failed", dev_total);
+  char* d = (char*)s.ptr;
+  uint8_t* d_raw = nullptr;
+  float* d_blobs = nullptr;
+  int32_t *d_counts = nullptr, *d_bstat = nullptr;
+  if (images) {
+    d_raw = (uint8_t*)d;               d += b_raw;
+    d_blobs = (float*)d;               d += b_blobs;
+    d_counts = (int32_t*)d;            d += b_counts;
+    d_bstat = (int32_t*)d;             d += b_counts;
+  }
+  double* d_xyz = (double*)d;          d += b_xyz;
+  double* d_err = (double*)d;          d += b_err;
+  int16_t* d_corr = (int16_t*)d;       d += b_corr;
+  int32_t* d_n = (int32_t*)d;          d += b_i;
+  int32_t* d_status = (int32_t*)d;     d += b_i;
+  int32_t* d_ncand = (int32_t*)d;
+
+  if (images) {
+    HIP_TRY(ctx, hipMemcpyAsync(d_raw, images, F * C * (size_t)ctx->img_rows * ctx->img_cols * 3, hipMemcpyHostToDevice, ctx->stream));
+    const int rc = mocap_blob_stage_locked(ctx, n_frames, d_raw, M_max, d_blobs, d_counts, d_bstat);
+    if (rc) return rc;
+  } else {
+    memcpy(h_blobs, blobs, sizeof(float) * F * C * M_max * 2);
+    memcpy(h_counts, counts, sizeof(int32_t) * F * C);
+  }
+  LocateArgs la;
+  la.n_frames = n_frames;
+  la.K_max = K_max;
+  la.O_max = O;
+  la.xyz = d_xyz;
+  la.err = d_err;
+  la.n_pts = d_n;
+  la.obj_pos = h_pos;
+  la.obj_heading = h_head;
+  la.obj_err = h_oerr;
+  la.obj_drone = h_drone;
+  la.obj_lead = nullptr;
+  la.n_obj = o.O_max > 0 ? h_nobj : nullptr;
+  TrackExportArgs ea;
+  memset(&ea, 0, sizeof ea);
+  ea.C = C;
+  ea.M = M_max;
+  ea.corr = d_corr;
+  ea.status = d_status;
+  ea.n_cand = d_ncand;
+  ea.out_xyz = h_xyz;
+  ea.out_err = h_err;
+  ea.out_corr = o.corr ? h_corr : nullptr;
+  ea.out_n_pts = h_n;
+  ea.out_status = h_status;
+  ea.out_n_cand = h_ncand;
+  if (images) {
+    ea.blobs = d_blobs;
+    ea.counts = d_counts;
+    ea.blob_status = d_bstat;
+    ea.out_blobs = h_blobs;
+    ea.out_counts = h_counts;
+    ea.out_blob_status = h_bstat;
+  }
+  const float* in_blobs = images ? d_blobs : h_blobs;       // the frame kernel reads pinned host memory in place (zero-copy)
+  const int32_t* in_counts = images ? d_counts : h_counts;
+  const int keep_cap = ctx->hit_cap;
+  for (int pass = 0; pass < 2; pass++) {
+    // pass 1 (only when a cap was hit): the largest caps the core has -- the reference has none (helpers.py:394-400)
+    const int64_t gc = pass ? ((int64_t)1 << 24) : G_cap;
+    if (pass) ctx->hit_cap = M_max;
+    int rc = match_dev_locked(ctx, n_frames, M_max, in_blobs, in_counts, gate_px, K_max, gc, d_xyz, d_err, d_corr, d_n,
+                              d_status, d_ncand);
+    ctx->hit_cap = keep_cap;
+    if (rc) return rc;
+    HIP_TRY(ctx, launch_track_export(la, ea, ctx->stream));
+    rc = wait_live_event(ctx);
+    if (rc) return rc;
+    bool again = false;
+    for (size_t f = 0; f < F; f++)
+      if (h_status[f] & (MOCAP_ST_CAND_OVERFLOW | MOCAP_ST_HIT_OVERFLOW)) again = true;
+    if (!again) break;
+  }
+  memcpy(o.n_pts, h_n, sizeof(int32_t) * F);
+  memcpy(o.status, h_status, sizeof(int32_t) * F);
+  for (size_t f = 0; f < F; f++) {
+    const size_t k = (size_t)(h_n[f] < 0 ? 0 : (h_n[f] > K_max ? K_max : h_n[f]));
+    memcpy(o.xyz + f * K_max * 3, h_xyz + f * K_max * 3, sizeof(double) * 3 * k);
+    memcpy(o.err + f * K_max, h_err + f * K_max, sizeof(double) * k);
+    if (o.corr) memcpy(o.corr + f * K_max * C, h_corr + f * K_max * C, sizeof(int16_t) * C * k);
+    if (o.O_max > 0) {
+      o.n_obj[f] = h_nobj[f];
+      const size_t no = (size_t)(h_nobj[f] < 0 ? 0 : (h_nobj[f] > o.O_max ? o.O_max : h_nobj[f]));
+      memcpy(o.pos + f * O * 3, h_pos + f * O * 3, sizeof(double) * 3 * no);
+      memcpy(o.heading + f * O, h_head + f * O, sizeof(double) * no);
+      memcpy(o.oerr + f * O, h_oerr + f * O, sizeof(double) * no);
+      memcpy(o.drone + f * O, h_drone + f * O, sizeof(int32_t) * no);
+    }
+  }
+  if (images) {
+    memcpy(o.counts, h_counts, sizeof(int32_t) * F * C);
+    memcpy(o.blob_status, h_bstat, sizeof(int32_t) * F * C);
+    for (size_t i = 0; i < F * C; i++) {
+      const size_t k = (size_t)(h_counts[i] < 0 ? 0 : (h_counts[i] > M_max ? M_max : h_counts[i]));
+      memcpy(o.blobs + i * M_max * 2, h_blobs + i * M_max * 2, sizeof(float) * 2 * k);
+    }
+  }
+  return MOCAP_OK;
+}
+
+}  // namespace
+
+extern "C" int mocap_track_frame(mocap_ctx* ctx, int64_t n_frames, int M_max, const float* blobs, const int32_t* counts,
+                                 double gate_px, int K_max, int64_t G_cap, double* xyz, double* err, int16_t* corr,
+                                 int32_t* n_pts, int32_t* status, int O_max, double* pos, double* heading, double* oerr,
+                                 int32_t* drone, int32_t* n_obj) {
+  if (!ctx) return MOCAP_E_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  const TrackOut o{xyz, err, corr, n_pts, status, O_max, pos, heading, oerr, drone, n_obj, nullptr, nullptr, nullptr};
+  return track_locked(ctx, n_frames, nullptr, M_max, blobs, counts, gate_px, K_max, G_cap, o);
+}
+
+extern "C" int mocap_track_frame_images(mocap_ctx* ctx, int64_t n_frames, const uint8_t* images, int M_max, double gate_px,
+                                        int K_max, int64_t G_cap, float* blobs, int32_t* counts, int32_t* blob_status,
+                                        double* xyz, double* err, int16_t* corr, int32_t* n_pts, int32_t* status, int O_max,
+                                        double* pos, double* heading, double* oerr, int32_t* drone, int32_t* n_obj) {
+  if (!ctx) return MOCAP_E_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (!images) return ctx->fail(MOCAP_E_ARG, "mocap_track_frame_images: null image buffer");
+  const TrackOut o{xyz, err, corr, n_pts, status, O_max, pos, heading, oerr, drone, n_obj, blobs, counts, blob_status};
+  return track_locked(ctx, n_frames, images, M_max, nullptr, nullptr, gate_px, K_max, G_cap, o);
+}
+
+extern "C" int mocap_track_frame_dev(mocap_ctx* ctx, int64_t n_frames, int M_max, const float* d_blobs,
+                                     const int32_t* d_counts, double gate_px, int K_max, int64_t G_cap, double* d_xyz,
+                                     double* d_err, int16_t* d_corr, int32_t* d_n_pts, int32_t* d_status, int O_max,
+                                     double* d_pos, double* d_heading, double* d_oerr, int32_t* d_drone, int32_t* d_n_obj) {
+  if (!ctx) return MOCAP_E_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  int rc = match_dev_locked(ctx, n_frames, M_max, d_blobs, d_counts, gate_px, K_max, G_cap, d_xyz, d_err, d_corr, d_n_pts,
+                            d_status, nullptr);
+  if (rc) return rc;
+  if (O_max > 0) {
+    rc = locate_dev_locked(ctx, n_frames, K_max, d_xyz, d_err, d_n_pts, O_max, d_pos, d_heading, d_oerr, d_drone, nullptr, d_n_obj);
+    if (rc) return rc;
+  }
+  return ctx->mark_enqueued();
 }

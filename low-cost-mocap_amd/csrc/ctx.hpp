@@ -38,6 +38,12 @@ struct mocap_ctx {
   double p3max2c = 0.0;     // ... and the constant in that frame
   double p3max2 = 0.0;      // EigCut constant of the current camera set (0: intrinsics not of the form the bound needs)
   hipStream_t own_stream = nullptr, stream = nullptr;
+  // stream hand-over (mocap_set_stream): every "_dev" entry point records this event behind what it enqueued; a new
+  // stream is ordered behind it with hipStreamWaitEvent -- the previous stream's handle (the caller's: it may be gone)
+  // is never touched again and the host never blocks
+  hipEvent_t handover_event = nullptr;
+  bool dev_outstanding = false;
+  int mark_enqueued();
   std::mutex mu;            // one context = one serialised caller (include/mocap_core.h)
   std::string err;          // guarded by err_mu (written by a failing call, copied out by mocap_last_error)
   std::mutex err_mu;
@@ -75,3 +81,7 @@ struct mocap_ctx {
   int fail(int code, const char* fmt, ...);
   int hip_fail(hipError_t e, const char* what);
 };
+
+// internal entry points shared between the translation units of the C ABI (context lock held by the caller)
+int mocap_blob_stage_locked(mocap_ctx* ctx, int64_t n_frames, const uint8_t* d_images, int M_max, float* d_blobs,
+                            int32_t* d_counts, int32_t* d_status);

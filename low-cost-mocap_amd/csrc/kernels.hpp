@@ -89,6 +89,29 @@ struct LocateArgs {
   int32_t* n_obj;        // [F]
 };
 hipError_t launch_locate_objects(const LocateArgs& a, hipStream_t stream);
+// live path (mocap_track_frame): one wave per frame runs the same scan (LocateArgs; n_obj == null = no object search) and
+// copies the valid slots of the frame path's device-side outputs to caller-visible (e.g. pinned host) buffers
+struct TrackExportArgs {
+  int C;
+  const int16_t* corr;      // [F][K_max][C] device
+  const int32_t* status;    // [F]
+  const int32_t* n_cand;    // [F] or null
+  double* out_xyz;          // null = no export; else [F][K_max][3]
+  double* out_err;          // [F][K_max]
+  int16_t* out_corr;        // [F][K_max][C] or null
+  int32_t* out_n_pts;       // [F]
+  int32_t* out_status;      // [F]
+  int32_t* out_n_cand;      // [F] or null
+  // images -> payload (mocap_track_frame_images): the blob stage's device-side outputs travel with the rest
+  int M;                    // blob slots per camera
+  const float* blobs;       // null, or [F][C][M][2] device
+  const int32_t* counts;    // [F][C]
+  const int32_t* blob_status;  // [F][C]
+  float* out_blobs;
+  int32_t* out_counts;
+  int32_t* out_blob_status;
+};
+hipError_t launch_track_export(const LocateArgs& a, const TrackExportArgs& e, hipStream_t stream);
 
 // compaction of a frame batch's valid points into fixed-stride records (the payload of the multi-GPU exchange)
 struct CompactArgs {

@@ -84,6 +84,137 @@ hipError_t launch_locate_objects(const LocateArgs& a, hipStream_t stream) {
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------- live path: one wave per frame + export
+// The same scan for the live loop (one or a few frames per call, helpers.py:94-133), where one lane walking K^2 distances
+// is all latency: one WAVE per frame.  The points sit in LDS; for a lead point i the lanes test all j at once
+// (`distance_deltas < 0.025`, helpers.py:441 -> one ballot per 64 points), the pair search walks p1 over the set bits in
+// ascending order and tests every p2 of the set in one ballot (first set bit = the first pair in cartesian_product's
+// order, helpers.py:444-449).  Same expressions, same bits as locate_objects_kernel (tested against it and the golden).
+// The kernel also EXPORTS the frame path's outputs: the match kernel wrote them to device memory, this wave copies the
+// valid slots (and the objects) to the caller-visible buffers -- pinned host memory in mocap_track_frame, so that one
+// event wait delivers the whole `object-points` payload.
+__global__ __launch_bounds__(64) void track_export_kernel(LocateArgs a, TrackExportArgs e) {
+  const double dist1 = 0.095, dist2 = 0.15, tol = 0.025;
+  const double pi = 3.141592653589793, half_pi = 1.5707963267948966;
+  __shared__ double P[256 * 3];
+  __shared__ double E[256];
+  const int lane = threadIdx.x;
+  for (int64_t f = blockIdx.x; f < a.n_frames; f += gridDim.x) {
+    int K = a.n_pts[f];
+    K = K < 0 ? 0 : (K > a.K_max ? a.K_max : K);
+    const double* gP = a.xyz + (size_t)f * a.K_max * 3;
+    const double* gE = a.err + (size_t)f * a.K_max;
+    __syncthreads();
+    for (int j = lane; j < 3 * K; j += 64) P[j] = gP[j];
+    for (int j = lane; j < K; j += 64) E[j] = gE[j];
+    __syncthreads();
+    // ---- export of the frame path's own outputs (valid slots only; the caller's fill stays beyond)
+    if (e.out_xyz) {
+      double* oP = e.out_xyz + (size_t)f * a.K_max * 3;
+      for (int j = lane; j < 3 * K; j += 64) oP[j] = P[j];
+      double* oE = e.out_err + (size_t)f * a.K_max;
+      for (int j = lane; j < K; j += 64) oE[j] = E[j];
+      if (e.out_corr) {
+        const int16_t* gc = e.corr + (size_t)f * a.K_max * e.C;
+        int16_t* oc = e.out_corr + (size_t)f * a.K_max * e.C;
+        for (int j = lane; j < K * e.C; j += 64) oc[j] = gc[j];
+      }
+      if (lane == 0) {
+        e.out_n_pts[f] = a.n_pts[f];
+        e.out_status[f] = e.status[f];
+        if (e.out_n_cand) e.out_n_cand[f] = e.n_cand ? e.n_cand[f] : 0;
+      }
+    }
+    if (e.blobs) {
+      const int nc = e.C;
+      const int32_t* gc = e.counts + (size_t)f * nc;
+      for (int c = lane; c < nc; c += 64) {
+        e.out_counts[(size_t)f * nc + c] = gc[c];
+        e.out_blob_status[(size_t)f * nc + c] = e.blob_status[(size_t)f * nc + c];
+      }
+      const size_t w = (size_t)nc * e.M * 2;
+      const float* gb = e.blobs + (size_t)f * w;
+      float* ob = e.out_blobs + (size_t)f * w;
+      for (int j = lane; j < (int)w; j += 64) {
+        const int c = j / (2 * e.M), k = (j - c * 2 * e.M) >> 1;
+        if (k < gc[c]) ob[j] = gb[j];
+      }
+    }
+    if (!a.n_obj) continue;  // is_locating_objects off (helpers.py:107)
+    int no = 0;
+    if (K <= 256) {
+      const int chunks = (K + 63) >> 6;
+      unsigned long long matched[4] = {0, 0, 0, 0};
+      for (int i = 0; i < K; i++) {
+        if (matched[i >> 6] >> (i & 63) & 1ull) continue;
+        unsigned long long m[4] = {0, 0, 0, 0};
+        int nm = 0;
+        for (int ch = 0; ch < chunks; ch++) {
+          const int j = ch * 64 + lane;
+          const bool ok = j < K && fabs(dist3(P + 3 * i, P + 3 * j) - dist1) < tol;
+          m[ch] = __ballot(ok);
+          nm += __popcll(m[ch]);
+        }
+        if (nm < 2) continue;
+        int p1f = -1, p2f = -1;
+        for (int c1 = 0; c1 < chunks && p1f < 0; c1++) {
+          unsigned long long rest = m[c1];
+          while (rest && p1f < 0) {
+            const int p1 = c1 * 64 + __builtin_ctzll(rest);
+            rest &= rest - 1;
+            for (int ch = 0; ch < chunks; ch++) {
+              const int j = ch * 64 + lane;
+              bool acc = false;
+              if (j < K && (m[ch] >> lane & 1ull)) acc = !(fabs(dist3(P + 3 * p1, P + 3 * j) - dist2) > tol);
+              const unsigned long long b = __ballot(acc);
+              if (b) {
+                p1f = p1;
+                p2f = ch * 64 + __builtin_ctzll(b);
+                break;
+              }
+            }
+          }
+        }
+        if (p1f < 0) continue;
+        matched[i >> 6] |= 1ull << (i & 63);
+        matched[p1f >> 6] |= 1ull << (p1f & 63);
+        matched[p2f >> 6] |= 1ull << (p2f & 63);
+        if (lane == 0 && no < a.O_max) {
+          const double* A = P + 3 * p1f;
+          const double* B = P + 3 * p2f;
+          const double loc[3] = {(A[0] + B[0]) / 2, (A[1] + B[1]) / 2, (A[2] + B[2]) / 2};
+          const double error = ((E[i] + E[p1f]) + E[p2f]) / 3.0;
+          double hx = A[0] - B[0], hy = A[1] - B[1], hz = A[2] - B[2];
+          const double nrm = sqrt((hx * hx + hy * hy) + hz * hz);
+          hx /= nrm;
+          hy /= nrm;
+          double heading = atan2(hy, hx);
+          heading = heading > half_pi ? heading - pi : heading;
+          heading = heading < -half_pi ? heading + pi : heading;
+          const int drone = (P[3 * i + 1] - loc[1]) > 0 ? 0 : 1;
+          const size_t o = (size_t)f * a.O_max + no;
+          a.obj_pos[3 * o + 0] = loc[0];
+          a.obj_pos[3 * o + 1] = loc[1];
+          a.obj_pos[3 * o + 2] = loc[2];
+          a.obj_heading[o] = -heading;
+          a.obj_err[o] = error;
+          a.obj_drone[o] = drone;
+          if (a.obj_lead) a.obj_lead[o] = i;
+        }
+        no++;
+      }
+    }
+    if (lane == 0) a.n_obj[f] = no;
+  }
+}
+
+hipError_t launch_track_export(const LocateArgs& a, const TrackExportArgs& e, hipStream_t stream) {
+  if (a.n_frames <= 0) return hipSuccess;
+  const int64_t blocks = a.n_frames > 4096 ? 4096 : a.n_frames;
+  hipLaunchKernelGGL(track_export_kernel, dim3((unsigned)blocks), dim3(64), 0, stream, a, e);
+  return hipGetLastError();
+}
+
 // ---------------------------------------------------------------- track compaction for the exchange step
 // The frame kernel writes fixed-capacity outputs ([F][K_max] slots, n_out of them valid): fine for consumers on
 // the same GPU, twice the bytes the valid points need when a frame shard's results travel to the gathering rank

@@ -47,6 +47,11 @@ SIGNATURES = {
     "mocap_triangulate_dev": (_i32, [_vp, _i64, _vp, _vp, _vp]),
     "mocap_match_triangulate": (_i32, [_vp, _i64, _i32, _vp, _vp, _dbl, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mocap_match_triangulate_dev": (_i32, [_vp, _i64, _i32, _vp, _vp, _dbl, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mocap_match_triangulate_auto": (_i32, [_vp, _i64, _i32, _vp, _vp, _dbl, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mocap_track_frame": (_i32, [_vp, _i64, _i32, _vp, _vp, _dbl, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "mocap_track_frame_images": (_i32, [_vp, _i64, _vp, _i32, _dbl, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp,
+                                        _vp, _vp, _vp]),
+    "mocap_track_frame_dev": (_i32, [_vp, _i64, _i32, _vp, _vp, _dbl, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
     "mocap_set_image_params": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp]),
     "mocap_set_blob_options": (_i32, [_vp, _i32]),
     "mocap_get_undistort_map": (_i32, [_vp, _i32, _vp]),
@@ -207,35 +212,97 @@ class MocapCore:
         return {"xyz": xyz, "err": err, "corr": corr, "n_out": n_out, "status": status, "n_cand": n_cand}
 
     def match_triangulate_auto(self, blobs, counts, gate_px=5.0, K_max=None, G_cap=1 << 20):
-        """match_triangulate, then frames whose caps overflowed are re-submitted ON THE GPU with the
-        worst-case root capacity (C*M), the largest candidate cap and (wide frames) an uncapped hit list."""
-        res = self.match_triangulate(blobs, counts, gate_px, K_max, G_cap)
-        bad = np.nonzero(res["status"])[0]
-        if bad.size:
-            F, C, M, _ = np.shape(blobs)
-            k0 = res["xyz"].shape[1]
-            self._apply_frame_limits(M, self._force_wide)
-            try:
-                # never less root capacity than the first call had (a caller's K_max may exceed C*M)
-                big = self.match_triangulate(np.asarray(blobs)[bad], np.asarray(counts)[bad], gate_px,
-                                             max(k0, min(C * M, 1024)), 1 << 24)
-            finally:
-                self._apply_frame_limits(self._hit_cap, self._force_wide)
-            if big["n_out"].max(initial=0) > k0:
-                grow = int(big["n_out"].max())
-                for key, fill in (("xyz", np.nan), ("err", np.nan), ("corr", -1)):
-                    shape = list(res[key].shape)
-                    shape[1] = grow
-                    new = np.full(shape, fill, dtype=res[key].dtype)
-                    new[:, :k0] = res[key]
-                    res[key] = new
-                k0 = grow
-            for j, f in enumerate(bad):
-                for key in ("xyz", "err", "corr"):
-                    res[key][f] = big[key][j][:k0]
-                for key in ("n_out", "status", "n_cand"):
-                    res[key][f] = big[key][j]
+        """mocap_match_triangulate_auto: frames whose caps overflowed are re-submitted ON THE GPU by the core itself with the
+        worst-case root capacity (C*M), the largest candidate cap and (wide frames) an uncapped hit list -- any caller of
+        the C ABI gets this, not only Python.  What is left to do here is grow the output arrays when a re-submitted frame
+        needs more than K_max slots (the C entry reports how many in n_out)."""
+        blobs = np.ascontiguousarray(blobs, dtype=np.float32)
+        counts = np.ascontiguousarray(counts, dtype=np.int32)
+        F, C, M, _ = blobs.shape
+        assert C == self.C and counts.shape == (F, C)
+        K_max = min(C * M, 64) if K_max is None else int(K_max)
+
+        def call(b, c, k):
+            f = b.shape[0]
+            out = {"xyz": np.full((f, k, 3), np.nan), "err": np.full((f, k), np.nan), "corr": np.full((f, k, C), -1, dtype=np.int16),
+                   "n_out": np.zeros(f, dtype=np.int32), "status": np.zeros(f, dtype=np.int32), "n_cand": np.zeros(f, dtype=np.int32)}
+            nres = ctypes.c_int32()
+            self._check(self.lib.mocap_match_triangulate_auto(self._h, f, M, _p(b), _p(c), float(gate_px), k, int(G_cap),
+                                                              _p(out["xyz"]), _p(out["err"]), _p(out["corr"]), _p(out["n_out"]),
+                                                              _p(out["status"]), _p(out["n_cand"]), ctypes.addressof(nres)))
+            out["resubmitted"] = nres.value
+            return out
+
+        res = call(blobs, counts, K_max)
+        need = np.nonzero((res["status"] == ST_ROOT_OVERFLOW) & (res["n_out"] > K_max))[0]
+        if need.size:
+            grow = int(res["n_out"][need].max())
+            big = call(blobs[need], counts[need], grow)
+            for key, fill in (("xyz", np.nan), ("err", np.nan), ("corr", -1)):
+                shape = list(res[key].shape)
+                shape[1] = grow
+                new = np.full(shape, fill, dtype=res[key].dtype)
+                new[:, :K_max] = res[key]
+                new[need] = big[key]
+                res[key] = new
+            for key in ("n_out", "status", "n_cand"):
+                res[key][need] = big[key]
         return res
+
+    # ------------------------------------------------------------------ the live loop in one call
+    def _track_outputs(self, F, K_max, O_max):
+        O = max(1, int(O_max))
+        return {"xyz": np.full((F, K_max, 3), np.nan), "err": np.full((F, K_max), np.nan),
+                "corr": np.full((F, K_max, self.C), -1, dtype=np.int16), "n_pts": np.zeros(F, dtype=np.int32),
+                "status": np.zeros(F, dtype=np.int32), "pos": np.full((F, O, 3), np.nan), "heading": np.full((F, O), np.nan),
+                "error": np.full((F, O), np.nan), "droneIndex": np.full((F, O), -1, dtype=np.int32),
+                "n_obj": np.zeros(F, dtype=np.int32)}
+
+    def track_frame(self, blobs, counts, gate_px=5.0, K_max=None, G_cap=1 << 20, O_max=8):
+        """mocap_track_frame: match -> world coordinates -> locate_objects for one or a few frames in one call
+        (helpers.py:94-133).  O_max = 0 switches the object search off (Cameras.is_locating_objects)."""
+        blobs = np.ascontiguousarray(blobs, dtype=np.float32)
+        counts = np.ascontiguousarray(counts, dtype=np.int32)
+        F, C, M, _ = blobs.shape
+        assert C == self.C and counts.shape == (F, C)
+        K_max = min(C * M, 64) if K_max is None else int(K_max)
+        while True:
+            o = self._track_outputs(F, K_max, O_max)
+            self._check(self.lib.mocap_track_frame(self._h, F, M, _p(blobs), _p(counts), float(gate_px), K_max, int(G_cap),
+                                                   _p(o["xyz"]), _p(o["err"]), _p(o["corr"]), _p(o["n_pts"]), _p(o["status"]),
+                                                   int(O_max), _p(o["pos"]), _p(o["heading"]), _p(o["error"]),
+                                                   _p(o["droneIndex"]), _p(o["n_obj"])))
+            if (o["status"] & ST_ROOT_OVERFLOW).any() and K_max < min(C * M, 256 if O_max else 1024):
+                K_max = min(C * M, 256 if O_max else 1024)        # every blob its own root
+                continue
+            return o
+
+    def track_frame_images(self, images, M_max=16, gate_px=5.0, K_max=None, G_cap=1 << 20, O_max=8):
+        """mocap_track_frame_images: raw camera frames [F][C][rows][cols][3] -> image points, object points, objects."""
+        images = np.ascontiguousarray(images, dtype=np.uint8)
+        F, C = images.shape[:2]
+        assert images.shape == (F, C, self.img_rows, self.img_cols, 3) and C == self.img_C == self.C
+        K_max = min(C * M_max, 64) if K_max is None else int(K_max)
+        while True:
+            o = self._track_outputs(F, K_max, O_max)
+            o.update(blobs=np.zeros((F, C, M_max, 2), dtype=np.float32), counts=np.zeros((F, C), dtype=np.int32),
+                     blob_status=np.zeros((F, C), dtype=np.int32))
+            self._check(self.lib.mocap_track_frame_images(self._h, F, _p(images), int(M_max), float(gate_px), K_max, int(G_cap),
+                                                          _p(o["blobs"]), _p(o["counts"]), _p(o["blob_status"]), _p(o["xyz"]),
+                                                          _p(o["err"]), _p(o["corr"]), _p(o["n_pts"]), _p(o["status"]), int(O_max),
+                                                          _p(o["pos"]), _p(o["heading"]), _p(o["error"]), _p(o["droneIndex"]),
+                                                          _p(o["n_obj"])))
+            if (o["status"] & ST_ROOT_OVERFLOW).any() and K_max < min(C * M_max, 256 if O_max else 1024):
+                K_max = min(C * M_max, 256 if O_max else 1024)
+                continue
+            return o
+
+    def track_frame_dev(self, n_frames, M_max, d_blobs, d_counts, gate_px, K_max, G_cap, d_xyz, d_err, d_corr, d_n_pts, d_status,
+                        O_max=0, d_pos=0, d_heading=0, d_oerr=0, d_drone=0, d_n_obj=0):
+        self._check(self.lib.mocap_track_frame_dev(
+            self._h, int(n_frames), int(M_max), _vp(d_blobs), _vp(d_counts), float(gate_px), int(K_max), int(G_cap), _vp(d_xyz),
+            _vp(d_err), _vp(d_corr), _vp(d_n_pts), _vp(d_status), int(O_max), _vp(d_pos or 0), _vp(d_heading or 0), _vp(d_oerr or 0),
+            _vp(d_drone or 0), _vp(d_n_obj or 0)))
 
     # ------------------------------------------------------------------ before the path
     def set_image_params(self, rows, cols, K, dist, rotation=None):

@@ -251,9 +251,11 @@ class PendingCompactGather:
     tensor) in rank order; None elsewhere.  result() may be called more than once (the first call completes the
     transfers and materialises the concatenation, later calls return it)."""
 
-    def __init__(self, works, n_parts, r_parts, is_dst):
+    def __init__(self, works, n_parts, r_parts, is_dst, alloc_stream=None):
         self._works, self._n, self._r, self._is_dst = works, n_parts, r_parts, is_dst
         self._done, self._out = False, None
+        # the stream gather_compact_async was called on: its caching-allocator pool owns the receive buffers
+        self._alloc_stream = alloc_stream
 
     def result(self):
         import torch
@@ -264,6 +266,17 @@ class PendingCompactGather:
             if self._is_dst:
                 # torch.cat copies: the result no longer aliases the compactor's buffers
                 self._out = (torch.cat(self._n), torch.cat(self._r))
+                # The parts were allocated on the stream the exchange was posted on (bench.py: `comm`), the cat above
+                # runs on the CALLER's current stream (bench.py: the compute stream, queued behind a step's kernels).
+                # Dropping the parts returns their blocks to the allocation stream's pool at once, where the next
+                # exchange's torch.empty + irecv could overwrite them while the cat is still queued: tell the allocator
+                # which stream still reads them.
+                if self._out[1].is_cuda:
+                    cur = torch.cuda.current_stream(self._out[1].device)
+                    if self._alloc_stream is None or cur != self._alloc_stream:
+                        for part in list(self._n) + list(self._r):
+                            if part.is_cuda and part.numel():
+                                part.record_stream(cur)
             self._n = self._r = None
             self._done = True
         return self._out
@@ -286,8 +299,9 @@ def gather_compact_async(n_out, records, n_records, frames_per_rank, dst=0):
     import torch
     import torch.distributed as dist
     rec = records[:n_records]
+    alloc_stream = torch.cuda.current_stream(n_out.device) if n_out.is_cuda else None
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-        return PendingCompactGather([], [n_out], [rec], True)
+        return PendingCompactGather([], [n_out], [rec], True, alloc_stream)
     world, rank = dist.get_world_size(), dist.get_rank()
     stride = records.shape[1]
     dev = n_out.device
@@ -299,7 +313,7 @@ def gather_compact_async(n_out, records, n_records, frames_per_rank, dst=0):
         works = list(dist.batch_isend_irecv([dist.P2POp(dist.isend, head, dst)]))
         if n_records:
             works += list(dist.batch_isend_irecv([dist.P2POp(dist.isend, rec.contiguous(), dst)]))
-        return PendingCompactGather(works, [head], [rec], False)   # keeps the staged header alive until the sends are done
+        return PendingCompactGather(works, [head], [rec], False, alloc_stream)   # keeps the staged header alive until the sends are done
     heads, ops = {}, []
     for r in range(world):
         if r == dst:
@@ -326,4 +340,4 @@ def gather_compact_async(n_out, records, n_records, frames_per_rank, dst=0):
         if counts[r]:
             ops.append(dist.P2POp(dist.irecv, rb, r))
     works = list(dist.batch_isend_irecv(ops)) if ops else []
-    return PendingCompactGather(works, n_parts, r_parts, True)
+    return PendingCompactGather(works, n_parts, r_parts, True, alloc_stream)

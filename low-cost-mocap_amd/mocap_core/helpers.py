@@ -279,6 +279,88 @@ def locate_objects(object_points, errors):
             for j in range(int(res["n_obj"][0]))]
 
 
+def _objects_list(res, f=0):
+    return [{"pos": res["pos"][f, j].copy(), "heading": float(res["heading"][f, j]),
+             "error": float(res["error"][f, j]), "droneIndex": int(res["droneIndex"][f, j])}
+            for j in range(min(int(res["n_obj"][f]), res["pos"].shape[1]))]
+
+
+def track_frame(image_points, camera_poses, is_locating_objects=True, O_max=8):
+    """The body of the reference's live loop after _find_dot in ONE core call (helpers.py:94-108):
+    find_point_correspondance_and_object_points -> world coordinates (needs set_to_world_coords_matrix; without it the
+    points stay in camera-0 coordinates) -> locate_objects.  Returns (errors, object_points, objects) -- exactly the
+    three values the loop holds at helpers.py:109 before the Kalman filter -- ready for object_points_payload().
+    `image_points` is mutated like the reference does (helpers.py:342-346)."""
+    for image_points_i in image_points:
+        try:
+            image_points_i.remove([None, None])
+        except Exception:
+            pass
+    with _state["lock"]:
+        core = _upload_cameras(camera_poses)
+        blobs, counts = pack_frame(image_points)
+        res = core.track_frame(blobs, counts, gate_px=5.0, O_max=O_max if is_locating_objects else 0)
+    if int(res["status"][0]) != 0:
+        raise capi.MocapError(f"frame exceeds the core's limits (status {int(res['status'][0])}): "
+                              "candidate groups / roots over the caps of include/mocap_core.h")
+    k = int(res["n_pts"][0])
+    if k == 0:
+        return np.array([]), np.array([]), []
+    return res["err"][0, :k].copy(), res["xyz"][0, :k].copy(), (_objects_list(res) if is_locating_objects else [])
+
+
+def camera_read_track(raw_frames, camera_poses, M_max=16, is_locating_objects=True, O_max=8):
+    """Raw camera frames -> (image_points, errors, object_points, objects): Cameras._camera_read's preprocessing,
+    _find_dot, the frame path, the world transform and locate_objects (helpers.py:68-108) in one core call; nothing but the
+    payload crosses PCIe on the way back.  image_points is what _find_dot returns per camera ([[None, None]] when a
+    camera saw nothing)."""
+    raw = np.ascontiguousarray(np.asarray(raw_frames, dtype=np.uint8))
+    C, rows, cols = raw.shape[0], raw.shape[1], raw.shape[2]
+    params = _state["camera_params"]
+    if params is None or len(params) < C:
+        raise RuntimeError("set_camera_params() has not been called with one entry per camera")
+    K = np.array([np.array(params[i]["intrinsic_matrix"], dtype=np.float64) for i in range(C)])
+    dist = np.array([np.array(params[i]["distortion_coef"], dtype=np.float64).ravel()[:5] for i in range(C)])
+    rot = np.array([int(params[i].get("rotation", 0)) for i in range(C)], dtype=np.int32)
+    with _state["lock"]:
+        core = _upload_cameras(camera_poses)
+        key = (rows, cols, K.tobytes(), dist.tobytes(), rot.tobytes())
+        if _state["img_key"] != key:
+            core.set_image_params(rows, cols, K, dist, rot)
+            _state["img_key"] = key
+        while True:
+            res = core.track_frame_images(raw[None], M_max=M_max, O_max=O_max if is_locating_objects else 0)
+            if (res["blob_status"] & capi.BLOB_ST_POINT_OVERFLOW).any() and M_max < 256:   # more dots than slots: ask again
+                M_max = min(256, 4 * M_max)
+                continue
+            break
+    if (res["blob_status"] & capi.BLOB_ST_CAP_OVERFLOW).any():
+        raise capi.MocapError("more contours than the blob stage's largest tables hold (BLOB_ST_CAP_OVERFLOW)")
+    if int(res["status"][0]) != 0:
+        raise capi.MocapError(f"frame exceeds the core's limits (status {int(res['status'][0])})")
+    image_points = []
+    for c in range(C):
+        n = int(res["counts"][0, c])
+        image_points.append(res["blobs"][0, c, :n].astype(np.int64).tolist() if n else [[None, None]])
+    k = int(res["n_pts"][0])
+    if k == 0:
+        return image_points, np.array([]), np.array([]), []
+    return (image_points, res["err"][0, :k].copy(), res["xyz"][0, :k].copy(),
+            _objects_list(res) if is_locating_objects else [])
+
+
+def object_points_payload(errors, object_points, objects, filtered_objects=()):
+    """The dict the reference emits as the `object-points` socket event (helpers.py:128-133), built from what
+    track_frame() / camera_read_track() return.  `filtered_objects` is the caller's Kalman output
+    (helpers.py:109-126: already .tolist()-ed there), passed through."""
+    return {
+        "object_points": np.asarray(object_points).tolist(),
+        "errors": np.asarray(errors).tolist(),
+        "objects": [{k: (v.tolist() if isinstance(v, np.ndarray) else v) for (k, v) in obj.items()} for obj in objects],
+        "filtered_objects": list(filtered_objects),
+    }
+
+
 # ----------------------------------------------------------------------------- initial poses (caller of BA)
 def initial_camera_poses(image_points):
     """The pose-chaining loop of the `calculate-camera-pose` handler (index.py:234-270): `image_points` is

@@ -305,6 +305,76 @@ def golden_post(name, n_frames, k_max, seed):
     print(name, "frames", n_frames, "objects", int(ref_nobj.sum()))
 
 
+def golden_track(name, n_frames, seed):
+    """The live loop's body after _find_dot, end to end through the reference's own code (helpers.py:94-108):
+    find_point_correspondance_and_object_points -> the world-coordinate loop (exec'd from the file) -> locate_objects,
+    on the really calibrated rig + to-world matrix of the reference UI (App.tsx:44-45).  Markers: 0-2 drone LED
+    triangles + clutter per frame, projected to int() pixel centroids like _find_dot's."""
+    rig = rig_from_poses(APP_TSX_POSES, [synth.DEFAULT_K] * 4)
+    C = 4
+    W = synth.APP_TSX_TO_WORLD
+    H = ref_harness.load_reference(C, intrinsics=rig["K"].tolist())
+    poses = synth.rig_to_pose_dicts(rig)
+    rng = np.random.default_rng(seed)
+    M = 12
+    blobs = np.zeros((n_frames, C, M, 2), dtype=np.float32)
+    counts = np.zeros((n_frames, C), dtype=np.int32)
+    h = np.sqrt(0.095 ** 2 - 0.075 ** 2)
+    for f in range(n_frames):
+        pts = []
+        for _ in range(int(rng.integers(0, 3))):
+            c = rig["centre"] + rng.uniform(-0.35, 0.35, 3)
+            u = rng.normal(0, 1, 3)
+            u /= np.linalg.norm(u)
+            w = np.cross(u, rng.normal(0, 1, 3))
+            w /= np.linalg.norm(w)
+            pts += [c + h * w, c + 0.075 * u, c - 0.075 * u]
+        pts += [rig["centre"] + rng.uniform(-0.45, 0.45, 3) for _ in range(int(rng.integers(0, 4)))]
+        for i in range(C):
+            px = []
+            for X in pts:
+                xc = rig["R"][i] @ X + rig["t"][i]
+                if xc[2] <= 0.1 or rng.random() < 0.03:
+                    continue
+                uv = rig["K"][i] @ (xc / xc[2])
+                if 0 <= uv[0] < 320 and 0 <= uv[1] < 320:
+                    px.append([int(uv[0]), int(uv[1])])
+            px = [px[j] for j in rng.permutation(len(px))][:M]
+            counts[f, i] = len(px)
+            if px:
+                blobs[f, i, :len(px)] = np.array(px, dtype=np.float32)
+    kmax, o_max = C * M, 8
+    ref_n = np.zeros(n_frames, dtype=np.int32)
+    ref_err = np.full((n_frames, kmax), np.nan)
+    ref_world = np.full((n_frames, kmax, 3), np.nan)
+    ref_nobj = np.zeros(n_frames, dtype=np.int32)
+    ref_pos = np.full((n_frames, o_max, 3), np.nan)
+    ref_heading = np.full((n_frames, o_max), np.nan)
+    ref_error = np.full((n_frames, o_max), np.nan)
+    ref_drone = np.full((n_frames, o_max), -1, dtype=np.int32)
+    for f in range(n_frames):
+        ip = synth.frame_to_reference_lists(blobs[f], counts[f], as_int=True)
+        errors, object_points, _ = H.find_point_correspondance_and_object_points(ip, poses, [None] * C)
+        k = len(errors)
+        ref_n[f] = k
+        if not k:
+            continue
+        object_points = reference_world_epilogue(object_points, W)       # helpers.py:96-103
+        objs = H.locate_objects(object_points, errors)                   # helpers.py:108
+        ref_err[f, :k] = errors
+        ref_world[f, :k] = object_points
+        ref_nobj[f] = len(objs)
+        for j, o in enumerate(objs[:o_max]):
+            ref_pos[f, j] = o["pos"]
+            ref_heading[f, j] = o["heading"]
+            ref_error[f, j] = o["error"]
+            ref_drone[f, j] = o["droneIndex"]
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), K=rig["K"], R=rig["R"], t=rig["t"], to_world=np.array(W, dtype=np.float64),
+                        blobs=blobs, counts=counts, ref_n=ref_n, ref_err=ref_err, ref_world=ref_world, ref_nobj=ref_nobj,
+                        ref_pos=ref_pos, ref_heading=ref_heading, ref_error=ref_error, ref_drone=ref_drone)
+    print(name, "frames", n_frames, "points", int(ref_n.sum()), "objects", int(ref_nobj.sum()))
+
+
 def golden_blobs(name, C, n_frames, n_markers, seed, Ks=None, dists=None, rotation=None, noisy=False):
     """Blob extraction: the reference's own Cameras._camera_read preprocessing and
     Cameras._find_dot (helpers.py:68-82, 143-163) on synthetic raw frames.  rot90 / make_square / the
@@ -348,6 +418,8 @@ def main():
         return main_pose()
     if "--ba-only" in sys.argv:
         return main_ba()
+    if "--track-only" in sys.argv:
+        return golden_track("track_apptsx_chain", 60, seed=19)
     if "--with-cv2" in sys.argv:       # pin the OpenCV restatements against a REAL cv2, where one exists
         from oracle import make_cv2_golden
         return make_cv2_golden.main()
@@ -375,6 +447,8 @@ def main():
     main_ba()
     # the rows right after the path: world-coordinate epilogue + object locator
     golden_post("post_world_locate", 300, 24, seed=10)
+    # ... and the live loop's body end to end (match -> world -> locate) on the reference UI's own rig
+    golden_track("track_apptsx_chain", 60, seed=19)
 
 
 def golden_pose(name, C, n_points, seed, Ks=None, dropout=0.05, noise_px=0.3):

@@ -40,12 +40,25 @@ def main():
     frames_per_rank = [b - a for a, b in (mdist.shard_bounds(F, r, world) for r in range(world))]
     comp = mdist.TrackCompactor(core, hi - lo, K, C, dev)
     handles = []
-    for step in range(3):                                  # three exchanges, two of them in flight: buffers are reused
+    # MULTIRANK_COMM_STREAM=1: bench.py's arrangement -- the exchange is posted under a side stream (whose allocator pool
+    # then owns the root's receive buffers) and completed on the compute stream while that stream is busy, with further
+    # exchanges posted in between (PendingCompactGather.result() has to record_stream the parts before releasing them)
+    comm = torch.cuda.Stream(dev) if os.environ.get("MULTIRANK_COMM_STREAM") == "1" else None
+    results = []
+    for step in range(5 if comm is not None else 3):       # several exchanges, two of them in flight: buffers are reused
         mine = run_shard(core, dev, blobs[lo:hi], counts[lo:hi], K)
         i = comp.compact(mine["n_out"], mine["xyz"], mine["err"], mine["corr"], stream)
         n = comp.count(i)
-        handles.append(comp.attach(i, mdist.gather_compact_async(comp.n_out[i], comp.records[i], n, frames_per_rank, dst=0)))
-    results = [h.result() for h in handles]
+        if comm is None:
+            handles.append(comp.attach(i, mdist.gather_compact_async(comp.n_out[i], comp.records[i], n, frames_per_rank, dst=0)))
+            continue
+        with torch.cuda.stream(comm):
+            comm.wait_event(comp.events[i])
+            handles.append(comp.attach(i, mdist.gather_compact_async(comp.n_out[i], comp.records[i], n, frames_per_rank, dst=0)))
+        if len(handles) > 2:
+            run_shard(core, dev, blobs[lo:hi], counts[lo:hi], K)       # keep the compute stream busy in front of the cat
+            results.append(handles.pop(0).result())
+    results += [h.result() for h in handles]
     if rank == 0:
         whole = run_shard(core, dev, blobs, counts, K)
         torch.cuda.synchronize(dev)

@@ -151,3 +151,45 @@ def test_bundle_adjustment_streams_camera_poses(core):
     assert n_res == int(info_res["njev"]) - 1 + 1                           # accepted steps + the final emit
     n_sp, info_sp = counts["scipy"]
     assert n_sp == info_sp["nfev"] + info_sp["njev"] * 22 + 1               # every evaluation (n = 22 FD probes per Jacobian)
+
+
+def test_stream_handover_is_ordered_on_the_device(core):
+    """mocap_set_stream: work a _dev entry point left running on the previous stream is ordered in front of the first launch
+    on the new one by an event (no host block, the previous stream -- the caller's, possibly gone -- is never touched
+    again).  Alternating streams over one context's shared work queues must give the one-stream results."""
+    import gc
+    import torch
+    from mocap_core import synth
+    rig = synth.ring_rig(8)
+    F, M, K = 3000, 16, 48
+    blobs, counts, _ = synth.make_blob_stream(rig, F, M, seed=31)
+    core.set_cameras(rig["K"], rig["R"], rig["t"])
+    want = core.match_triangulate(blobs, counts, K_max=K)
+    dev = torch.device("cuda", 0)
+    d_b, d_c = torch.from_numpy(blobs).to(dev), torch.from_numpy(counts).to(dev)
+
+    def outputs():
+        return dict(xyz=torch.empty((F, K, 3), dtype=torch.float64, device=dev), err=torch.empty((F, K), dtype=torch.float64, device=dev),
+                    corr=torch.empty((F, K, 8), dtype=torch.int16, device=dev), n=torch.zeros(F, dtype=torch.int32, device=dev),
+                    st=torch.zeros(F, dtype=torch.int32, device=dev))
+
+    outs = []
+    try:
+        for rep in range(6):
+            s = torch.cuda.Stream(dev)                    # a fresh stream per launch; the previous one is dropped below
+            core.set_stream(s.cuda_stream)
+            o = outputs()
+            core.match_triangulate_dev(F, M, d_b.data_ptr(), d_c.data_ptr(), 5.0, K, 1 << 20, o["xyz"].data_ptr(), o["err"].data_ptr(),
+                                       o["corr"].data_ptr(), o["n"].data_ptr(), o["st"].data_ptr())
+            outs.append(o)
+            del s
+            gc.collect()
+        core.synchronize()
+    finally:
+        core.set_stream(0)
+    torch.cuda.synchronize(dev)
+    valid = np.arange(K)[None, :] < want["n_out"][:, None]
+    for o in outs:
+        assert np.array_equal(o["n"].cpu().numpy(), want["n_out"]) and not o["st"].cpu().numpy().any()
+        assert np.array_equal(o["xyz"].cpu().numpy()[valid], want["xyz"][valid])
+        assert np.array_equal(o["corr"].cpu().numpy()[valid], want["corr"][valid])

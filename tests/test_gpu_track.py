@@ -1,0 +1,177 @@
+"""GPU: the live loop's body in one call (reference helpers.py:94-133): mocap_track_frame /
+mocap_track_frame_images / helpers.track_frame / helpers.object_points_payload against what the reference's own code
+returned for the same frames (tests/golden/track_apptsx_chain.npz: find_point_correspondance_and_object_points -> the
+world-coordinate loop -> locate_objects on the reference UI's rig), against the separate entry points bit for bit,
+and the C-level re-submit (mocap_match_triangulate_auto)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def chain(core):
+    g = load_golden("track_apptsx_chain")
+    core.set_cameras(g["K"], g["R"], g["t"])
+    core.set_world_transform(g["to_world"])
+    yield g
+    core.set_world_transform(None)
+
+
+def test_track_frame_vs_reference_chain_golden(core, chain):
+    g = chain
+    F = g["blobs"].shape[0]
+    objects = 0
+    for f in range(F):
+        res = core.track_frame(g["blobs"][f:f + 1], g["counts"][f:f + 1], gate_px=5.0, O_max=8)
+        assert int(res["status"][0]) == 0
+        k = int(g["ref_n"][f])
+        assert int(res["n_pts"][0]) == k, f
+        if not k:
+            assert int(res["n_obj"][0]) == 0
+            continue
+        # points: north_star's 1e-5 relative; errors 1e-3 (a float32 rounding of cv.projectPoints can flip)
+        scale = np.abs(g["ref_world"][f, :k]).max()
+        assert np.abs(res["xyz"][0, :k] - g["ref_world"][f, :k]).max() <= 1e-5 * scale, f
+        np.testing.assert_allclose(res["err"][0, :k], g["ref_err"][f, :k], rtol=1e-3, atol=1e-9)
+        no = int(g["ref_nobj"][f])
+        assert int(res["n_obj"][0]) == no, f
+        objects += no
+        assert np.array_equal(res["droneIndex"][0, :no], g["ref_drone"][f, :no])
+        np.testing.assert_allclose(res["pos"][0, :no], g["ref_pos"][f, :no], rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(res["heading"][0, :no], g["ref_heading"][f, :no], rtol=0, atol=1e-5)
+        np.testing.assert_allclose(res["error"][0, :no], g["ref_error"][f, :no], rtol=1e-3, atol=1e-9)
+    assert objects > 40        # the golden really holds drone patterns
+
+
+def test_track_frame_equals_the_separate_entry_points_bitwise(core, chain):
+    g = chain
+    F = g["blobs"].shape[0]
+    K = 48
+    one = core.track_frame(g["blobs"], g["counts"], K_max=K, O_max=8)          # all frames in one call
+    sep = core.match_triangulate(g["blobs"], g["counts"], K_max=K)
+    assert np.array_equal(one["n_pts"], sep["n_out"]) and np.array_equal(one["status"], sep["status"])
+    valid = np.arange(K)[None, :] < sep["n_out"][:, None]
+    for key in ("xyz", "err", "corr"):
+        assert np.array_equal(one[key][valid], sep[key][valid]), key
+    assert np.isnan(one["xyz"][~valid]).all()                                   # slots beyond n_pts keep the caller's fill
+    loc = core.locate_objects(sep["xyz"], sep["err"], sep["n_out"], O_max=8)
+    assert np.array_equal(one["n_obj"], loc["n_obj"])
+    have = np.arange(8)[None, :] < loc["n_obj"][:, None]
+    for key in ("pos", "heading", "error", "droneIndex"):
+        assert np.array_equal(one[key][have], loc[key][have]), key
+    off = core.track_frame(g["blobs"][:5], g["counts"][:5], K_max=K, O_max=0)   # is_locating_objects off
+    assert np.array_equal(off["xyz"][valid[:5]], sep["xyz"][:5][valid[:5]]) and not off["n_obj"].any()
+
+
+def test_wave_and_lane_object_search_agree(core):
+    """locate_objects: one wave per frame (small batches, the live path) and one lane per frame (big batches) are the same
+    function -- bit for bit, up to the 256 points per frame both accept."""
+    from mocap_core import synth
+    for k_max, n in ((24, 700), (200, 40), (256, 12)):
+        xyz, err, n_pts = synth.make_object_frames(n, k_max, seed=5 + k_max)
+        out = {}
+        for which in ("lane", "wave"):
+            os.environ["MOCAP_LOCATE_KERNEL"] = which
+            try:
+                out[which] = core.locate_objects(xyz, err, n_pts, O_max=12)
+            finally:
+                del os.environ["MOCAP_LOCATE_KERNEL"]
+        assert out["lane"]["n_obj"].sum() > 0
+        for key in ("n_obj", "pos", "heading", "error", "droneIndex", "lead"):
+            assert np.array_equal(out["lane"][key], out["wave"][key], equal_nan=True), (k_max, key)
+
+
+def test_object_points_payload_is_the_reference_event(core, chain):
+    """helpers.track_frame + object_points_payload: the dict of helpers.py:128-133, JSON-serialisable like the socket
+    event, from the reference's own nested-list frame."""
+    from mocap_core import helpers, synth
+    g = chain
+    helpers.set_core(core)
+    helpers.set_camera_params([{"intrinsic_matrix": g["K"][i].tolist()} for i in range(4)])
+    helpers.set_to_world_coords_matrix(g["to_world"])
+    try:
+        poses = [{"R": g["R"][i].tolist(), "t": g["t"][i].tolist()} for i in range(4)]
+        f = int(np.argmax(g["ref_nobj"]))
+        ip = synth.frame_to_reference_lists(g["blobs"][f], g["counts"][f], as_int=True)
+        errors, object_points, objects = helpers.track_frame(ip, poses)
+        payload = helpers.object_points_payload(errors, object_points, objects, filtered_objects=[])
+        assert list(payload) == ["object_points", "errors", "objects", "filtered_objects"]
+        json.dumps(payload)                                                      # what socketio.emit serialises
+        k, no = int(g["ref_n"][f]), int(g["ref_nobj"][f])
+        assert len(payload["object_points"]) == k and len(payload["errors"]) == k and len(payload["objects"]) == no
+        np.testing.assert_allclose(np.array(payload["object_points"]), g["ref_world"][f, :k], rtol=1e-5, atol=1e-7)
+        for j, o in enumerate(payload["objects"]):
+            assert set(o) == {"pos", "heading", "error", "droneIndex"} and isinstance(o["pos"], list)
+            assert o["droneIndex"] == int(g["ref_drone"][f, j])
+            np.testing.assert_allclose(o["pos"], g["ref_pos"][f, j], rtol=1e-5, atol=1e-7)
+        # a frame in which no camera saw anything: empty lists, like np.array([]).tolist() upstream
+        errors, object_points, objects = helpers.track_frame([[[None, None]] for _ in range(4)], poses)
+        assert helpers.object_points_payload(errors, object_points, objects) == \
+            {"object_points": [], "errors": [], "objects": [], "filtered_objects": []}
+    finally:
+        helpers.set_to_world_coords_matrix(None)
+
+
+def test_images_to_payload_chain_equals_the_staged_calls(core):
+    """mocap_track_frame_images (raw frames -> blobs -> points -> world -> objects in one enqueue) against the same
+    stages called one by one."""
+    from mocap_core import synth
+    g = load_golden("post_world_locate")
+    C = 4
+    rig = synth.ring_rig(C)
+    images, _ = synth.render_camera_frames(rig, 3, 6, seed=21)
+    dists = [synth.REFERENCE_DISTORTION] * C
+    core.set_cameras(rig["K"], rig["R"], rig["t"])
+    core.set_image_params(240, 320, rig["K"], dists)
+    core.set_world_transform(g["to_world"])
+    try:
+        one = core.track_frame_images(images, M_max=16, K_max=32, O_max=4)
+        bl = core.find_blobs(images, M_max=16)
+        assert np.array_equal(one["counts"], bl["counts"]) and np.array_equal(one["blob_status"], bl["status"])
+        slot = np.arange(16)[None, None, :] < bl["counts"][:, :, None]
+        assert np.array_equal(one["blobs"][slot], bl["blobs"][slot]) and bl["counts"].sum() > 20
+        mt = core.match_triangulate(bl["blobs"], bl["counts"], K_max=32)
+        assert np.array_equal(one["n_pts"], mt["n_out"]) and mt["n_out"].sum() > 0
+        valid = np.arange(32)[None, :] < mt["n_out"][:, None]
+        for key in ("xyz", "err", "corr"):
+            assert np.array_equal(one[key][valid], mt[key][valid]), key
+        loc = core.locate_objects(mt["xyz"], mt["err"], mt["n_out"], O_max=4)
+        assert np.array_equal(one["n_obj"], loc["n_obj"])
+    finally:
+        core.set_world_transform(None)
+
+
+def test_c_level_resubmit_of_overflowed_frames(core):
+    """mocap_match_triangulate_auto: frames over a cap come back as if the caps had been large from the start -- for any
+    caller of the C ABI (the re-submit used to live in Python); a frame that needs more slots than K_max says how many."""
+    from mocap_core import capi, synth
+    rig = synth.ring_rig(8)
+    blobs, counts, _ = synth.make_blob_stream(rig, 300, 16, seed=3)
+    core.set_cameras(rig["K"], rig["R"], rig["t"])
+    want = core.match_triangulate(blobs, counts, K_max=128, G_cap=1 << 24)
+    assert not want["status"].any()
+    tight = core.match_triangulate(blobs, counts, K_max=128, G_cap=64)
+    assert (tight["status"] & capi.ST_CAND_OVERFLOW).any()
+    got = core.match_triangulate_auto(blobs, counts, K_max=128, G_cap=64)
+    assert got["resubmitted"] == int(np.count_nonzero(tight["status"])) and not got["status"].any()
+    valid = np.arange(128)[None, :] < want["n_out"][:, None]
+    assert np.array_equal(got["n_out"], want["n_out"])
+    for key in ("xyz", "err", "corr"):
+        assert np.array_equal(got[key][valid], want[key][valid]), key
+    # root capacity: K_max = 8 is too small for 16-marker frames -> the C entry reports the need, the binding grows
+    small = core.match_triangulate_auto(blobs[:20], counts[:20], K_max=8)
+    assert small["xyz"].shape[1] == int(want["n_out"][:20].max()) and not small["status"].any()
+    v20 = np.arange(small["xyz"].shape[1])[None, :] < want["n_out"][:20, None]
+    assert np.array_equal(small["xyz"][v20], want["xyz"][:20, :small["xyz"].shape[1]][v20])
+    # the live call re-submits by itself too
+    f = int(np.nonzero(tight["status"])[0][0])
+    live = core.track_frame(blobs[f:f + 1], counts[f:f + 1], K_max=128, G_cap=64, O_max=0)
+    assert int(live["status"][0]) == 0 and int(live["n_pts"][0]) == int(want["n_out"][f])
+    k = int(want["n_out"][f])
+    assert np.array_equal(live["xyz"][0, :k], want["xyz"][f, :k])
