@@ -216,6 +216,53 @@ def frame_latency(core, blobs, counts, n=300):
                     "includes the Python/ctypes call overhead)"}
 
 
+def chain_latency(core, blobs, counts, n=200, distinct=16):
+    """latency.chain: the live loop's body per frame set, wall clock per call incl. Python/ctypes and the payload dict.
+    `track`: image points (host) -> `object-points` payload (helpers.py:94-133: match, world transform, locate_objects,
+    the dict) through ONE core call (mocap_track_frame).  `chain`: raw 8-camera frame set as pseyepy hands it over (host
+    memory, 1.8 MB) -> the same payload through mocap_track_frame_images (helpers.py:68-133), PCIe upload included."""
+    from mocap_core import helpers
+
+    def payload(res):
+        k = int(res["n_pts"][0])
+        objs = helpers._objects_list(res)
+        return helpers.object_points_payload(res["err"][0, :k], res["xyz"][0, :k], objs)
+
+    def stats(ts):
+        ts = np.sort(np.array(ts)) * 1e3
+        return {"calls": len(ts), "p50_ms": float(ts[len(ts) // 2]), "p99_ms": float(ts[int(len(ts) * 0.99)]), "max_ms": float(ts[-1])}
+
+    out = {}
+    core.set_world_transform(synth.APP_TSX_TO_WORLD)
+    try:
+        ts = []
+        for f in range(n + 10):
+            t0 = time.perf_counter()
+            pl = payload(core.track_frame(blobs[f:f + 1], counts[f:f + 1], K_max=K_MAX, O_max=8))
+            ts.append(time.perf_counter() - t0)
+        out["track"] = dict(stats(ts[10:]), points_last=len(pl["object_points"]),
+                            path="mocap_track_frame: image points (host) -> match -> world -> locate_objects -> payload dict; "
+                                 "one enqueue, one event wait, zero-copy through pinned memory")
+        C, M_max = CAMS, 32
+        rig = synth.ring_rig(C)
+        images, _ = synth.render_camera_frames(rig, distinct, MARKERS, seed=1)
+        core.set_cameras(rig["K"], rig["R"], rig["t"])
+        core.set_image_params(240, 320, rig["K"], [synth.REFERENCE_DISTORTION] * C)
+        ts = []
+        for i in range(n + 10):
+            img = images[i % distinct][None]
+            t0 = time.perf_counter()
+            pl = payload(core.track_frame_images(img, M_max=M_max, K_max=K_MAX, O_max=8))
+            ts.append(time.perf_counter() - t0)
+        out["chain"] = dict(stats(ts[10:]), points_last=len(pl["object_points"]), image_bytes=int(images[0].nbytes),
+                            path="mocap_track_frame_images: 8 raw 240x320 RGB frames (pageable host memory) -> H2D -> blob stage -> "
+                                 "match -> world -> locate_objects -> payload dict; one enqueue, one event wait")
+    finally:
+        core.set_world_transform(None)
+    out["frame_budget_ms_at_120fps"] = 1e3 / 120.0
+    return out
+
+
 def blob_stage_bench(core, dev, stream, steps=5, frames=1024, distinct=16):
     """The row before the path: raw 8-camera PS3-Eye frame sets (240 x 320 RGB, resident in
     HBM) -> blob centroids (mocap_find_blobs_dev), and the chain images -> blobs -> 3-D markers without
@@ -769,6 +816,8 @@ def main():
             if default_wl and not args.no_latency:
                 core.set_stream(0)
                 line["latency"] = frame_latency(core, blobs, counts)
+                line["latency"].update(chain_latency(core, blobs, counts))
+                core.set_cameras(rig["K"], rig["R"], rig["t"])
             if not args.no_blobs and default_wl:
                 line["blob_stage"] = blob_stage_bench(core, dev, stream)
             if not args.no_ba and default_wl:

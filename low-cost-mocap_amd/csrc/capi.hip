@@ -885,6 +885,14 @@ extern "C" int mocap_locate_objects(mocap_ctx* ctx, int64_t n_frames, int K_max,
   return MOCAP_OK;
 }
 
+// does a frame batch with these sizes fit one of the frame kernels?  (the size logic of match_dev_locked, hit lists uncapped)
+static bool frame_shape_fits(const mocap_ctx* ctx, int M_max, int K) {
+  if (frame_bb_fits(ctx->C, M_max, K) && ctx->cv.uniformK && !ctx->force_wide && M_max <= 255) return true;
+  const bool must_wide = ctx->force_wide != 0 || (M_max > 255 && ctx->cv.uniformK);
+  if (!must_wide && frame_lds_bytes(ctx->C, M_max, K, 64, M_max, false, ctx->cv.uniformK != 0) <= (size_t)160 * 1024) return true;
+  return frame_lds_bytes(ctx->C, M_max, K, kWideThreads, M_max, true, false) <= (size_t)160 * 1024;
+}
+
 // ------------------------------------------------------------------ C-level re-submit (uncapped enumeration)
 // The reference enumerates the full Cartesian product whatever its size (helpers.py:394-400); the frame path works under
 // caps (K_max roots, G_cap groups per root, hit_cap hits per pair of the wide variant) and reports per frame when one was
@@ -906,6 +914,18 @@ extern "C" int mocap_match_triangulate_auto(mocap_ctx* ctx, int64_t n_frames, in
   // worst-case root capacity: every blob its own root (never less than the caller asked for)
   int K_big = C * M_max < 1024 ? C * M_max : 1024;
   if (K_big < K_max) K_big = K_max;
+  {  // ... as far as the frame state fits a kernel (64 cameras x 256 blobs: the per-root tables of the wide variant end at
+     // a few hundred roots); a frame with more roots than that keeps its root-overflow status
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (!frame_shape_fits(ctx, M_max, K_big)) {
+      int lo = K_max, hi = K_big;  // largest K in [K_max, K_big) that fits (K_max itself ran, or failed, above)
+      while (lo < hi) {
+        const int mid = (lo + hi + 1) / 2;
+        if (frame_shape_fits(ctx, M_max, mid)) lo = mid; else hi = mid - 1;
+      }
+      K_big = lo;
+    }
+  }
   const size_t fb = (size_t)C * M_max * 2;
   std::vector<float> b2(nb * fb);
   std::vector<int32_t> c2(nb * C), n2(nb), s2(nb), g2(nb);

@@ -67,9 +67,9 @@ namespace mocap {
 // place from the input batch.  Same code either way: the arrays are reached through pointers.
 struct FrameLayout {
   // byte offsets, computed identically on host (sizes) and device (carving)
-  size_t line, dist, seg_e, seg_x, seg_g, goff, gcnt, outslot, root_blob, root_cam, claimed, claimw, hl_d, hl_k, nact,
-      cnt, misc, rbound, lds_total;                  // always LDS
-  size_t bxy, cxy, hits, dig, nh, act;               // LDS when narrow, workspace when wide
+  size_t line, dist, seg_e, seg_x, seg_g, goff, gcnt, outslot, root_blob, root_cam, claimed, claimw, nact,
+      cnt, misc, rbound, h0, nhc, lds_total;         // always LDS
+  size_t bxy, cxy, hits, dig, nh, act;               // narrow: LDS.  wide: hits / nh (exact counts of the multi-hit pairs) in the workspace, the rest unused
   size_t bt;                                          // table mode: DLT contribution per (camera, blob)
   size_t ws_total;
   int Hs;  // hit-list capacity per (root, camera): M when narrow (no cap), H when wide
@@ -79,11 +79,11 @@ struct FrameLayout {
   __host__ __device__ FrameLayout(int C, int M, int R, int T, int H, bool wide, bool table) {
     Hs = wide ? H : M;
     size_t o = 0;
-    line = o;      o += sizeof(double) * kLineStride * R;
+    line = o;      o += wide ? 0 : sizeof(double) * kLineStride * R;   // wide: the lines stay in registers (match_pairs_wide)
     seg_e = o;     o += sizeof(double) * (T + R);
     seg_x = o;     o += sizeof(double) * 3 * (T + R);
     // dist (phase B scratch) and the segment arrays (phase D/E) are never live together
-    dist = line + sizeof(double) * kLineStride * R;
+    dist = line + (wide ? 0 : sizeof(double) * kLineStride * R);
     const size_t dist_n = wide ? 0 : ((size_t)R * M > (size_t)T ? (size_t)R * M : (size_t)T);
     const size_t dist_end = dist + sizeof(double) * dist_n;
     if (dist_end > o) o = dist_end;
@@ -96,27 +96,29 @@ struct FrameLayout {
     misc = o;      o += sizeof(int32_t) * 8;
     root_blob = o; o += sizeof(uint16_t) * R;
     root_cam = o;  o += R;
-    claimed = o;   o += M;
-    nact = o;      o += R;
+    claimed = o;   o += wide ? 0 : M;
+    nact = o;      o += wide ? 0 : R;
     o = align(o, 16);
     // wide: blobs claimed so far per camera, 64 per word (match_wide)
     o = align(o, 8);
     claimw = o;    o += wide ? sizeof(unsigned long long) * (size_t)C * ((M + 63) / 64) : 0;
-    // wide: one list of gated blobs per wave (distance, index) for the (root, camera) pairs with several hits; holds a
-    // whole camera (kMaxBlobs), so a re-submit with an uncapped hit list (H = M) never truncates
-    hl_d = o;      o += wide ? sizeof(double) * (size_t)(T / 64) * kMaxBlobs : 0;
-    hl_k = o;      o += wide ? (size_t)(T / 64) * kMaxBlobs : 0;
+    // wide: THE state of a frame's matching, LDS-resident: per (root, camera) the closest hit's blob index and the number
+    // of gated hits (saturating at 255).  Almost every pair of a wide frame has exactly one hit (the marker's own
+    // blob), so these two bytes are all a candidate group is ever decoded from; the full hit lists of the rare
+    // multi-hit pairs (and their exact counts) sit in the HBM workspace and are touched only for those pairs.
+    h0 = o;        o += wide ? (size_t)R * C : 0;
+    nhc = o;       o += wide ? (size_t)R * C : 0;
     o = align(o, 16);
     size_t w = wide ? 0 : o;  // the movable arrays continue in LDS, or start a workspace
-    cxy = w;       w += table ? (size_t)C * T : sizeof(float2) * (size_t)C * T;
+    cxy = w;       w += wide ? 0 : (table ? (size_t)C * T : sizeof(float2) * (size_t)C * T);
     w = align(w, 16);
     bt = w;        w += table ? sizeof(double) * 10 * (size_t)C * M : 0;
     bxy = w;       w += wide ? 0 : sizeof(float2) * (size_t)C * M;
     nh = w;        w += sizeof(uint16_t) * (size_t)R * C;
     hits = w;      w += (size_t)R * C * Hs;
     w = align(w, 8);  // (the branch-and-bound variant keeps doubles here)
-    dig = w;       w += (size_t)C * T;
-    act = w;       w += (size_t)R * C;
+    dig = w;       w += wide ? 0 : (size_t)C * T;
+    act = w;       w += wide ? 0 : (size_t)R * C;
     w = align(w, 256);
     lds_total = wide ? o : align(w, 16);
     ws_total = wide ? w : 0;
@@ -146,8 +148,8 @@ struct FrameState {
   uint8_t *dig;   // [C][T]    this lane's odometer digits
   uint8_t *root_cam, *claimed, *act, *nact;  // act [R][C]: cameras of root r with >= 2 hits
   unsigned long long* claimw;  // wide: [C][ceil(M / 64)] blobs claimed so far (match_wide)
-  double* hl_d;                // wide: [T / 64][kMaxBlobs] a wave's list of gated blobs: distances ...
-  uint8_t* hl_k;               // ... and blob indices
+  uint8_t* h0;                 // wide: [R][C] blob index of the closest gated hit (the root's own blob at its camera)   (LDS)
+  uint8_t* nhc;                // wide: [R][C] number of gated hits, saturating at 255 (1 at the root's camera, 0 before it) (LDS)
 
   __device__ FrameState(const FrameArgs& p_, unsigned char* smem)
       : p(p_), cv(p_.cv), C(p_.cv.C), M(p_.M), R(p_.K_max), tid(threadIdx.x) {
@@ -179,8 +181,26 @@ struct FrameState {
     nh = (uint16_t*)(big + L.nh);
     act = (uint8_t*)(big + L.act);
     claimw = (unsigned long long*)(smem + L.claimw);
-    hl_d = (double*)(smem + L.hl_d);
-    hl_k = (uint8_t*)(smem + L.hl_k);
+    h0 = smem + L.h0;
+    nhc = smem + L.nhc;
+  }
+
+  // gated hits of root r in camera c (wide: the LDS byte, or the exact count from the workspace when it saturated)
+  __device__ __forceinline__ uint32_t nhits(int r, int c) const {
+    if constexpr (WIDE) {
+      const uint32_t n = nhc[(size_t)r * C + c];
+      return n < 255u ? n : (uint32_t)nh[(size_t)r * C + c];
+    } else {
+      return nh[(size_t)r * C + c];
+    }
+  }
+  // blob index of root r's d-th closest hit in camera c (d < nhits(r, c))
+  __device__ __forceinline__ uint32_t hit_at(int r, int c, uint32_t d) const {
+    if constexpr (WIDE) {
+      return d == 0 ? (uint32_t)h0[(size_t)r * C + c] : (uint32_t)hits[((size_t)r * C + c) * Hs + d];
+    } else {
+      return hits[((size_t)r * C + c) * Hs + d];
+    }
   }
 
   // ---------------------------------------------------------------- phases A-C
@@ -423,8 +443,6 @@ struct FrameState {
     const int lane = tid & 63, wave = tid >> 6;
     const int H = p.H, MW = (M + 63) / 64;
     const double om = (double)__int_as_float(misc[MI_OMAX]);
-    double* hbd = hl_d + (size_t)wave * kMaxBlobs;  // this wave's list of gated blobs
-    uint8_t* hbk = hl_k + (size_t)wave * kMaxBlobs;
     for (int i = clo + wave; i < C; i += W) {  // wave-uniform
       const int Mi = cnt[i];
       const float2* row = bxy + (size_t)i * M;
@@ -434,7 +452,9 @@ struct FrameState {
       for (int sg = 0; sg < 4; sg++) {
         const int k = 64 * sg + lane;
         ok[sg] = k < Mi;
-        bl[sg] = ok[sg] ? row[k] : make_float2(0.f, 0.f);
+        // slots beyond the camera's count hold +inf: the pre-test's |fl(a x + b y + c)| <= thr is false for them
+        // (inf or NaN), no separate validity test in the inner loop
+        bl[sg] = ok[sg] ? row[k] : make_float2(__int_as_float(0x7f800000), __int_as_float(0x7f800000));
       }
       for (int rb = rlo; rb < rhi; rb += 64) {
         const int r = rb + lane;
@@ -470,7 +490,7 @@ struct FrameState {
         const float a32 = (float)la, b32 = (float)lb, c32 = (float)lc;
         float thr = __int_as_float(0x7f800000);
         if (F32R) thr = __double2float_ru(p.gate_px * lden * (1.0 + 1e-12) + (2.5 * 0x1p-24) * (2.0 * om + fabs(lc)) * (1.0 + 1e-6));
-        int my_nh = 0;
+        int my_nh = 0, my_k0 = 0;
         // the usual outcome of a (root, camera) pair: ONE blob passes the pre-test (the marker's own blob).  It is handed
         // to the lane that holds the root's line (its coordinates travel, not the line), and the exact decision is
         // taken for the batch's 64 roots at once after the loop.
@@ -486,11 +506,33 @@ struct FrameState {
           unsigned long long pmask[4];
 #pragma unroll
           for (int sg = 0; sg < 4; sg++) {
-            pm[sg] = ok[sg] && fabsf(fmaf(fa, bl[sg].x, fmaf(fb, bl[sg].y, fc))) <= ft;
+            pm[sg] = fabsf(fmaf(fa, bl[sg].x, fmaf(fb, bl[sg].y, fc))) <= ft;
+            if (!F32R) pm[sg] = ok[sg];  // (thr = +inf would let the +inf padding's NaN through as "false": keep it explicit)
             pmask[sg] = __ballot(pm[sg]);
           }
+#ifdef MOCAP_DEBUG_PRETEST  // self-check build: the exact decision (helpers.py:373,375) for EVERY blob the float32 pre-test
+          {                    // rejected; a blob inside the gate among them is a false negative (must never happen)
+            auto bc = [&](double v) {
+              const long long bits = __double_as_longlong(v);
+              return __longlong_as_double(((long long)__builtin_amdgcn_readlane((int)(bits >> 32), q) << 32) |
+                                          (unsigned int)__builtin_amdgcn_readlane((int)bits, q));
+            };
+            const double qa = bc(la), qb = bc(lb), qc = bc(lc), qden = bc(lden), qrden = bc(lrden);
+            int fneg = 0;
+#pragma unroll
+            for (int sg = 0; sg < 4; sg++)
+              if (ok[sg] && !pm[sg] && div_by(fabs(qa * (double)bl[sg].x + qb * (double)bl[sg].y + qc), qden, qrden) < p.gate_px) fneg++;
+            if (lane == 0) atomicAdd(&p.status[p.n_frames], 1);
+            if (fneg) {
+              atomicAdd(&p.status[p.n_frames + 1], fneg);
+              printf("PRETEST false negative: root %d camera %d lane %d line %.9g %.9g %.9g thr %.9g omax %g\n", rb + q, i, lane, qa, qb, qc,
+                     (double)ft, om);
+            }
+          }
+#endif
+          const unsigned long long any01 = pmask[0] | pmask[1], any23 = pmask[2] | pmask[3];
+          if (!(any01 | any23)) continue;
           const int npass = __popcll(pmask[0]) + __popcll(pmask[1]) + __popcll(pmask[2]) + __popcll(pmask[3]);
-          if (!npass) continue;
           if (npass == 1) {
             float cx, cy;
             int ck;
@@ -523,20 +565,20 @@ struct FrameState {
             continue;
           }
           // ---- rare: several blobs within reach of the gate; the line in double, the decision of helpers.py:373,375
-          auto bcast = [&](double v) {
+          auto bcast = [&](double v, int l) {
             const long long bits = __double_as_longlong(v);
-            return __longlong_as_double(((long long)__builtin_amdgcn_readlane((int)(bits >> 32), q) << 32) |
-                                        (unsigned int)__builtin_amdgcn_readlane((int)bits, q));
+            return __longlong_as_double(((long long)__builtin_amdgcn_readlane((int)(bits >> 32), l) << 32) |
+                                        (unsigned int)__builtin_amdgcn_readlane((int)bits, l));
           };
-          const double qa = bcast(la), qb = bcast(lb), qc = bcast(lc), qden = bcast(lden), qrden = bcast(lrden);
+          const double qa = bcast(la, q), qb = bcast(lb, q), qc = bcast(lc, q), qden = bcast(lden, q), qrden = bcast(lrden, q);
           double dd[4] = {0.0, 0.0, 0.0, 0.0};
           bool hit[4] = {false, false, false, false};
           unsigned long long hmask[4] = {0ull, 0ull, 0ull, 0ull};
           int nhits = 0;
 #pragma unroll
           for (int sg = 0; sg < 4; sg++) {
-            if (!__ballot(pm[sg])) continue;  // wave-uniform: usually one segment of the four has a candidate
-            if (pm[sg]) {
+            if (!pmask[sg]) continue;  // wave-uniform: usually one segment of the four has a candidate
+            if (pm[sg] && ok[sg]) {
               dd[sg] = div_by(fabs(qa * (double)bl[sg].x + qb * (double)bl[sg].y + qc), qden, qrden);
               hit[sg] = dd[sg] < p.gate_px;  // strict <, helpers.py:375,383
             }
@@ -545,49 +587,49 @@ struct FrameState {
           }
           if (!nhits) continue;
           if (nhits > H) atomicOr(&misc[MI_STATUS], MOCAP_ST_HIT_OVERFLOW_);
-          uint8_t* hl = hits + ((size_t)(rb + q) * C + i) * Hs;
-          if (lane == q) my_nh = nhits < H ? nhits : H;
           if (nhits == 1) {
-            // the usual case: the one blob inside the gate is the closest hit and claims itself (helpers.py:391)
+            // the one blob inside the gate is the closest hit and claims itself (helpers.py:391)
+            int k1 = 0;
 #pragma unroll
             for (int sg = 0; sg < 4; sg++)
-              if (hit[sg]) {
-                hl[0] = (uint8_t)(64 * sg + lane);
-                atomicOr(&claimw[(size_t)i * MW + sg], 1ull << lane);
-              }
+              if (hmask[sg]) k1 = 64 * sg + (__ffsll((long long)hmask[sg]) - 1);
+#pragma unroll
+            for (int sg = 0; sg < 4; sg++)
+              if (hit[sg]) atomicOr(&claimw[(size_t)i * MW + sg], 1ull << lane);
+            if (lane == q) {
+              my_nh = 1;
+              my_k0 = k1;
+            }
             continue;
           }
-          // several hits: through the wave's list, out in (distance, blob index) order -- stable where NumPy's default
-          // argsort is not (helpers.py:384; documented deviation)
-          int base = 0;
+          // several hits: ranked by (distance, blob index) -- stable where NumPy's default argsort is not (helpers.py:384;
+          // documented deviation) -- among the lanes that hold them: every hit's (d, k) is broadcast once and compared
+          // with the (at most four) hits of every lane.  The list goes to the workspace in HBM (this is the rare case).
+          int rank[4] = {0, 0, 0, 0};
+#pragma unroll
+          for (int s2 = 0; s2 < 4; s2++) {
+            unsigned long long mm = hmask[s2];
+            while (mm) {  // wave-uniform
+              const int l2 = __ffsll((long long)mm) - 1;
+              mm &= mm - 1;
+              const double d2 = bcast(dd[s2], l2);
+              const int k2 = 64 * s2 + l2;
+#pragma unroll
+              for (int sg = 0; sg < 4; sg++) rank[sg] += (hit[sg] && (d2 < dd[sg] || (d2 == dd[sg] && k2 < 64 * sg + lane))) ? 1 : 0;
+            }
+          }
+          uint8_t* hl = hits + ((size_t)(rb + q) * C + i) * Hs;
+          int k0 = 0;
 #pragma unroll
           for (int sg = 0; sg < 4; sg++) {
-            if (hit[sg]) {
-              const int pos = base + __popcll(hmask[sg] & ((1ull << lane) - 1ull));
-              hbd[pos] = dd[sg];  // (pos < kMaxBlobs: a camera has no more blobs)
-              hbk[pos] = (uint8_t)(64 * sg + lane);
-            }
-            base += __popcll(hmask[sg]);
+            if (hit[sg] && rank[sg] < H) hl[rank[sg]] = (uint8_t)(64 * sg + lane);
+            const unsigned long long first = __ballot(hit[sg] && rank[sg] == 0);
+            if (first) k0 = 64 * sg + (__ffsll((long long)first) - 1);  // wave-uniform
           }
-          const int n = nhits;
-          wave_lds_sync();
-          int k0 = 0;
-          for (int e0 = 0; e0 < n; e0 += 64) {  // wave-uniform; one pass unless a pair has more than 64 hits
-            const int e = e0 + lane;
-            int rank = -1, k = 0;
-            if (e < n) {
-              const double d = hbd[e];
-              k = hbk[e];
-              rank = 0;
-              for (int m2 = 0; m2 < n; m2++) {
-                const double d2 = hbd[m2];
-                const int k2 = hbk[m2];
-                rank += (d2 < d || (d2 == d && k2 < k)) ? 1 : 0;
-              }
-              if (rank < H) hl[rank] = (uint8_t)k;
-            }
-            const unsigned long long first = __ballot(rank == 0);
-            if (first) k0 = __builtin_amdgcn_readlane(k, __ffsll((long long)first) - 1);  // wave-uniform
+          if (lane == q) {
+            my_nh = nhits < H ? nhits : H;
+            my_k0 = k0;
+            nh[(size_t)(rb + q) * C + i] = (uint16_t)my_nh;  // the exact count (the LDS byte saturates at 255)
           }
           // the closest hit's coordinates claim every blob that has them (helpers.py:391): such a blob has the same
           // distance, so it is among the hits; the coordinates come from the registers that hold the camera's blobs
@@ -603,16 +645,18 @@ struct FrameState {
             const unsigned long long cm = __ballot(hit[sg] && bl[sg].x == p0x && bl[sg].y == p0y);
             if (cm && lane == 0) atomicOr(&claimw[(size_t)i * MW + sg], cm);
           }
-          wave_lds_sync();  // the list is reused by the next root
         }
         if (cand_k >= 0) {  // single candidates: helpers.py:373 in double, strict < (helpers.py:375,383); a lone hit claims itself
           if (div_by(fabs(la * (double)cand_x + lb * (double)cand_y + lc), lden, lrden) < p.gate_px) {
-            hits[((size_t)r * C + i) * Hs] = (uint8_t)cand_k;
             atomicOr(&claimw[(size_t)i * MW + (cand_k >> 6)], 1ull << (cand_k & 63));
             my_nh = 1;
+            my_k0 = cand_k;
           }
         }
-        if (have) nh[(size_t)r * C + i] = (uint16_t)my_nh;
+        if (have) {
+          h0[(size_t)r * C + i] = (uint8_t)my_k0;
+          nhc[(size_t)r * C + i] = (uint8_t)(my_nh < 255 ? my_nh : 255);
+        }
       }
     }
   }
@@ -648,6 +692,14 @@ struct FrameState {
       for (int r = tid; r < n0; r += T) {
         root_cam[r] = 0;
         root_blob[r] = (uint16_t)r;
+      }
+      // a root's own camera counts as one "hit" (its blob), the cameras before it as none: a candidate group is decoded
+      // from these two bytes per camera alone
+      const int ncam0 = (MOCAP_WIDE_DEBUG_SKIP & 1) ? C : 1;
+      for (int idx = tid; idx < n0 * ncam0; idx += T) {
+        const int r = idx / ncam0, c = idx - r * ncam0;
+        nhc[(size_t)r * C + c] = c == 0 ? 1 : 0;
+        h0[(size_t)r * C + c] = (uint8_t)r;
       }
       if (tid == 0) {
         misc[MI_NROOTS] = n0;
@@ -690,8 +742,16 @@ struct FrameState {
       }
       __syncthreads();
       const int now = misc[MI_NROOTS];
-      if (now > n_roots && j + 1 < C && !(MOCAP_WIDE_DEBUG_SKIP & 2)) {  // workgroup-uniform
-        match_pairs_wide(n_roots, now, j + 1);
+      if (now > n_roots) {  // workgroup-uniform
+        // cameras up to the root's own (the pairs with the cameras after it are written by match_pairs_wide below, by
+        // other waves at the same time: the two must not touch the same bytes)
+        const int ncam = (MOCAP_WIDE_DEBUG_SKIP & 2) ? C : j + 1;
+        for (int idx = tid; idx < (now - n_roots) * ncam; idx += T) {
+          const int r = n_roots + idx / ncam, c = idx % ncam;
+          nhc[(size_t)r * C + c] = c == j ? 1 : 0;
+          h0[(size_t)r * C + c] = (uint8_t)root_blob[r];
+        }
+        if (j + 1 < C && !(MOCAP_WIDE_DEBUG_SKIP & 2)) match_pairs_wide(n_roots, now, j + 1);
         __syncthreads();
       }
       n_roots = now;
@@ -708,8 +768,10 @@ struct FrameState {
       int views = 1, na = 0;
       bool over = false;
       for (int c = rc + 1; c < C; c++) {
-        const unsigned n = nh[(size_t)r * C + c];
-        if (n > 1) act[(size_t)r * C + na++] = (uint8_t)c;  // the digits an odometer step can change
+        const unsigned n = nhits(r, c);
+        if constexpr (!WIDE) {
+          if (n > 1) act[(size_t)r * C + na++] = (uint8_t)c;  // the digits an odometer step can change
+        }
         if (n) {
           views++;
           total *= n;
@@ -720,7 +782,7 @@ struct FrameState {
         }
       }
       if (over) atomicOr(&misc[MI_STATUS], MOCAP_ST_CAND_OVERFLOW_);
-      nact[r] = (uint8_t)na;
+      if constexpr (!WIDE) nact[r] = (uint8_t)na;
       rbound[r] = 0x7ff0000000000000ull;
       gcnt[r] = (views > 1 && !over) ? (uint32_t)total : 0u;  // helpers.py:413-414 drops 1-view roots
     }
@@ -766,41 +828,6 @@ struct FrameState {
     const uint8_t* hr = hits + (size_t)r * C * Hs;
     const float qn = __int_as_float(0x7fc00000);
     uint32_t rem = gl;
-    if constexpr (WIDE) {
-      // wide frames: hit counts, hit lists and blobs sit in device memory (workspace / input batch) -- eight cameras per
-      // step, each of the three dependent reads issued for all eight before any is used (one round trip per step and
-      // stage instead of one per camera and stage: 24 instead of 192 at 64 cameras)
-      for (int c0 = 0; c0 < C; c0 += 8) {
-        uint32_t n[8], dg[8];
-        uint16_t sl[8];
-        float2 ob[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) n[u] = (c0 + u < C && c0 + u > rc) ? nhr[c0 + u] : 0u;
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-          dg[u] = 0;
-          if (n[u] && !FIRST) {
-            uint32_t qd;
-            divmod_small(rem, n[u], qd, dg[u]);
-            rem = qd;
-          }
-        }
-        uint8_t hv[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) hv[u] = n[u] ? hr[(size_t)(c0 + u) * Hs + dg[u]] : (uint8_t)0;
-#pragma unroll
-        for (int u = 0; u < 8; u++) sl[u] = (c0 + u == rc) ? rb : (n[u] ? (uint16_t)hv[u] : kNone);
-#pragma unroll
-        for (int u = 0; u < 8; u++) ob[u] = (c0 + u < C && sl[u] != kNone) ? bxy[(size_t)(c0 + u) * M + sl[u]] : make_float2(qn, qn);
-#pragma unroll
-        for (int u = 0; u < 8; u++)
-          if (c0 + u < C) {
-            dig[(size_t)(c0 + u) * T] = (uint8_t)dg[u];
-            cxy[(size_t)(c0 + u) * T] = ob[u];
-          }
-      }
-      return;
-    }
     for (int c = 0; c < C; c++) {
       uint16_t s = kNone;
       uint32_t dgt = 0;
@@ -858,7 +885,7 @@ struct FrameState {
       }
       int r = lo;
       uint32_t r_beg = goff[r], r_end = goff[r + 1];
-      load_group<false>(r, g - r_beg);
+      if constexpr (!WIDE) load_group<false>(r, g - r_beg);
       double best_e = __builtin_huge_val(), best_X[3] = {0, 0, 0};
       uint32_t best_g = 0;
       bool have = false;
@@ -879,6 +906,48 @@ struct FrameState {
         __device__ __forceinline__ bool operator()(int c, double& x, double& y) const { return decode(raw(c), x, y); }
       };
       const ColumnObs obs{cxy};
+      // Wide frames: no per-lane group column at all.  A candidate group is DECODED while it is evaluated: camera c of
+      // group gl of root r is the root's only hit there (one LDS byte -- almost every pair), or, for the few cameras with
+      // several hits, the digit of gl in the mixed radix of those cameras (helpers.py:394-400 order: the first camera
+      // after the root's is the fastest digit), peeled off by one small division as the pass walks the cameras in
+      // ascending order.  Each pass (DLT, depths, reprojection) starts at camera 0, which resets the remainder.  The
+      // blobs are read in place from the input batch (L2); nothing per candidate is written anywhere.
+      struct WideObs {
+        const uint8_t* h0r;     // LDS [C]: closest hit per camera of the current root
+        const uint8_t* nhr;     // LDS [C]: hit count (saturating)
+        const uint16_t* nh16r;  // workspace [C]: exact counts (read only where the byte saturated)
+        const uint8_t* hitsr;   // workspace [C][Hs]: full hit lists of the multi-hit pairs
+        const float2* blobs;    // the frame's blobs [C][M]
+        int M, Hs;
+        uint32_t gl;
+        uint32_t rem;
+        __device__ __forceinline__ unsigned long long raw(int c) {
+          if (c == 0) rem = gl;
+          uint32_t n = nhr[c];
+          unsigned long long w = 0x7fc000007fc00000ull;  // NaN, NaN: camera not in the group
+          if (n) {
+            uint32_t k = h0r[c];
+            if (n > 1) {
+              if (n == 255u) n = nh16r[c];
+              uint32_t qd, dg;
+              divmod_small(rem, n, qd, dg);
+              rem = qd;
+              if (dg) k = hitsr[(size_t)c * Hs + dg];
+            }
+            w = *reinterpret_cast<const unsigned long long*>(blobs + (size_t)c * M + k);
+          }
+          return w;
+        }
+        __device__ __forceinline__ bool decode(unsigned long long w, double& x, double& y) const {
+          const float fx = __uint_as_float((uint32_t)w), fy = __uint_as_float((uint32_t)(w >> 32));
+          if (fx != fx) return false;
+          x = (double)fx;
+          y = (double)fy;
+          return true;
+        }
+        __device__ __forceinline__ bool operator()(int c, double& x, double& y) { return decode(raw(c), x, y); }
+      };
+      WideObs wobs{h0 + (size_t)r * C, nhc + (size_t)r * C, nh + (size_t)r * C, hits + (size_t)r * C * Hs, bxy, M, Hs, g - r_beg, 0u};
       // table mode: the column holds blob indices; 0xFF marks "camera not in the group"
       auto contrib = [&](int c, double (&B)[10]) -> bool {
         const uint32_t k = cix[(size_t)c * T];
@@ -917,13 +986,17 @@ struct FrameState {
           X[0] = X[1] = X[2] = 0.0;
         } else if constexpr (TABLE)
           triangulate_and_score_tab<true, F32R>(cv, contrib, obs_ix, X, e, bound, ec);
+        else if constexpr (WIDE)
+          triangulate_and_score<UNIFORM_K, true, F32R, MOCAP_WIDE_BATCH>(cv, wobs, wobs, X, e, bound, ec);
         else
-          triangulate_and_score<UNIFORM_K, true, F32R, (WIDE ? MOCAP_WIDE_BATCH : 1)>(cv, obs, obs, X, e, bound, ec);
+          triangulate_and_score<UNIFORM_K, true, F32R, 1>(cv, obs, obs, X, e, bound, ec);
 #ifdef MOCAP_DEBUG_EIGCHECK  // self-check of the cut-offs: a group that was cut must not beat the bound it was cut against
         if (!(e < inf)) {
           double X2[3], e2;
           if constexpr (TABLE)
             triangulate_and_score_tab<true, F32R>(cv, contrib, obs_ix, X2, e2);
+          else if constexpr (WIDE)
+            triangulate_and_score<UNIFORM_K, true, F32R>(cv, wobs, wobs, X2, e2);
           else
             triangulate_and_score<UNIFORM_K, true, F32R>(cv, obs, obs, X2, e2);
           if (e2 <= bound)
@@ -959,9 +1032,17 @@ struct FrameState {
           do { r++; } while (goff[r + 1] <= g);
           r_beg = goff[r];
           r_end = goff[r + 1];
-          load_group<true>(r, 0);
+          if constexpr (WIDE) {
+            wobs.h0r = h0 + (size_t)r * C;
+            wobs.nhr = nhc + (size_t)r * C;
+            wobs.nh16r = nh + (size_t)r * C;
+            wobs.hitsr = hits + (size_t)r * C * Hs;
+            wobs.gl = 0;
+          } else {
+            load_group<true>(r, 0);
+          }
         } else {
-          next_group(r);
+          if constexpr (WIDE) wobs.gl = g - r_beg; else next_group(r);
         }
       }
       const int s = tid + outslot[r];
@@ -1013,11 +1094,11 @@ struct FrameState {
       if (c == rc) {
         s = (int16_t)root_blob[r];
       } else if (c > rc) {
-        const uint32_t n = nh[(size_t)r * C + c];
+        const uint32_t n = nhits(r, c);
         if (n) {
           uint32_t qd, dgt;
           divmod_small(rem, n, qd, dgt);
-          s = (int16_t)hits[((size_t)r * C + c) * Hs + dgt];
+          s = (int16_t)hit_at(r, c, dgt);
           rem = qd;
         }
       }

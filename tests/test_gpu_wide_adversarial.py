@@ -1,0 +1,288 @@
+"""GPU: the wide variant of the frame path (csrc/frame_kernel.hip match_pairs_wide; BASELINE.json configs[4], 64 cameras x
+256 markers) drops most (root, camera, blob) triples on a float32 pre-test with a rigorous error bound before the exact
+double decision of helpers.py:373,375.  "Dropped without evaluating" is where a bit-exact path can go wrong silently, so
+it is attacked here the way tests/test_gpu_bb_adversarial.py attacks the branch and bound:
+  * 256 stress frames against the C oracle (indices exact, points to 1e-9);
+  * blobs placed on float32 neighbours either side of distance == gate, duplicate pixels, heavy dropout, rigs in
+    millimetres, 16 k-pixel coordinates, random rigs (Hypothesis), all against the C oracle;
+  * a self-check build (-DMOCAP_DEBUG_PRETEST) that takes the exact decision on the device for every blob the pre-test
+    rejected and counts false negatives (must be 0; counters prove it ran);
+  * candidate-cap overflow at the stress shape, repaired by the re-submit path."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _compare(core, rig, blobs, counts, gate, K_max, G_cap=1 << 20, force_wide=False, min_points=1):
+    from oracle import c_oracle
+    core.set_cameras(rig["K"], rig["R"], rig["t"])
+    try:
+        if force_wide:
+            core.set_frame_limits(hit_cap=32, force_wide=True)
+        res = core.match_triangulate_auto(blobs, counts, gate_px=gate, K_max=K_max, G_cap=G_cap)
+        assert core.last_frame_kernel() == "frame_kernel<1024, wide>", core.last_frame_kernel()
+    finally:
+        if force_wide:
+            core.set_frame_limits(hit_cap=32, force_wide=False)
+    # the oracle walks every candidate group (as the reference does): frames above 2^20 groups for one root would take it
+    # minutes each and are left out of the comparison (status 2 on its side)
+    ref = c_oracle.COracle(rig["K"], rig["R"], rig["t"]).match_triangulate(blobs, counts, gate_px=gate, K_max=K_max, G_cap=1 << 20)
+    ok = ref["status"] == 0
+    assert ok.any()
+    assert np.array_equal(res["status"][ok], ref["status"][ok])
+    assert np.array_equal(res["n_out"][ok], ref["n_out"][ok]) and ref["n_out"][ok].sum() >= min_points
+    assert np.array_equal(res["n_cand"][ok], ref["n_cand"][ok])
+    kk = min(res["corr"].shape[1], ref["corr"].shape[1])
+    valid = (np.arange(kk)[None, :] < ref["n_out"][:, None]) & ok[:, None]
+    assert np.array_equal(res["corr"][:, :kk][valid], ref["corr"][:, :kk][valid])          # bit-exact indices
+    np.testing.assert_allclose(res["xyz"][:, :kk][valid], ref["xyz"][:, :kk][valid], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(res["err"][:, :kk][valid], ref["err"][:, :kk][valid], rtol=1e-3, atol=1e-12)
+    return res, ref
+
+
+def test_256_stress_frames_vs_c_oracle(core):
+    """BASELINE.json configs[4] at its own shape, 256 frames (round 3 checked 3)."""
+    from mocap_core import synth
+    rig = synth.stress_rig(64)
+    blobs, counts, _ = synth.make_stress_stream(rig, 256, 256, seed=4242)
+    res, ref = _compare(core, rig, blobs, counts, synth.STRESS_GATE_PX, K_max=384, min_points=256 * 200)
+    assert ref["n_cand"].max() > 3000          # frames with real multi-hit pairs are in the set
+
+
+def _gate_straddlers(rig, blobs, counts, gate, rng, pairs_per_frame=6):
+    """Overwrite blobs of cameras i >= 1 with float32 points whose exact distance (helpers.py:373) from the epipolar line
+    of a camera-0 blob is just below / just at-or-above the gate: for each chosen (root, camera) two float32 neighbours
+    x_lo, x_hi (same y) with d(x_lo) < gate <= d(x_hi), found by bisection over the float32 ordinals."""
+    from oracle import mocap_oracle as mo
+    F, C, M, _ = blobs.shape
+    Ftab = mo.fundamental_table(rig["K"], rig["R"], rig["t"])
+    made = 0
+    for f in range(F):
+        for _ in range(pairs_per_frame):
+            r = int(rng.integers(0, max(1, counts[f, 0])))
+            i = int(rng.integers(1, C))
+            if counts[f, 0] == 0 or counts[f, i] < 4:
+                continue
+            a, b, c = mo.epiline(Ftab[0, i], blobs[f, 0, r])
+            if abs(a) < 0.05:
+                continue
+            den = np.sqrt(a ** 2 + b ** 2)
+
+            def dist(x32, y32):
+                return abs(a * float(x32) + b * float(y32) + c) / den
+
+            y = np.float32(rng.uniform(2000, 14000)) if blobs[f].max() > 1000 else np.float32(rng.uniform(40, 280))
+            side = 1.0 if rng.random() < 0.5 else -1.0
+            x_on = (-(b * float(y) + c)) / a                       # on the line
+            x_in = np.float32(x_on + side * 0.5 * gate * den / abs(a))
+            x_out = np.float32(x_on + side * 1.5 * gate * den / abs(a))
+            if not (dist(x_in, y) < gate <= dist(x_out, y)):
+                continue
+            lo, hi = x_in.view(np.int32).item(), x_out.view(np.int32).item()
+            if (lo < 0) != (hi < 0):
+                continue
+            step = 1 if hi > lo else -1
+            while abs(hi - lo) > 1:
+                mid = (lo + hi) // 2
+                if dist(np.int32(mid).view(np.float32), y) < gate:
+                    lo = mid
+                else:
+                    hi = mid
+            x_lo, x_hi = np.int32(lo).view(np.float32), np.int32(hi).view(np.float32)
+            assert dist(x_lo, y) < gate <= dist(x_hi, y) and step
+            k = int(counts[f, i]) - 1 - 2 * int(rng.integers(0, 2))     # replace two existing blobs near the end
+            blobs[f, i, k] = (x_lo, y)
+            blobs[f, i, k - 1] = (x_hi, y)
+            made += 1
+    return made
+
+
+@pytest.mark.parametrize("shape", ["stress64x256", "px320_forced_wide"])
+def test_blobs_on_either_side_of_the_gate(core, shape):
+    from mocap_core import synth
+    rng = np.random.default_rng(7)
+    if shape == "stress64x256":
+        rig = synth.stress_rig(64)
+        blobs, counts, _ = synth.make_stress_stream(rig, 24, 256, seed=77)
+        gate, K_max, fw = synth.STRESS_GATE_PX, 512, False
+    else:
+        rig = synth.ring_rig(8)
+        blobs, counts, _ = synth.make_blob_stream(rig, 200, 16, seed=78)
+        gate, K_max, fw = 5.0, 128, True
+    made = _gate_straddlers(rig, blobs, counts, gate, rng)
+    assert made > 60
+    _compare(core, rig, blobs, counts, gate, K_max=K_max, G_cap=1 << 24, force_wide=fw)
+
+
+def test_duplicate_pixels_and_heavy_dropout(core):
+    """Duplicate coordinates inside a camera (claimed by value, helpers.py:391) and 50 % dropout (many roots from cameras
+    after the first: the chain that creates roots is where the wide variant differs most from the narrow one)."""
+    from mocap_core import synth
+    rig = synth.stress_rig(64)
+    blobs, counts, _ = synth.make_blob_stream(rig, 16, 256, seed=5, noise_px=0.02, dropout=0.5, half_extent=1.5, min_sep=0.05,
+                                              truncate=False)
+    rng = np.random.default_rng(9)
+    for f in range(blobs.shape[0]):
+        for i in rng.choice(64, size=20, replace=False):
+            n = int(counts[f, i])
+            if n >= 6:
+                a, b = rng.choice(n, size=2, replace=False)
+                blobs[f, i, a] = blobs[f, i, b]
+    res, ref = _compare(core, rig, blobs, counts, synth.STRESS_GATE_PX, K_max=600, G_cap=1 << 24)
+    assert ref["n_out"].max() > 256            # kept roots created by cameras 1..: more points than camera 0 has blobs
+
+
+def test_rig_in_millimetres_and_tiny_gate(core):
+    """World units do not enter the pre-test's bound (the line is normalised), coordinates do: a rig in millimetres with
+    16 k-pixel coordinates, and a gate far below the float32 resolution of the coordinates' products."""
+    from mocap_core import synth
+    rig = synth.ring_rig(64, radius=3000.0, height=1500.0, K=synth.STRESS_K, image_size=(16000, 16000))
+    blobs, counts, _ = synth.make_blob_stream(rig, 12, 256, seed=6, noise_px=0.02, dropout=0.05, half_extent=1500.0,
+                                              min_sep=50.0, truncate=False)
+    _compare(core, rig, blobs, counts, 0.5, K_max=384)
+    # float32 coordinates near 8 000 px are quantised to 2^-10 px: a 0.02 px gate is ~20 ulps of a coordinate
+    blobs, counts, _ = synth.make_blob_stream(rig, 12, 256, seed=7, noise_px=0.002, dropout=0.05, half_extent=1500.0,
+                                              min_sep=50.0, truncate=False)
+    _compare(core, rig, blobs, counts, 0.02, K_max=600, G_cap=1 << 24)
+
+
+def test_random_rigs_forced_wide_vs_c_oracle(core):
+    """Hypothesis: random camera counts, blob counts, focal lengths, gates, integer or float centroids -- every batch forced
+    through the wide variant and compared with the C oracle."""
+    from hypothesis import given, settings, strategies as st, HealthCheck
+    from mocap_core import synth
+
+    @settings(max_examples=20, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+    @given(C=st.integers(2, 12), M=st.integers(1, 40), f=st.sampled_from([200.0, 320.0, 900.0, 12000.0]),
+           gate=st.sampled_from([0.5, 2.0, 5.0]), trunc=st.booleans(), seed=st.integers(0, 10 ** 6),
+           dropout=st.sampled_from([0.0, 0.05, 0.4]))
+    def run(C, M, f, gate, trunc, seed, dropout):
+        K = [[f, 0.0, f / 2], [0.0, f, f / 2], [0.0, 0.0, 1.0]]
+        rig = synth.ring_rig(C, K=K, image_size=(int(f), int(f)))
+        blobs, counts, _ = synth.make_blob_stream(rig, 12, M, seed=seed, noise_px=0.05 * gate, dropout=dropout,
+                                                  truncate=trunc)
+        _compare(core, rig, blobs, counts, gate, K_max=min(C * M, 1024), G_cap=1 << 24, force_wide=True, min_points=0)
+
+    run()
+
+
+def test_candidate_cap_overflow_at_the_stress_shape_is_resubmitted(core):
+    """Frames over the candidate cap come back empty with status 2 from the plain call and complete from the re-submit
+    (G_cap = 2^24 per root, uncapped hit lists): equal to the oracle, which has no caps."""
+    from mocap_core import capi, synth
+    from oracle import c_oracle
+    rig = synth.stress_rig(64)
+    blobs, counts, _ = synth.make_stress_stream(rig, 12, 256, seed=31)
+    core.set_cameras(rig["K"], rig["R"], rig["t"])
+    tight = core.match_triangulate(blobs, counts, gate_px=synth.STRESS_GATE_PX, K_max=384, G_cap=2)
+    assert core.last_frame_kernel() == "frame_kernel<1024, wide>"
+    assert (tight["status"] & capi.ST_CAND_OVERFLOW).all() and not tight["n_out"].any()
+    auto = core.match_triangulate_auto(blobs, counts, gate_px=synth.STRESS_GATE_PX, K_max=384, G_cap=2)
+    ref = c_oracle.COracle(rig["K"], rig["R"], rig["t"]).match_triangulate(blobs, counts, gate_px=synth.STRESS_GATE_PX, K_max=384,
+                                                                           G_cap=1 << 20)
+    ok = ref["status"] == 0         # (a frame with a root of more than 2^20 groups is left to the core alone: minutes on the CPU)
+    assert auto["resubmitted"] == 12 and ok.sum() >= 10 and not auto["status"][ok].any()
+    assert np.array_equal(auto["n_out"][ok], ref["n_out"][ok]) and np.array_equal(auto["n_cand"][ok], ref["n_cand"][ok])
+    valid = (np.arange(384)[None, :] < ref["n_out"][:, None]) & ok[:, None]
+    assert np.array_equal(auto["corr"][valid], ref["corr"][valid])
+    np.testing.assert_allclose(auto["xyz"][valid], ref["xyz"][valid], rtol=1e-9, atol=1e-12)
+    # hit-list cap: one hit per pair kept -> frames with a multi-hit pair are flagged and repaired
+    try:
+        core.set_frame_limits(hit_cap=1)
+        capped = core.match_triangulate(blobs, counts, gate_px=synth.STRESS_GATE_PX, K_max=384)
+        assert (capped["status"] & capi.ST_HIT_OVERFLOW).any()
+        rep = core.match_triangulate_auto(blobs, counts, gate_px=synth.STRESS_GATE_PX, K_max=384)
+        assert not rep["status"][ok].any() and np.array_equal(rep["corr"][valid], ref["corr"][valid])
+    finally:
+        core.set_frame_limits(hit_cap=32)
+
+
+def test_a_camera_whose_every_blob_is_inside_the_gate(core):
+    """256 hits for one (root, camera) pair -- the longest list a pair can have (only the uncapped re-submit keeps it) --
+    and a product of exactly 256 candidates for the root."""
+    from mocap_core import synth
+    from oracle import mocap_oracle as mo
+    rig = synth.ring_rig(3, K=synth.STRESS_K, image_size=(16000, 16000))
+    rng = np.random.default_rng(3)
+    M = 256
+    blobs = np.zeros((2, 3, M, 2), dtype=np.float32)
+    counts = np.zeros((2, 3), dtype=np.int32)
+    Ftab = mo.fundamental_table(rig["K"], rig["R"], rig["t"])
+    for f in range(2):
+        blobs[f, 0, 0] = (7000.0 + 100 * f, 8100.0)
+        counts[f, 0] = 1
+        a, b, c = mo.epiline(Ftab[0, 1], blobs[f, 0, 0])
+        den = np.hypot(a, b)
+        for k in range(M):                              # camera 1: every blob within 0.4 px of the root's line
+            if abs(b) > abs(a):
+                x = rng.uniform(3000, 13000)
+                y = (-(a * x + c)) / b
+            else:
+                y = rng.uniform(3000, 13000)
+                x = (-(b * y + c)) / a
+            off = rng.uniform(-0.4, 0.4)
+            blobs[f, 1, k] = (x + off * a / den, y + off * b / den)
+        counts[f, 1] = M
+        a2, b2, c2 = mo.epiline(Ftab[0, 2], blobs[f, 0, 0])
+        blobs[f, 2, 0] = (8000.0, (-(a2 * 8000.0 + c2)) / b2) if abs(b2) > 1e-3 else ((-(c2 + b2 * 8000.0)) / a2, 8000.0)
+        counts[f, 2] = 1
+    res, ref = _compare(core, rig, blobs, counts, 0.5, K_max=600, G_cap=1 << 24)
+    assert ref["n_cand"].min() >= 200
+
+
+def test_pretest_self_check_build_reports_no_false_negative():
+    """lib/libmocap_core_pretest.so (-DMOCAP_DEBUG_PRETEST): for every (root, camera) pair the exact double decision is
+    taken on the device for every blob the float32 pre-test rejected; a blob inside the gate among them prints a PRETEST
+    line and is counted.  Runs the stress shape, the gate-straddling sets, a millimetre rig and integer-pixel frames."""
+    lib = os.path.join(ROOT, "low-cost-mocap_amd", "lib", "libmocap_core_pretest.so")
+    assert os.path.exists(lib), "build it with `make -C low-cost-mocap_amd all` (__graft_entry__.build does)"
+    code = r"""
+import sys, numpy as np
+sys.path[:0] = [%r, %r, %r]
+import torch
+from mocap_core import capi, synth
+import test_gpu_wide_adversarial as adv
+core = capi.MocapCore(0)
+dev = torch.device("cuda:0")
+tot = [0, 0]
+rng = np.random.default_rng(11)
+sets = []
+rig = synth.stress_rig(64)
+b, c, _ = synth.make_stress_stream(rig, 48, 256, seed=55)
+adv._gate_straddlers(rig, b, c, synth.STRESS_GATE_PX, rng)
+sets.append((rig, b, c, synth.STRESS_GATE_PX, 512, False))
+rig = synth.ring_rig(64, radius=3000.0, height=1500.0, K=synth.STRESS_K, image_size=(16000, 16000))
+b, c, _ = synth.make_blob_stream(rig, 8, 256, seed=7, noise_px=0.002, dropout=0.05, half_extent=1500.0, min_sep=50.0, truncate=False)
+sets.append((rig, b, c, 0.02, 600, False))
+rig = synth.ring_rig(8)
+b, c, _ = synth.make_blob_stream(rig, 400, 16, seed=78)
+adv._gate_straddlers(rig, b, c, 5.0, rng)
+sets.append((rig, b, c, 5.0, 128, True))
+for rig, blobs, counts, gate, K, fw in sets:
+    F, C, M, _ = blobs.shape
+    core.set_cameras(rig["K"], rig["R"], rig["t"])
+    core.set_frame_limits(hit_cap=32, force_wide=fw)
+    d_b, d_c = torch.from_numpy(blobs).to(dev), torch.from_numpy(counts).to(dev)
+    xyz = torch.empty((F, K, 3), dtype=torch.float64, device=dev); err = torch.empty((F, K), dtype=torch.float64, device=dev)
+    corr = torch.empty((F, K, C), dtype=torch.int16, device=dev); n_out = torch.zeros(F, dtype=torch.int32, device=dev)
+    status = torch.zeros(F + 2, dtype=torch.int32, device=dev)          # + the self-check build's two counters
+    core.match_triangulate_dev(F, M, d_b.data_ptr(), d_c.data_ptr(), gate, K, 1 << 24, xyz.data_ptr(), err.data_ptr(),
+                               corr.data_ptr(), n_out.data_ptr(), status.data_ptr())
+    core.synchronize()
+    assert core.last_frame_kernel() == "frame_kernel<1024, wide>", core.last_frame_kernel()
+    s = status.cpu().numpy()
+    tot[0] += int(s[F]); tot[1] += int(s[F + 1])
+print("CHECKED", tot[0], tot[1])
+""" % (ROOT, os.path.join(ROOT, "low-cost-mocap_amd"), os.path.join(ROOT, "tests"))
+    env = dict(os.environ, MOCAP_CORE_LIB=lib)
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert "PRETEST" not in p.stdout, p.stdout[:2000]
+    checked = [ln for ln in p.stdout.splitlines() if ln.startswith("CHECKED")][-1].split()
+    assert int(checked[1]) > 500000 and int(checked[2]) == 0, checked        # (root, camera) pairs checked, false negatives
