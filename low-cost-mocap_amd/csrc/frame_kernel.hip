@@ -68,7 +68,7 @@ namespace mocap {
 struct FrameLayout {
   // byte offsets, computed identically on host (sizes) and device (carving)
   size_t line, dist, seg_e, seg_x, seg_g, goff, gcnt, outslot, root_blob, root_cam, claimed, claimw, nact,
-      cnt, misc, rbound, h0, nhc, lds_total;         // always LDS
+      cnt, misc, rbound, h0, nhc, wbl, lds_total;    // always LDS
   size_t bxy, cxy, hits, dig, nh, act;               // narrow: LDS.  wide: hits / nh (exact counts of the multi-hit pairs) in the workspace, the rest unused
   size_t bt;                                          // table mode: DLT contribution per (camera, blob)
   size_t ws_total;
@@ -109,6 +109,9 @@ struct FrameLayout {
     h0 = o;        o += wide ? (size_t)R * C : 0;
     nhc = o;       o += wide ? (size_t)R * C : 0;
     o = align(o, 16);
+    // wide: one camera's blobs per wave, staged for match_roots_wide (read back as broadcasts): matching scratch, dead before the
+    // segment arrays of phase D / E come alive -- it lies over them (seg_e + seg_x = 32 (T + R) bytes >= 32 KB at T = 1024)
+    wbl = seg_e;
     size_t w = wide ? 0 : o;  // the movable arrays continue in LDS, or start a workspace
     cxy = w;       w += wide ? 0 : (table ? (size_t)C * T : sizeof(float2) * (size_t)C * T);
     w = align(w, 16);
@@ -150,6 +153,7 @@ struct FrameState {
   unsigned long long* claimw;  // wide: [C][ceil(M / 64)] blobs claimed so far (match_wide)
   uint8_t* h0;                 // wide: [R][C] blob index of the closest gated hit (the root's own blob at its camera)   (LDS)
   uint8_t* nhc;                // wide: [R][C] number of gated hits, saturating at 255 (1 at the root's camera, 0 before it) (LDS)
+  float2* wbl;                 // wide: [T / 64][kMaxBlobs] a wave's copy of the camera it is matching against               (LDS)
 
   __device__ FrameState(const FrameArgs& p_, unsigned char* smem)
       : p(p_), cv(p_.cv), C(p_.cv.C), M(p_.M), R(p_.K_max), tid(threadIdx.x) {
@@ -183,6 +187,7 @@ struct FrameState {
     claimw = (unsigned long long*)(smem + L.claimw);
     h0 = smem + L.h0;
     nhc = smem + L.nhc;
+    wbl = (float2*)(smem + L.wbl);
   }
 
   // gated hits of root r in camera c (wide: the LDS byte, or the exact count from the workspace when it saturated)
@@ -420,6 +425,261 @@ struct FrameState {
     count_candidates();
   }
 
+  // One (root, camera) pair with several candidate blobs, the rare case of a wide frame: the wave holds the camera's blobs
+  // four per lane (bl), pc marks the ones to decide, lane q holds the root's line.  Decision of helpers.py:373,375 in
+  // double; the hits ranked by (distance, blob index) -- stable where NumPy's default argsort is not (helpers.py:384;
+  // documented deviation) -- among the lanes that hold them: every hit's (d, k) is broadcast once and compared with the
+  // (at most four) hits of every lane.  A list of two or more goes to the workspace in HBM; the closest hit's
+  // coordinates claim every blob that has them (helpers.py:391).  Result in lane q's my_nh / my_k0.  Wave-uniform call.
+  __device__ __forceinline__ void resolve_pair(int q, int rq, int i, const float2 (&bl)[4], const bool (&pc)[4], double la, double lb,
+                                               double lc, double lden, double lrden, int& my_nh, int& my_k0) {
+    const int lane = tid & 63;
+    const int H = p.H, MW = (M + 63) / 64;
+    auto bcast = [&](double v, int l) {
+      const long long bits = __double_as_longlong(v);
+      return __longlong_as_double(((long long)__builtin_amdgcn_readlane((int)(bits >> 32), l) << 32) |
+                                  (unsigned int)__builtin_amdgcn_readlane((int)bits, l));
+    };
+    const double qa = bcast(la, q), qb = bcast(lb, q), qc = bcast(lc, q), qden = bcast(lden, q), qrden = bcast(lrden, q);
+    double dd[4] = {0.0, 0.0, 0.0, 0.0};
+    bool hit[4] = {false, false, false, false};
+    unsigned long long hmask[4] = {0ull, 0ull, 0ull, 0ull};
+    int nhits = 0;
+#pragma unroll
+    for (int sg = 0; sg < 4; sg++) {
+      if (!__ballot(pc[sg])) continue;  // wave-uniform: usually one segment of the four has a candidate
+      if (pc[sg]) {
+        dd[sg] = div_by(fabs(qa * (double)bl[sg].x + qb * (double)bl[sg].y + qc), qden, qrden);
+        hit[sg] = dd[sg] < p.gate_px;  // strict <, helpers.py:375,383
+      }
+      hmask[sg] = __ballot(hit[sg]);
+      nhits += __popcll(hmask[sg]);
+    }
+    if (!nhits) return;
+    if (nhits > H) atomicOr(&misc[MI_STATUS], MOCAP_ST_HIT_OVERFLOW_);
+    if (nhits == 1) {
+      // the one blob inside the gate is the closest hit and claims itself (helpers.py:391)
+      int k1 = 0;
+#pragma unroll
+      for (int sg = 0; sg < 4; sg++)
+        if (hmask[sg]) k1 = 64 * sg + (__ffsll((long long)hmask[sg]) - 1);
+#pragma unroll
+      for (int sg = 0; sg < 4; sg++)
+        if (hit[sg]) atomicOr(&claimw[(size_t)i * MW + sg], 1ull << lane);
+      if (lane == q) {
+        my_nh = 1;
+        my_k0 = k1;
+      }
+      return;
+    }
+    int rank[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int s2 = 0; s2 < 4; s2++) {
+      unsigned long long mm = hmask[s2];
+      while (mm) {  // wave-uniform
+        const int l2 = __ffsll((long long)mm) - 1;
+        mm &= mm - 1;
+        const double d2 = bcast(dd[s2], l2);
+        const int k2 = 64 * s2 + l2;
+#pragma unroll
+        for (int sg = 0; sg < 4; sg++) rank[sg] += (hit[sg] && (d2 < dd[sg] || (d2 == dd[sg] && k2 < 64 * sg + lane))) ? 1 : 0;
+      }
+    }
+    uint8_t* hl = hits + ((size_t)rq * C + i) * Hs;
+    int k0 = 0;
+#pragma unroll
+    for (int sg = 0; sg < 4; sg++) {
+      if (hit[sg] && rank[sg] < H) hl[rank[sg]] = (uint8_t)(64 * sg + lane);
+      const unsigned long long first = __ballot(hit[sg] && rank[sg] == 0);
+      if (first) k0 = 64 * sg + (__ffsll((long long)first) - 1);  // wave-uniform
+    }
+    if (lane == q) {
+      my_nh = nhits < H ? nhits : H;
+      my_k0 = k0;
+      nh[(size_t)rq * C + i] = (uint16_t)my_nh;  // the exact count (the LDS byte saturates at 255)
+    }
+    float p0x = 0.f, p0y = 0.f;
+#pragma unroll
+    for (int sg = 0; sg < 4; sg++)
+      if ((k0 >> 6) == sg) {
+        p0x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bl[sg].x), k0 & 63));
+        p0y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bl[sg].y), k0 & 63));
+      }
+#pragma unroll
+    for (int sg = 0; sg < 4; sg++) {
+      const unsigned long long cm = __ballot(hit[sg] && bl[sg].x == p0x && bl[sg].y == p0y);
+      if (cm && lane == 0) atomicOr(&claimw[(size_t)i * MW + sg], cm);
+    }
+  }
+
+  // Epipolar line of a root in camera i: cv.computeCorrespondEpilines on a float32 point -- double math, scale by
+  // 1/sqrt(a^2+b^2), float32 result (helpers.py:363-364) -- plus what the distance of helpers.py:373 divides by.
+  template <class Tab>
+  __device__ __forceinline__ void epiline_wide(Tab Fm, float2 rp, double& la, double& lb, double& lc, double& lden, double& lrden) {
+    const double x = (double)rp.x, y = (double)rp.y;
+    double a = Fm[0] * x + Fm[1] * y + Fm[2];
+    double bb = Fm[3] * x + Fm[4] * y + Fm[5];
+    double c = Fm[6] * x + Fm[7] * y + Fm[8];
+    double nu = a * a + bb * bb;
+    nu = nu != 0.0 ? 1.0 / sqrt(nu) : 1.0;
+    a *= nu;
+    bb *= nu;
+    c *= nu;
+    if (F32R) {
+      a = (double)(float)a;
+      bb = (double)(float)bb;
+      c = (double)(float)c;
+    }
+    la = a;
+    lb = bb;
+    lc = c;
+    lden = sqrt(a * a + bb * bb);  // helpers.py:373 divides by it again
+    lrden = recip_refined(lden);
+  }
+
+  // ---------------------------------------------------------------- many roots against the cameras after them (round 4)
+  // One LANE per root, the camera's blobs broadcast from the wave's LDS copy.  What a (root, camera) pair costs is the
+  // float32 pre-test of the camera's blobs against the root's line -- two FMAs and a compare per blob for the 64 roots of a
+  // batch at once -- and little else: the usual outcome (exactly one blob passes, the marker's own) is simply what the
+  // root's lane has in its registers when the loop ends (blob index + count; the bookkeeping instructions run only for
+  // the blobs that pass for some root of the batch, a scalar branch).  The exact decision of helpers.py:373,375
+  // follows for the 64 roots at once; a root with several candidates goes through resolve_pair.  Round 3 kept the blobs in
+  // registers and broadcast the roots instead: each pair then paid ~30 scalar / cross-lane instructions to hand the one
+  // passing blob to the lane that holds the root's line (55 issue slots per pair, measured).  CAM0: every root of the
+  // call is a camera-0 root (the fundamental matrices come over the scalar cache).
+  template <bool CAM0>
+  __device__ void match_roots_wide(int rlo, int rhi, int clo) {
+    constexpr int W = T / 64;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int MW = (M + 63) / 64;
+    const double om = (double)__int_as_float(misc[MI_OMAX]);
+    // the wave's copy of the camera's blobs, x and y apart: four consecutive x (or y) are one broadcast read
+    float* wx = reinterpret_cast<float*>(wbl) + (size_t)wave * 2 * kMaxBlobs;
+    float* wy = wx + kMaxBlobs;
+    const float finf = __int_as_float(0x7f800000);
+    for (int g0 = rlo; g0 < rhi; g0 += 256) {
+      // the roots' own points: once per group of four batches, not once per camera
+      float2 rp[4];
+      int rcv[4];
+#pragma unroll
+      for (int b = 0; b < 4; b++) {
+        const int r = g0 + 64 * b + lane;
+        const bool okr = r < rhi;
+        rcv[b] = okr ? root_cam[r] : 0;
+        rp[b] = bxy[(size_t)rcv[b] * M + (okr ? root_blob[r] : 0)];
+      }
+      for (int i = clo + wave; i < C; i += W) {  // wave-uniform
+        const int Mi = __builtin_amdgcn_readfirstlane(cnt[i]);  // (uniform anyway: tells the compiler so -- scalar loop control below)
+        const int M4 = (Mi + 3) & ~3;
+        const float2* row = bxy + (size_t)i * M;
+        wave_lds_sync();  // the previous camera's reads are done
+#pragma unroll
+        for (int sg = 0; sg < 4; sg++) {
+          const int k = 64 * sg + lane;
+          // slots beyond the camera's count hold +inf: |fl(a x + b y + c)| <= thr is false for them (inf or NaN)
+          if (k < M4) {
+            const float2 v = k < Mi ? row[k] : make_float2(finf, finf);
+            wx[k] = v.x;
+            wy[k] = v.y;
+          }
+        }
+        wave_lds_sync();
+        for (int b = 0; b < 4 && g0 + 64 * b < rhi; b++) {  // wave-uniform; ONE copy of the body (not unrolled)
+          const int r = g0 + 64 * b + lane;
+          const bool have = r < rhi;
+          // this batch's root point: selected from registers (b is wave-uniform), never an indexed array
+          const float2 rpb = b == 0 ? rp[0] : (b == 1 ? rp[1] : (b == 2 ? rp[2] : rp[3]));
+          const int rcb = b == 0 ? rcv[0] : (b == 1 ? rcv[1] : (b == 2 ? rcv[2] : rcv[3]));
+          double la = 0, lb = 0, lc = 0, lden = 1, lrden = 1;
+          if (have) {
+            if constexpr (CAM0)
+              epiline_wide(as_ctab(cv.F + 9 * (size_t)i), rpb, la, lb, lc, lden, lrden);
+            else
+              epiline_wide(cv.F + 9 * ((size_t)rcb * C + i), rpb, la, lb, lc, lden, lrden);
+          }
+          // pre-test threshold, rounded up (a rigorous bound on the float32 evaluation, see match_pairs_wide); +inf --
+          // everything goes to the exact test -- without the float32 line; idle lanes never pass
+          const float a32 = (float)la, b32 = (float)lb, c32 = (float)lc;
+          float thr = finf;
+          if (F32R) thr = __double2float_ru(p.gate_px * lden * (1.0 + 1e-12) + (2.5 * 0x1p-24) * (2.0 * om + fabs(lc)) * (1.0 + 1e-6));
+          if (!have) thr = -1.0f;
+          int np = 0, kk = 0;
+          for (int k0 = 0; k0 < M4; k0 += 4) {  // scalar loop; four blobs per step, two broadcast reads
+            const float4 X = *reinterpret_cast<const float4*>(wx + k0);
+            const float4 Y = *reinterpret_cast<const float4*>(wy + k0);
+            const float t0 = fmaf(a32, X.x, fmaf(b32, Y.x, c32)), t1 = fmaf(a32, X.y, fmaf(b32, Y.y, c32));
+            const float t2 = fmaf(a32, X.z, fmaf(b32, Y.z, c32)), t3 = fmaf(a32, X.w, fmaf(b32, Y.w, c32));
+            const unsigned long long m0 = __ballot(fabsf(t0) <= thr), m1 = __ballot(fabsf(t1) <= thr);
+            const unsigned long long m2 = __ballot(fabsf(t2) <= thr), m3 = __ballot(fabsf(t3) <= thr);
+            if ((m0 | m1) | (m2 | m3)) {  // some root of the batch has a candidate among these four (scalar branch)
+              if (m0) {
+                const bool ps = fabsf(t0) <= thr;
+                np += ps ? 1 : 0;
+                kk = ps ? k0 : kk;
+              }
+              if (m1) {
+                const bool ps = fabsf(t1) <= thr;
+                np += ps ? 1 : 0;
+                kk = ps ? k0 + 1 : kk;
+              }
+              if (m2) {
+                const bool ps = fabsf(t2) <= thr;
+                np += ps ? 1 : 0;
+                kk = ps ? k0 + 2 : kk;
+              }
+              if (m3) {
+                const bool ps = fabsf(t3) <= thr;
+                np += ps ? 1 : 0;
+                kk = ps ? k0 + 3 : kk;
+              }
+            }
+          }
+#ifdef MOCAP_DEBUG_PRETEST  // self-check build: the exact decision (helpers.py:373,375) for EVERY blob the float32 pre-test
+          if (have) {          // rejected; a blob inside the gate among them is a false negative (must never happen)
+            int fneg = 0;
+            for (int k = 0; k < Mi; k++) {
+              const float2 v = make_float2(wx[k], wy[k]);
+              const bool pass = fabsf(fmaf(a32, v.x, fmaf(b32, v.y, c32))) <= thr;
+              if (!pass && div_by(fabs(la * (double)v.x + lb * (double)v.y + lc), lden, lrden) < p.gate_px) fneg++;
+            }
+            atomicAdd(&p.status[p.n_frames], 1);
+            if (fneg) atomicAdd(&p.status[p.n_frames + 1], fneg);  // (no printf here: it costs the build 300 spilled registers)
+          }
+#endif
+          int my_nh = 0, my_k0 = 0;
+          if (have && np == 1) {  // the usual outcome: one candidate; helpers.py:373 in double, strict < (helpers.py:375,383)
+            const float2 v = make_float2(wx[kk], wy[kk]);
+            if (kk < Mi && div_by(fabs(la * (double)v.x + lb * (double)v.y + lc), lden, lrden) < p.gate_px) {
+              atomicOr(&claimw[(size_t)i * MW + (kk >> 6)], 1ull << (kk & 63));  // a lone hit claims itself (helpers.py:391)
+              my_nh = 1;
+              my_k0 = kk;
+            }
+          }
+          unsigned long long multi = __ballot(have && np >= 2);
+          if (multi) {  // rare: roots with several candidates, one at a time, the camera's blobs four per lane
+            float2 bl[4];
+            bool pc[4];
+#pragma unroll
+            for (int sg = 0; sg < 4; sg++) {
+              const int k = 64 * sg + lane;
+              pc[sg] = k < Mi;
+              bl[sg] = pc[sg] ? make_float2(wx[k], wy[k]) : make_float2(finf, finf);
+            }
+            while (multi) {
+              const int q = __ffsll((long long)multi) - 1;
+              multi &= multi - 1;
+              resolve_pair(q, g0 + 64 * b + q, i, bl, pc, la, lb, lc, lden, lrden, my_nh, my_k0);
+            }
+          }
+          if (have) {
+            h0[(size_t)r * C + i] = (uint8_t)my_k0;
+            nhc[(size_t)r * C + i] = (uint8_t)(my_nh < 255 ? my_nh : 255);
+          }
+        }
+      }
+    }
+  }
+
   // ---------------------------------------------------------------- phases A-B, wide frames (round 3)
   // The reference matches camera after camera (helpers.py:359-406) because a blob no root claims becomes a new root
   // for the cameras after it; only THAT is sequential.  A root's lines, gates, orders and claims in all the cameras
@@ -441,7 +701,7 @@ struct FrameState {
   __device__ void match_pairs_wide(int rlo, int rhi, int clo) {
     constexpr int W = T / 64;
     const int lane = tid & 63, wave = tid >> 6;
-    const int H = p.H, MW = (M + 63) / 64;
+    const int MW = (M + 63) / 64;
     const double om = (double)__int_as_float(misc[MI_OMAX]);
     for (int i = clo + wave; i < C; i += W) {  // wave-uniform
       const int Mi = cnt[i];
@@ -523,11 +783,7 @@ struct FrameState {
             for (int sg = 0; sg < 4; sg++)
               if (ok[sg] && !pm[sg] && div_by(fabs(qa * (double)bl[sg].x + qb * (double)bl[sg].y + qc), qden, qrden) < p.gate_px) fneg++;
             if (lane == 0) atomicAdd(&p.status[p.n_frames], 1);
-            if (fneg) {
-              atomicAdd(&p.status[p.n_frames + 1], fneg);
-              printf("PRETEST false negative: root %d camera %d lane %d line %.9g %.9g %.9g thr %.9g omax %g\n", rb + q, i, lane, qa, qb, qc,
-                     (double)ft, om);
-            }
+            if (fneg) atomicAdd(&p.status[p.n_frames + 1], fneg);
           }
 #endif
           const unsigned long long any01 = pmask[0] | pmask[1], any23 = pmask[2] | pmask[3];
@@ -564,86 +820,12 @@ struct FrameState {
             }
             continue;
           }
-          // ---- rare: several blobs within reach of the gate; the line in double, the decision of helpers.py:373,375
-          auto bcast = [&](double v, int l) {
-            const long long bits = __double_as_longlong(v);
-            return __longlong_as_double(((long long)__builtin_amdgcn_readlane((int)(bits >> 32), l) << 32) |
-                                        (unsigned int)__builtin_amdgcn_readlane((int)bits, l));
-          };
-          const double qa = bcast(la, q), qb = bcast(lb, q), qc = bcast(lc, q), qden = bcast(lden, q), qrden = bcast(lrden, q);
-          double dd[4] = {0.0, 0.0, 0.0, 0.0};
-          bool hit[4] = {false, false, false, false};
-          unsigned long long hmask[4] = {0ull, 0ull, 0ull, 0ull};
-          int nhits = 0;
+          // ---- rare: several blobs within reach of the gate
+          {
+            bool pc[4];
 #pragma unroll
-          for (int sg = 0; sg < 4; sg++) {
-            if (!pmask[sg]) continue;  // wave-uniform: usually one segment of the four has a candidate
-            if (pm[sg] && ok[sg]) {
-              dd[sg] = div_by(fabs(qa * (double)bl[sg].x + qb * (double)bl[sg].y + qc), qden, qrden);
-              hit[sg] = dd[sg] < p.gate_px;  // strict <, helpers.py:375,383
-            }
-            hmask[sg] = __ballot(hit[sg]);
-            nhits += __popcll(hmask[sg]);
-          }
-          if (!nhits) continue;
-          if (nhits > H) atomicOr(&misc[MI_STATUS], MOCAP_ST_HIT_OVERFLOW_);
-          if (nhits == 1) {
-            // the one blob inside the gate is the closest hit and claims itself (helpers.py:391)
-            int k1 = 0;
-#pragma unroll
-            for (int sg = 0; sg < 4; sg++)
-              if (hmask[sg]) k1 = 64 * sg + (__ffsll((long long)hmask[sg]) - 1);
-#pragma unroll
-            for (int sg = 0; sg < 4; sg++)
-              if (hit[sg]) atomicOr(&claimw[(size_t)i * MW + sg], 1ull << lane);
-            if (lane == q) {
-              my_nh = 1;
-              my_k0 = k1;
-            }
-            continue;
-          }
-          // several hits: ranked by (distance, blob index) -- stable where NumPy's default argsort is not (helpers.py:384;
-          // documented deviation) -- among the lanes that hold them: every hit's (d, k) is broadcast once and compared
-          // with the (at most four) hits of every lane.  The list goes to the workspace in HBM (this is the rare case).
-          int rank[4] = {0, 0, 0, 0};
-#pragma unroll
-          for (int s2 = 0; s2 < 4; s2++) {
-            unsigned long long mm = hmask[s2];
-            while (mm) {  // wave-uniform
-              const int l2 = __ffsll((long long)mm) - 1;
-              mm &= mm - 1;
-              const double d2 = bcast(dd[s2], l2);
-              const int k2 = 64 * s2 + l2;
-#pragma unroll
-              for (int sg = 0; sg < 4; sg++) rank[sg] += (hit[sg] && (d2 < dd[sg] || (d2 == dd[sg] && k2 < 64 * sg + lane))) ? 1 : 0;
-            }
-          }
-          uint8_t* hl = hits + ((size_t)(rb + q) * C + i) * Hs;
-          int k0 = 0;
-#pragma unroll
-          for (int sg = 0; sg < 4; sg++) {
-            if (hit[sg] && rank[sg] < H) hl[rank[sg]] = (uint8_t)(64 * sg + lane);
-            const unsigned long long first = __ballot(hit[sg] && rank[sg] == 0);
-            if (first) k0 = 64 * sg + (__ffsll((long long)first) - 1);  // wave-uniform
-          }
-          if (lane == q) {
-            my_nh = nhits < H ? nhits : H;
-            my_k0 = k0;
-            nh[(size_t)(rb + q) * C + i] = (uint16_t)my_nh;  // the exact count (the LDS byte saturates at 255)
-          }
-          // the closest hit's coordinates claim every blob that has them (helpers.py:391): such a blob has the same
-          // distance, so it is among the hits; the coordinates come from the registers that hold the camera's blobs
-          float p0x = 0.f, p0y = 0.f;
-#pragma unroll
-          for (int sg = 0; sg < 4; sg++)
-            if ((k0 >> 6) == sg) {
-              p0x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bl[sg].x), k0 & 63));
-              p0y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bl[sg].y), k0 & 63));
-            }
-#pragma unroll
-          for (int sg = 0; sg < 4; sg++) {
-            const unsigned long long cm = __ballot(hit[sg] && bl[sg].x == p0x && bl[sg].y == p0y);
-            if (cm && lane == 0) atomicOr(&claimw[(size_t)i * MW + sg], cm);
+            for (int sg = 0; sg < 4; sg++) pc[sg] = pm[sg] && ok[sg];
+            resolve_pair(q, rb + q, i, bl, pc, la, lb, lc, lden, lrden, my_nh, my_k0);
           }
         }
         if (cand_k >= 0) {  // single candidates: helpers.py:373 in double, strict < (helpers.py:375,383); a lone hit claims itself
@@ -708,7 +890,7 @@ struct FrameState {
     }
     __syncthreads();
 #if !(MOCAP_WIDE_DEBUG_SKIP & 1)
-    match_pairs_wide(0, n0, 1);
+    match_roots_wide<true>(0, n0, 1);
 #endif
     __syncthreads();
     int n_roots = n0;
@@ -751,7 +933,10 @@ struct FrameState {
           nhc[(size_t)r * C + c] = c == j ? 1 : 0;
           h0[(size_t)r * C + c] = (uint8_t)root_blob[r];
         }
-        if (j + 1 < C && !(MOCAP_WIDE_DEBUG_SKIP & 2)) match_pairs_wide(n_roots, now, j + 1);
+        if (j + 1 < C && !(MOCAP_WIDE_DEBUG_SKIP & 2)) {
+          // few new roots (the usual chain step): the blobs stay in registers and the roots are broadcast; many: one lane per root
+          if (now - n_roots < 24) match_pairs_wide(n_roots, now, j + 1); else match_roots_wide<false>(n_roots, now, j + 1);
+        }
         __syncthreads();
       }
       n_roots = now;

@@ -238,8 +238,7 @@ def test_a_camera_whose_every_blob_is_inside_the_gate(core):
 
 def test_pretest_self_check_build_reports_no_false_negative():
     """lib/libmocap_core_pretest.so (-DMOCAP_DEBUG_PRETEST): for every (root, camera) pair the exact double decision is
-    taken on the device for every blob the float32 pre-test rejected; a blob inside the gate among them prints a PRETEST
-    line and is counted.  Runs the stress shape, the gate-straddling sets, a millimetre rig and integer-pixel frames."""
+    taken on the device for every blob the float32 pre-test rejected; a blob inside the gate among them is counted.  Runs the stress shape, the gate-straddling sets, a millimetre rig and integer-pixel frames."""
     lib = os.path.join(ROOT, "low-cost-mocap_amd", "lib", "libmocap_core_pretest.so")
     assert os.path.exists(lib), "build it with `make -C low-cost-mocap_amd all` (__graft_entry__.build does)"
     code = r"""
@@ -283,6 +282,5 @@ print("CHECKED", tot[0], tot[1])
     env = dict(os.environ, MOCAP_CORE_LIB=lib)
     p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
-    assert "PRETEST" not in p.stdout, p.stdout[:2000]
     checked = [ln for ln in p.stdout.splitlines() if ln.startswith("CHECKED")][-1].split()
     assert int(checked[1]) > 500000 and int(checked[2]) == 0, checked        # (root, camera) pairs checked, false negatives
