@@ -474,11 +474,8 @@ def ba_parity(core):
         row = {"reference": {"nfev": int(g["ba_stats"][0]), "njev": int(g["ba_stats"][1]),
                              "self_dR_max": float(g["self_dR"].max()), "self_dt_rel_max": float(g["self_dt"].max())}}
         for mode in ("scipy", "resident"):
-            helpers.set_bundle_adjustment_mode(mode)
-            try:
+            with helpers.bundle_adjustment_mode(mode):
                 poses, info = helpers.bundle_adjustment(synth.obs_to_reference_array(g["obs"]), poses0, None, return_info=True)
-            finally:
-                helpers.set_bundle_adjustment_mode(helpers.DEFAULT_BA_MODE)
             R = np.array([np.asarray(p["R"], dtype=np.float64) for p in poses])
             t = np.array([np.asarray(p["t"], dtype=np.float64).reshape(3) for p in poses])
             row[mode] = {"nfev": int(info["nfev"]), "njev": int(info["njev"]), "dR_max": float(np.abs(R - g["R_ba"]).max()),
@@ -524,7 +521,23 @@ def ba_bench(core, iters=200, cpu=True):
                         "the iteration is a chain of dependent steps (launch, residual phase, two cross-XCD hand-offs, "
                         "PCIe hand-over, host subproblem).  MFMA issue counters: profiles/r02_ba_pmc_mfma.csv"}
     out_cpu = ba_cpu_baseline(rig, init, obs, x0) if cpu else None
-    return {"metric": "BA iters/sec (8 cams, 1k pts)", "value": info["iterations"] / dt, "roofline": roofline,
+    # what index.py:272 reaches by DEFAULT: helpers.bundle_adjustment in mode "scipy" -- the reference's own optimizer call,
+    # residuals on the GPU (poses bit-identical to the reference's on the solver goldens) -- on the same 8 cams x 1 000 points
+    ref_obs = synth.obs_to_reference_array(obs)
+    poses0 = [{"R": init["R"][i].copy(), "t": init["t"][i].copy()} for i in range(CAMS)]
+    helpers.set_core(core)
+    with helpers.bundle_adjustment_mode("scipy"):
+        t0 = time.perf_counter()
+        _, dinfo = helpers.bundle_adjustment(ref_obs, poses0, None, return_info=True)
+        d_dt = time.perf_counter() - t0
+    default_mode = {"mode": helpers.DEFAULT_BA_MODE, "measured_mode": "scipy", "wall_s": d_dt, "njev": int(dinfo["njev"]),
+                    "nfev": int(dinfo["nfev"]), "iterations_per_s": dinfo["njev"] / d_dt,
+                    "residual_evaluations_per_s": (dinfo["nfev"] + dinfo["njev"] * x0.size) / d_dt,
+                    "note": "the seam's default: scipy.optimize.least_squares drives, every residual evaluation is one "
+                            "mocap_ba_residuals call (n + 1 of them per Jacobian, host round trip each); `value` above is mode "
+                            "\"resident\" (mocap_ba_solve), opt-in via helpers.set_bundle_adjustment_mode"}
+    return {"metric": "BA iters/sec (8 cams, 1k pts)", "value": info["iterations"] / dt, "measured_mode": "resident",
+            "default_mode": default_mode, "roofline": roofline,
             "cpu_baseline": out_cpu, "parity": ba_parity(core),
             "iterations": info["iterations"], "nfev": info["nfev"], "ms_per_iter": 1e3 * dt / max(info["iterations"], 1),
             "runs_ms": [round(1e3 * r[0], 2) for r in runs], "statistic": "median of 5 solves", "warmup_solves": n_warm,
@@ -562,7 +575,9 @@ def dry_run(args):
     rank, _, world = mdist.init_process_group(backend="gloo")
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    C, K, F = 8, 16, (args.frames or 64) + rank          # uneven shards
+    wl = WORKLOADS[args.workload]
+    C, K = wl["C"], (16 if args.workload == "8x16" else min(wl["K_max"], 40))   # the record stride follows the camera count (64 x 256: 160 B)
+    F = (args.frames or 64) + rank                       # uneven shards
     frames_per_rank = [(args.frames or 64) + r for r in range(world)]
     stride = mdist.track_record_bytes(C)
     t0 = time.perf_counter()
@@ -595,7 +610,7 @@ def dry_run(args):
         print(json.dumps({"metric": "triangulated 3D markers/sec at 8 cams x 16 markers", "value": None, "unit": "markers/s",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "dry_run": True, "backend": "gloo",
                           "data": "made-up track records (no GPU): control flow and exchange only",
-                          "config": {"frames_per_rank": frames_per_rank,
+                          "config": {"frames_per_rank": frames_per_rank, "workload": args.workload, "record_bytes": int(stride),
                                      "exchange": {"format": "compact records, count in the first point-to-point message",
                                                   "payload_checksums_match": bool(ok),
                                                   "records_sent_all_ranks": int(allv[:, 3].sum())}},
@@ -613,6 +628,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="8x16")
     ap.add_argument("--frames", type=int, default=0, help="frames per GPU per step (0 = the workload's default)")
+    ap.add_argument("--chunks", type=int, default=0,
+                    help="N > 1: sub-batches a rank's shard is cut into per step, so that the gather of chunk k travels while chunk "
+                         "k + 1 is computed inside ONE step (0 = automatic: 4; 1 = the whole shard at once)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ba", action="store_true")
     ap.add_argument("--no-blobs", action="store_true")
@@ -680,19 +698,24 @@ def main():
     # transfer of step i is posted -- on its own stream -- once step i + 1's kernels are queued, so it hides behind
     # them; only the last step's exchange is exposed.  MOCAP_BENCH_EXCHANGE=1 runs the same code path on one GPU.
     multi = world > 1 or bool(int(os.environ.get("MOCAP_BENCH_EXCHANGE", "0")))
-    comp = mdist.TrackCompactor(core, F, K_MAX, C, dev) if multi else None
+    # A rank's shard is cut into sub-batches: the gather of chunk k is posted once chunk k + 1's kernels are queued, so the
+    # exchange overlaps compute INSIDE a step too (a one-step run used to expose all of it: at 64 x 256 that is 532 MB per
+    # rank, 3.7 GB into the root).  Each chunk has its own compactor buffers.
+    n_chunks = 1 if not multi else max(1, min(args.chunks or 4, F))
+    cb = [mdist.shard_bounds(F, c, n_chunks) for c in range(n_chunks)]
+    comps = [mdist.TrackCompactor(core, hi - lo, K_MAX, C, dev) for lo, hi in cb] if multi else []
     comm = torch.cuda.Stream(dev) if multi else None
-    frames_per_rank = [F] * world          # weak scaling: every rank owns F frames
     exchanged = {"records": 0, "bytes": 0}
 
-    def post_exchange(i):
-        n = comp.count(i)                  # waits for step i's compaction only
+    def post_exchange(c, i):
+        comp = comps[c]
+        n = comp.count(i)                  # waits for this chunk's compaction only
         exchanged["records"] += n
-        exchanged["bytes"] += n * comp.stride + 4 * F
+        exchanged["bytes"] += n * comp.stride + 4 * comp.F
         with torch.cuda.stream(comm):
             comm.wait_event(comp.events[i])
             # the handle stays attached to buffer i: compact() will not overwrite it while the exchange reads it
-            return comp.attach(i, mdist.gather_compact_async(comp.n_out[i], comp.records[i], n, frames_per_rank, dst=0))
+            return comp.attach(i, mdist.gather_compact_async(comp.n_out[i], comp.records[i], n, [comp.F] * world, dst=0))
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -700,24 +723,37 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    exposed = {"ms": None}
+
     def run(n_steps, events=None):
         prev, pending = None, []
         for i in range(n_steps):
             if events:
                 events[i][0].record(stream)
-            hot_path()
-            if multi:
-                cur = comp.compact(d_nout, d_xyz, d_err, d_corr, stream)
-            if events:
-                events[i][1].record(stream)
-            if multi:
-                if prev is not None:
-                    pending.append(post_exchange(prev))
+            if not multi:
+                hot_path()
+            for c, (lo, hi) in enumerate(cb if multi else []):
+                hot_path(lo, hi)
+                cur = comps[c].compact(d_nout[lo:hi], d_xyz[lo:hi], d_err[lo:hi], d_corr[lo:hi], stream)
+                if prev is not None:               # chunk k's transfer is posted behind chunk k + 1's kernels
+                    pending.append(post_exchange(*prev))
                     while len(pending) > 2:        # at most two exchanges in flight (bounds the staging memory)
                         pending.pop(0).result()
-                prev = cur
+                prev = (c, cur)
+            if events:
+                events[i][1].record(stream)
         if multi and prev is not None:
-            pending.append(post_exchange(prev))
+            # what is left when the last kernel has finished = the exposed part of the exchange
+            e_comp, e_all = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e_comp.record(stream)
+            pending.append(post_exchange(*prev))
+            for h in pending:
+                h.result()
+            pending = []
+            stream.wait_stream(comm)
+            e_all.record(stream)
+            e_all.synchronize()
+            exposed["ms"] = e_comp.elapsed_time(e_all)
         for h in pending:
             h.result()
 
@@ -736,7 +772,8 @@ def main():
     status = d_status.cpu().numpy()
     n_cand = d_ncand.cpu().numpy()
     local = torch.tensor([float(n_out.sum()), elapsed, float(status.astype(bool).sum()), float((status & 1).astype(bool).sum()),
-                          float((status & 2).astype(bool).sum()), float((status & 4).astype(bool).sum())], dtype=torch.float64, device=dev)
+                          float((status & 2).astype(bool).sum()), float((status & 4).astype(bool).sum()),
+                          float(exposed["ms"] or 0.0)], dtype=torch.float64, device=dev)
     if world > 1:
         allv = [torch.zeros_like(local) for _ in range(world)]
         dist.all_gather(allv, local)
@@ -776,6 +813,11 @@ def main():
                        "exchange": ({"format": "compact records (32 + 2C bytes per valid point) + n_out per frame, count-first "
                                                "point-to-point gather on rank 0",
                                      "bytes_per_rank_per_step": exchanged["bytes"] / max(args.steps, 1),
+                                     "chunks_per_step": n_chunks,
+                                     "exposed_ms": float(allv[:, 6].max()),
+                                     "exposed_note": "per run, max over ranks: from the last kernel's end to the last transfer's "
+                                                     "completion on the root (the final chunk's gather; every other chunk travels "
+                                                     "under the next chunk's kernels)",
                                      "padded_format_bytes_per_step": F * (4 + K_MAX * (32 + 2 * C))} if multi else None)},
             "roofline": dict({"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": ach / HBM_PEAK_GBS, "traffic": traffic,

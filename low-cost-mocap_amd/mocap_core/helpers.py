@@ -35,6 +35,8 @@ DEFAULT_BA_MODE = "scipy"
 
 _state = {
     "core": None,
+    "ba_core": None,         # bundle adjustment's own context (own stream, own lock inside the library): a calibration never blocks the frame loop
+    "ba_lock": threading.Lock(),   # one calibration at a time (the reference's handler is not re-entrant either)
     "camera_params": None,   # list of dicts like api/camera-params.json
     "cam_key": None,         # bytes of (K, R, t) currently uploaded
     "lock": threading.Lock(),
@@ -50,9 +52,20 @@ def get_core(device_id=0):
     return _state["core"]
 
 
+def _ba_core():
+    """Bundle adjustment runs on its own context of the same GPU: the reference's frame loop (helpers.py:68-135, MJPEG
+    thread) keeps running while calculate_camera_pose -> bundle_adjustment (index.py:229-277) runs in a socket handler
+    thread; one context means one internal lock and one stream, i.e. a calibration of seconds in front of every frame."""
+    if _state["ba_core"] is None:
+        _state["ba_core"] = capi.MocapCore(get_core().device_id)
+    return _state["ba_core"]
+
+
 def set_core(core):
     """Use an existing MocapCore (e.g. one per GPU in a frame-sharded run)."""
     with _state["lock"]:
+        if _state["ba_core"] is not None and (core is None or core.device_id != _state["ba_core"].device_id):
+            _state["ba_core"] = None
         _state["core"] = core
         _state["cam_key"] = None      # cameras, lens model and world transform live in the context:
         _state["img_key"] = None      # re-upload them to the new one on first use
@@ -70,6 +83,23 @@ def set_camera_params(camera_params):
 def set_bundle_adjustment_mode(mode):
     assert mode in ("resident", "scipy")
     _state["ba_mode"] = mode
+
+
+class bundle_adjustment_mode:
+    """with helpers.bundle_adjustment_mode("resident"): ...  -- the previous mode comes back whatever happens inside."""
+
+    def __init__(self, mode):
+        assert mode in ("resident", "scipy")
+        self.mode = mode
+
+    def __enter__(self):
+        self.prev = _state["ba_mode"]
+        _state["ba_mode"] = self.mode
+        return self
+
+    def __exit__(self, *exc):
+        _state["ba_mode"] = self.prev
+        return False
 
 
 def _intrinsics(C):
@@ -426,14 +456,22 @@ def bundle_adjustment(image_points, camera_poses, socketio, return_info=False):
     per-evaluation host round trip and emits once per accepted step (1 / (n + 2) as often), then the final poses."""
     C = len(camera_poses)
     x0 = _ba_x0(camera_poses)
-    with _state["lock"]:
-        core = _upload_cameras(camera_poses)
-        obs = _obs_array(image_points, C)
-        def emit(params):
-            if socketio is not None:
-                socketio.emit("camera-pose", {"camera_poses": camera_pose_to_serializable(_params_to_camera_poses(params))})
+    obs = _obs_array(image_points, C)
+    R, t = _pose_arrays(camera_poses)
+    K = _intrinsics(C)
 
-        if _state["ba_mode"] == "resident":
+    def emit(params):
+        if socketio is not None:
+            socketio.emit("camera-pose", {"camera_poses": camera_pose_to_serializable(_params_to_camera_poses(params))})
+
+    # The solve runs on bundle adjustment's OWN context: the module lock -- the one every frame call takes -- is held only to
+    # fetch that context, never across a residual evaluation, let alone the whole solve.
+    with _state["lock"]:
+        core = _ba_core()
+        mode = _state["ba_mode"]
+    with _state["ba_lock"]:
+        core.set_cameras(K, R, t)
+        if mode == "resident":
             core.set_ba_progress(emit if socketio is not None else None)
             try:
                 x, info = core.ba_solve(x0, obs, ftol=1e-2, f32_residuals=True, use_cauchy=True)
@@ -450,7 +488,6 @@ def bundle_adjustment(image_points, camera_poses, socketio, return_info=False):
             res = optimize.least_squares(residual_function, x0, verbose=0, loss="cauchy", ftol=1e-2)
             x, info = res.x, {"iterations": res.njev, "njev": res.njev, "nfev": res.nfev, "status": res.status,
                        "cost": res.cost, "optimality": res.optimality}
-        _state["cam_key"] = None
     poses = _params_to_camera_poses(x)
     if socketio is not None:
         socketio.emit("camera-pose", {"camera_poses": camera_pose_to_serializable(poses)})

@@ -29,6 +29,15 @@ def test_bench_gpus2_self_launches_and_prints_one_rank0_line():
     assert line["config"]["frames_per_rank"] == [24, 25]  # uneven shards went through the count-first exchange
 
 
+def test_bench_gpus2_dry_run_at_the_stress_shape():
+    """--workload 64x256 through the same launcher / exchange: 64-camera records (160 bytes each)."""
+    p = _run({"MOCAP_BENCH_DRY": "1"}, "--gpus", "2", "--steps", "2", "--warmup", "1", "--frames", "9", "--workload", "64x256")
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    assert line["n_gpus"] == 2 and line["config"]["workload"] == "64x256" and line["config"]["record_bytes"] == 160
+    assert line["config"]["exchange"]["payload_checksums_match"] is True
+
+
 def test_bench_world_size_mismatch_is_an_error_not_a_silent_single_rank_run():
     p = _run({"MOCAP_BENCH_DRY": "1", "WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"}, "--gpus", "2")
     assert p.returncode != 0 and "WORLD_SIZE" in (p.stderr + p.stdout)

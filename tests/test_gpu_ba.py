@@ -283,11 +283,8 @@ def _reference_mode(core, name, mode):
     helpers.set_core(core)
     helpers.set_camera_params([{"intrinsic_matrix": k.tolist()} for k in g["K"]])
     poses0 = [{"R": g["R_init"][i].copy(), "t": g["t_init"][i].copy()} for i in range(C)]
-    helpers.set_bundle_adjustment_mode(mode)
-    try:
+    with helpers.bundle_adjustment_mode(mode):
         poses, info = helpers.bundle_adjustment(synth.obs_to_reference_array(g["obs"]), poses0, None, return_info=True)
-    finally:
-        helpers.set_bundle_adjustment_mode(helpers.DEFAULT_BA_MODE)
     R = np.array([np.asarray(p["R"], dtype=np.float64) for p in poses])
     t = np.array([np.asarray(p["t"], dtype=np.float64).reshape(3) for p in poses])
     return g, R, t, info
@@ -371,11 +368,11 @@ def test_helpers_bundle_adjustment_api(core):
             assert name == "camera-pose" and len(payload["camera_poses"]) == 4
             Sock.n += 1
     for mode in ("resident", "scipy"):
-        helpers.set_bundle_adjustment_mode(mode)
-        out = helpers.bundle_adjustment(synth.obs_to_reference_array(obs), poses0, Sock())
+        with helpers.bundle_adjustment_mode(mode):
+            out = helpers.bundle_adjustment(synth.obs_to_reference_array(obs), poses0, Sock())
         assert len(out) == 4 and np.array_equal(out[0]["R"], np.eye(3))
         assert all(np.asarray(p["R"]).shape == (3, 3) and np.asarray(p["t"]).size == 3 for p in out)
-    helpers.set_bundle_adjustment_mode(helpers.DEFAULT_BA_MODE)
+    assert helpers._state["ba_mode"] == helpers.DEFAULT_BA_MODE
     assert Sock.n >= 2            # progress events: tests/test_gpu_boundary.py counts them
 
 

@@ -141,12 +141,11 @@ def test_bundle_adjustment_streams_camera_poses(core):
             self.last = payload
     counts = {}
     for mode in ("resident", "scipy"):
-        helpers.set_bundle_adjustment_mode(mode)
         s = Sock()
-        out, info = helpers.bundle_adjustment(synth.obs_to_reference_array(obs), poses0, s, return_info=True)
+        with helpers.bundle_adjustment_mode(mode):
+            out, info = helpers.bundle_adjustment(synth.obs_to_reference_array(obs), poses0, s, return_info=True)
         counts[mode] = (s.n, info)
         np.testing.assert_allclose(np.array(s.last["camera_poses"][1]["R"]), np.asarray(out[1]["R"]), atol=0)
-    helpers.set_bundle_adjustment_mode(helpers.DEFAULT_BA_MODE)
     n_res, info_res = counts["resident"]
     assert n_res == int(info_res["njev"]) - 1 + 1                           # accepted steps + the final emit
     n_sp, info_sp = counts["scipy"]
@@ -193,3 +192,56 @@ def test_stream_handover_is_ordered_on_the_device(core):
         assert np.array_equal(o["n"].cpu().numpy(), want["n_out"]) and not o["st"].cpu().numpy().any()
         assert np.array_equal(o["xyz"].cpu().numpy()[valid], want["xyz"][valid])
         assert np.array_equal(o["corr"].cpu().numpy()[valid], want["corr"][valid])
+
+
+def test_frame_calls_stay_fast_while_a_calibration_runs(core):
+    """The reference's frame loop (helpers.py:68-135, MJPEG thread) keeps running while calculate_camera_pose ->
+    bundle_adjustment (index.py:229-277) runs in a handler thread.  The mirror runs the calibration on its own context /
+    stream and never holds the module lock across a residual evaluation: frame calls issued while a default-mode
+    (scipy) 8-camera bundle adjustment is in flight keep their sub-millisecond latency."""
+    import sys
+    import threading
+    import time
+    from conftest import load_golden
+    from mocap_core import helpers, synth
+    g = load_golden("ba_c8_n100_solved")
+    C = g["K"].shape[0]
+    helpers.set_core(core)
+    helpers.set_camera_params([{"intrinsic_matrix": k.tolist()} for k in g["K"]])
+    poses0 = [{"R": g["R_init"][i].copy(), "t": g["t_init"][i].copy()} for i in range(C)]
+    rig = synth.ring_rig(8)
+    blobs, counts, _ = synth.make_blob_stream(rig, 64, 16, seed=4)
+    frame_poses = synth.rig_to_pose_dicts(rig)
+    frames = [synth.frame_to_reference_lists(blobs[f], counts[f], as_int=True) for f in range(64)]
+    want = [helpers.find_point_correspondance_and_object_points([list(p) for p in fr], frame_poses, None)[1] for fr in frames]
+    result = {}
+
+    def calibrate():
+        t0 = time.perf_counter()
+        result["poses"], result["info"] = helpers.bundle_adjustment(synth.obs_to_reference_array(g["obs"]), poses0, None, return_info=True)
+        result["seconds"] = time.perf_counter() - t0
+
+    old = sys.getswitchinterval()
+    sys.setswitchinterval(1e-4)            # the calibration thread is mostly Python: hand the GIL over quickly
+    try:
+        th = threading.Thread(target=calibrate)
+        th.start()
+        lat, k = [], 0
+        while th.is_alive():
+            fr = [list(p) for p in frames[k % 64]]
+            t0 = time.perf_counter()
+            _, xyz, _ = helpers.find_point_correspondance_and_object_points(fr, frame_poses, None)
+            lat.append(time.perf_counter() - t0)
+            assert np.array_equal(xyz, want[k % 64])          # the two contexts do not disturb each other's cameras
+            k += 1
+            time.sleep(0.002)
+        th.join()
+    finally:
+        sys.setswitchinterval(old)
+    assert result["seconds"] > 0.3 and len(lat) > 50, (result.get("seconds"), len(lat))       # the calibration really overlapped
+    lat = np.sort(np.array(lat)) * 1e3
+    p50, p99 = lat[len(lat) // 2], lat[int(len(lat) * 0.99)]
+    assert p50 < 0.5 and p99 < 1.0, (p50, p99, lat[-1])
+    # and the calibration's own answer is the reference's, as when it runs alone
+    R = np.array([np.asarray(p["R"], dtype=np.float64) for p in result["poses"]])
+    assert np.abs(R - g["R_ba"]).max() == 0.0 and int(result["info"]["nfev"]) == int(g["ba_stats"][0])

@@ -13,10 +13,11 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("world,comm_stream", [(2, False), (3, False), (2, True)])
-def test_sharded_gpu_run_equals_one_rank_bitwise(world, comm_stream):
+@pytest.mark.parametrize("world,comm_stream,workload", [(2, False, "8x16"), (3, False, "8x16"), (2, True, "8x16"), (2, True, "64x256")])
+def test_sharded_gpu_run_equals_one_rank_bitwise(world, comm_stream, workload):
     """comm_stream: the exchange is posted under a side stream and completed on a busy compute stream (bench.py's
-    arrangement; the root's receive buffers then belong to the side stream's allocator pool)."""
+    arrangement; the root's receive buffers then belong to the side stream's allocator pool).  64x256: BASELINE
+    configs[4]'s shape (wide variant, 160-byte records)."""
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -24,6 +25,7 @@ def test_sharded_gpu_run_equals_one_rank_bitwise(world, comm_stream):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env["MULTIRANK_COMM_STREAM"] = "1" if comm_stream else "0"
+    env["MULTIRANK_WORKLOAD"] = workload
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
                         "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "_multirank_worker.py")],
                        env=env, capture_output=True, text=True, timeout=600)
