@@ -56,6 +56,9 @@ namespace mocap {
 #ifndef MOCAP_WIDE_DEBUG_SKIP
 #define MOCAP_WIDE_DEBUG_SKIP 0
 #endif
+#ifndef MOCAP_WIDE_CHAIN_T
+#define MOCAP_WIDE_CHAIN_T 24  // wide frames: a chain step with fewer new roots than this keeps the blobs in registers and broadcasts the roots (swept: 8 +2 %, 0 +34 %, never = 24)
+#endif
 #ifndef MOCAP_FRAME_WAVES_PER_EU
 #define MOCAP_FRAME_WAVES_PER_EU 4
 #endif
@@ -935,7 +938,7 @@ struct FrameState {
         }
         if (j + 1 < C && !(MOCAP_WIDE_DEBUG_SKIP & 2)) {
           // few new roots (the usual chain step): the blobs stay in registers and the roots are broadcast; many: one lane per root
-          if (now - n_roots < 24) match_pairs_wide(n_roots, now, j + 1); else match_roots_wide<false>(n_roots, now, j + 1);
+          if (now - n_roots < MOCAP_WIDE_CHAIN_T) match_pairs_wide(n_roots, now, j + 1); else match_roots_wide<false>(n_roots, now, j + 1);
         }
         __syncthreads();
       }
