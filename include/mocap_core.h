@@ -45,8 +45,10 @@ enum {
 enum {
   MOCAP_ST_ROOT_OVERFLOW = 1, /* more roots than K_max: frame output invalid          */
   MOCAP_ST_CAND_OVERFLOW = 2, /* a root has more than G_cap candidate groups: invalid */
-  MOCAP_ST_HIT_OVERFLOW = 4   /* wide frames only: a (root, camera) pair has more gated hits
+  MOCAP_ST_HIT_OVERFLOW = 4,  /* wide frames only: a (root, camera) pair has more gated hits
                                  than hit_cap (mocap_set_frame_limits): invalid          */
+  MOCAP_ST_ROUNDED = 8        /* mocap_match_triangulate_f64 only, INFORMATIONAL (outputs valid): a coordinate of the
+                                 frame was not representable in float32 and was rounded to the nearest float32 */
 };
 
 /* flags for mocap_set_options */
@@ -151,6 +153,15 @@ int mocap_match_triangulate_auto(mocap_ctx* ctx, int64_t n_frames, int M_max, co
                                  const int32_t* counts, double gate_px, int K_max, int64_t G_cap, double* xyz,
                                  double* err, int16_t* corr, int32_t* n_out, int32_t* status, int32_t* n_cand,
                                  int32_t* n_resubmitted);
+
+/* mocap_match_triangulate_f64: the same for DOUBLE centroids (the reference measures on whatever its image_points hold,
+ * helpers.py:367-373: int64 for _find_dot's int() centroids, float64 for anything else).  blobs [F][C][M_max][2] float64.
+ * Coordinates float32 can represent (every integer pixel, every float32-valued centroid) are used exactly; any other is
+ * rounded to the nearest float32 and the frame's status gets MOCAP_ST_ROUNDED (informational); NaN / infinite
+ * coordinates are MOCAP_E_ARG.  Everything else as mocap_match_triangulate_auto. */
+int mocap_match_triangulate_f64(mocap_ctx* ctx, int64_t n_frames, int M_max, const double* blobs, const int32_t* counts,
+                                double gate_px, int K_max, int64_t G_cap, double* xyz, double* err, int16_t* corr,
+                                int32_t* n_out, int32_t* status, int32_t* n_cand, int32_t* n_resubmitted);
 
 /* ---------------------------------------------------------------- before the path
  * Blob extraction: replaces the per-camera preprocessing of Cameras._camera_read (helpers.py:68-82:

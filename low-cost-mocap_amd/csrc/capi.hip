@@ -967,6 +967,51 @@ extern "C" int mocap_match_triangulate_auto(mocap_ctx* ctx, int64_t n_frames, in
   return MOCAP_OK;
 }
 
+// ------------------------------------------------------------------ double-precision centroids at the boundary
+// The reference measures on whatever its image_points lists hold (helpers.py:367-373): int64 for _find_dot's int()
+// centroids, float64 for anything else.  The kernels carry blob coordinates as float32 (half the LDS / HBM bytes of the
+// one array every phase reads).  This entry takes doubles: coordinates float32 can represent -- every integer pixel below
+// 2^24, every float32-valued sub-pixel centroid -- go through unchanged, i.e. EXACTLY as the reference would see them;
+// anything else is rounded to the nearest float32 (|dx| <= 2^-24 |x|: 2e-5 px at 320 px, far inside north_star's 1e-5
+// relative on the points) and the frame is FLAGGED (MOCAP_ST_ROUNDED, informational: the outputs are valid) instead of
+// being refused or silently altered.  NaN / inf coordinates are an argument error.
+extern "C" int mocap_match_triangulate_f64(mocap_ctx* ctx, int64_t n_frames, int M_max, const double* blobs,
+                                           const int32_t* counts, double gate_px, int K_max, int64_t G_cap, double* xyz,
+                                           double* err, int16_t* corr, int32_t* n_out, int32_t* status, int32_t* n_cand,
+                                           int32_t* n_resubmitted) {
+  if (!ctx) return MOCAP_E_ARG;
+  int C;
+  {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (!ctx->C) return ctx->fail(MOCAP_E_NOCAMS, "mocap_set_cameras has not been called");
+    if (n_frames < 0 || M_max < 1 || K_max < 1) return ctx->fail(MOCAP_E_ARG, "mocap_match_triangulate_f64: bad size argument");
+    if (n_frames > 0 && (!blobs || !counts || !status)) return ctx->fail(MOCAP_E_ARG, "mocap_match_triangulate_f64: null buffer");
+    C = ctx->C;
+  }
+  const size_t per = (size_t)C * M_max * 2;
+  std::vector<float> b32((size_t)n_frames * per);
+  std::vector<uint8_t> rounded((size_t)n_frames, 0);
+  for (int64_t f = 0; f < n_frames; f++)
+    for (int c = 0; c < C; c++) {
+      int n = counts[(size_t)f * C + c];
+      n = n < 0 ? 0 : (n > M_max ? M_max : n);
+      for (int k = 0; k < 2 * n; k++) {
+        const size_t o = (size_t)f * per + (size_t)c * M_max * 2 + k;
+        const double v = blobs[o];
+        if (!(v - v == 0.0)) return ctx->fail(MOCAP_E_ARG, "mocap_match_triangulate_f64: frame %lld camera %d: coordinate is NaN or infinite", (long long)f, c);
+        const float r = (float)v;
+        b32[o] = r;
+        if ((double)r != v) rounded[f] = 1;
+      }
+    }
+  const int rc = mocap_match_triangulate_auto(ctx, n_frames, M_max, b32.data(), counts, gate_px, K_max, G_cap, xyz, err, corr, n_out,
+                                              status, n_cand, n_resubmitted);
+  if (rc) return rc;
+  for (int64_t f = 0; f < n_frames; f++)
+    if (rounded[f]) status[f] |= MOCAP_ST_ROUNDED;
+  return MOCAP_OK;
+}
+
 // ------------------------------------------------------------------ the live loop in one call
 // helpers.py:94-133 per frame: find_point_correspondance_and_object_points -> world coordinates -> locate_objects ->
 // the `object-points` payload.  One enqueue: [blob stage ->] frame kernel (world epilogue fused in its store) -> one wave

@@ -22,6 +22,7 @@ MOCAP_E_NOCONV = -5
 ST_ROOT_OVERFLOW = 1
 ST_CAND_OVERFLOW = 2
 ST_HIT_OVERFLOW = 4
+ST_ROUNDED = 8          # informational (mocap_match_triangulate_f64): a coordinate was rounded to float32
 BLOB_ST_POINT_OVERFLOW = 1
 BLOB_ST_CAP_OVERFLOW = 2
 OPT_F32_ROUNDING = 1
@@ -48,6 +49,7 @@ SIGNATURES = {
     "mocap_match_triangulate": (_i32, [_vp, _i64, _i32, _vp, _vp, _dbl, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mocap_match_triangulate_dev": (_i32, [_vp, _i64, _i32, _vp, _vp, _dbl, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mocap_match_triangulate_auto": (_i32, [_vp, _i64, _i32, _vp, _vp, _dbl, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mocap_match_triangulate_f64": (_i32, [_vp, _i64, _i32, _vp, _vp, _dbl, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mocap_track_frame": (_i32, [_vp, _i64, _i32, _vp, _vp, _dbl, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
     "mocap_track_frame_images": (_i32, [_vp, _i64, _vp, _i32, _dbl, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp,
                                         _vp, _vp, _vp]),
@@ -248,6 +250,26 @@ class MocapCore:
             for key in ("n_out", "status", "n_cand"):
                 res[key][need] = big[key]
         return res
+
+    def match_triangulate_f64(self, blobs, counts, gate_px=5.0, K_max=None, G_cap=1 << 20):
+        """mocap_match_triangulate_f64: double centroids.  float32-representable coordinates are used exactly; others are
+        rounded to the nearest float32 and the frame's status carries ST_ROUNDED (informational)."""
+        blobs = np.ascontiguousarray(blobs, dtype=np.float64)
+        counts = np.ascontiguousarray(counts, dtype=np.int32)
+        F, C, M, _ = blobs.shape
+        assert C == self.C and counts.shape == (F, C)
+        K_max = min(C * M, 64) if K_max is None else int(K_max)
+        while True:
+            out = {"xyz": np.full((F, K_max, 3), np.nan), "err": np.full((F, K_max), np.nan), "corr": np.full((F, K_max, C), -1, dtype=np.int16),
+                   "n_out": np.zeros(F, dtype=np.int32), "status": np.zeros(F, dtype=np.int32), "n_cand": np.zeros(F, dtype=np.int32)}
+            self._check(self.lib.mocap_match_triangulate_f64(self._h, F, M, _p(blobs), _p(counts), float(gate_px), K_max, int(G_cap),
+                                                             _p(out["xyz"]), _p(out["err"]), _p(out["corr"]), _p(out["n_out"]),
+                                                             _p(out["status"]), _p(out["n_cand"]), None))
+            need = ((out["status"] & ~ST_ROUNDED) == ST_ROOT_OVERFLOW) & (out["n_out"] > K_max)
+            if need.any():
+                K_max = int(out["n_out"][need].max())
+                continue
+            return out
 
     # ------------------------------------------------------------------ the live loop in one call
     def _track_outputs(self, F, K_max, O_max):

@@ -191,29 +191,35 @@ def calculate_reprojection_error(image_points, object_point, camera_poses):
 
 
 # ----------------------------------------------------------------------------- frame path
-def pack_frame(image_points, M_max=None):
-    """Nested lists of one frame -> (blobs f32 [1][C][M][2], counts i32 [1][C])."""
+def pack_frame(image_points, M_max=None, strict=False):
+    """Nested lists of one frame -> (blobs f32 [1][C][M][2], counts i32 [1][C], rounded: bool).
+
+    The C ABI's frame path carries blob coordinates as float32.  The reference measures point-line distances on whatever
+    image_points holds (helpers.py:367-373: int64 for _find_dot's int() centroids, float64 for floats).  Integer centroids
+    (the reference's own, |x| < 2^24) and float32-valued sub-pixel centroids are carried exactly.  Any other float64
+    coordinate is rounded to the nearest float32 (2e-5 px at 320 px; `rounded` says so) -- or refused with strict=True.
+    NaN / infinite coordinates are always refused."""
     C = len(image_points)
     n = [len(p) for p in image_points]
     M = max(1, max(n) if n else 1) if M_max is None else M_max
     blobs = np.full((1, C, M, 2), np.nan, dtype=np.float32)
     counts = np.zeros((1, C), dtype=np.int32)
+    rounded = False
     for c, pts in enumerate(image_points):
         if pts:
             exact = np.asarray(pts, dtype=np.float64)
+            if not np.isfinite(exact).all():
+                raise ValueError(f"image point of camera {c} is NaN or infinite")
             as_f32 = exact.astype(np.float32)
-            # The C ABI carries blob coordinates as float32.  The reference measures point-line distances on whatever
-            # image_points holds (helpers.py:367-373: int64 for _find_dot's int() centroids, float64 for floats), so a
-            # coordinate that float32 cannot represent would be silently rounded before the 5 px gate.  Integer
-            # centroids (the reference's own, |x| < 2^24) and float32-valued sub-pixel centroids pass; anything else is
-            # refused rather than rounded.
             if not np.array_equal(as_f32.astype(np.float64), exact):
-                bad = exact[as_f32.astype(np.float64) != exact][0]
-                raise ValueError(f"image point coordinate {bad!r} (camera {c}) is not representable in float32: the core's "
-                                 "blob arrays are float32 (include/mocap_core.h); round sub-pixel centroids to float32 first")
+                if strict:
+                    bad = exact[as_f32.astype(np.float64) != exact][0]
+                    raise ValueError(f"image point coordinate {bad!r} (camera {c}) is not representable in float32: the core's "
+                                     "blob arrays are float32 (include/mocap_core.h)")
+                rounded = True
             blobs[0, c, :len(pts)] = as_f32
         counts[0, c] = len(pts)
-    return blobs, counts
+    return blobs, counts, rounded
 
 
 def find_point_correspondance_and_object_points(image_points, camera_poses, frames):
@@ -227,7 +233,7 @@ def find_point_correspondance_and_object_points(image_points, camera_poses, fram
             pass
     with _state["lock"]:
         core = _upload_cameras(camera_poses)
-        blobs, counts = pack_frame(image_points)
+        blobs, counts, _ = pack_frame(image_points)
         res = core.match_triangulate_auto(blobs, counts, gate_px=5.0)
     if int(res["status"][0]) != 0:
         # still over a cap after the worst-case re-submit (> 2^24 candidate groups for one root, > 2^32 per
@@ -328,7 +334,7 @@ def track_frame(image_points, camera_poses, is_locating_objects=True, O_max=8):
             pass
     with _state["lock"]:
         core = _upload_cameras(camera_poses)
-        blobs, counts = pack_frame(image_points)
+        blobs, counts, _ = pack_frame(image_points)
         res = core.track_frame(blobs, counts, gate_px=5.0, O_max=O_max if is_locating_objects else 0)
     if int(res["status"][0]) != 0:
         raise capi.MocapError(f"frame exceeds the core's limits (status {int(res['status'][0])}): "

@@ -175,3 +175,37 @@ def test_c_level_resubmit_of_overflowed_frames(core):
     assert int(live["status"][0]) == 0 and int(live["n_pts"][0]) == int(want["n_out"][f])
     k = int(want["n_out"][f])
     assert np.array_equal(live["xyz"][0, :k], want["xyz"][f, :k])
+
+
+def test_double_precision_centroids_at_the_boundary(core):
+    """mocap_match_triangulate_f64: float64 blob arrays (the reference measures on whatever its lists hold,
+    helpers.py:367-373).  float32-representable coordinates -- the reference's own int() centroids -- give bit for bit
+    the float32 entry's results; sub-pixel float64 centroids are rounded to the nearest float32 (frames flagged
+    ST_ROUNDED, outputs valid) and agree with the C oracle run on the rounded coordinates exactly and with the
+    unrounded ones to north_star's 1e-5."""
+    from mocap_core import capi, synth
+    from oracle import c_oracle
+    rig = synth.ring_rig(8)
+    blobs, counts, _ = synth.make_blob_stream(rig, 200, 16, seed=9)
+    core.set_cameras(rig["K"], rig["R"], rig["t"])
+    want = core.match_triangulate_auto(blobs, counts, K_max=64)
+    got = core.match_triangulate_f64(blobs.astype(np.float64), counts, K_max=64)
+    assert not got["status"].any()
+    valid = np.arange(64)[None, :] < want["n_out"][:, None]
+    assert np.array_equal(got["n_out"], want["n_out"])
+    for key in ("xyz", "err", "corr"):
+        assert np.array_equal(got[key][valid], want[key][valid]), key
+    # sub-pixel float64 centroids
+    sub, counts2, _ = synth.make_blob_stream(rig, 200, 16, seed=10, truncate=False)
+    sub64 = sub.astype(np.float64) + np.random.default_rng(1).uniform(-1e-5, 1e-5, sub.shape)
+    sub64[np.isnan(sub64)] = 0.0
+    got = core.match_triangulate_f64(sub64, counts2, K_max=64)
+    assert (got["status"] == capi.ST_ROUNDED).all()
+    ref = c_oracle.COracle(rig["K"], rig["R"], rig["t"]).match_triangulate(sub64.astype(np.float32), counts2, K_max=64)
+    valid = np.arange(64)[None, :] < ref["n_out"][:, None]
+    assert np.array_equal(got["n_out"], ref["n_out"]) and np.array_equal(got["corr"][valid], ref["corr"][valid])
+    np.testing.assert_allclose(got["xyz"][valid], ref["xyz"][valid], rtol=1e-9, atol=1e-12)
+    with pytest.raises(capi.MocapError, match="NaN"):
+        bad = sub64.copy()
+        bad[3, 2, 0, 1] = np.nan
+        core.match_triangulate_f64(bad, counts2, K_max=64)

@@ -79,8 +79,8 @@ def test_synth_is_deterministic_and_well_formed():
 def test_host_marshalling():
     from mocap_core import helpers
     pts = [[[10, 20], [30, 40]], [], [[5, 6]]]
-    blobs, counts = helpers.pack_frame(pts)
-    assert blobs.shape == (1, 3, 2, 2) and counts.tolist() == [[2, 0, 1]]
+    blobs, counts, rounded = helpers.pack_frame(pts)
+    assert not rounded and blobs.shape == (1, 3, 2, 2) and counts.tolist() == [[2, 0, 1]]
     assert blobs[0, 0, 1].tolist() == [30.0, 40.0] and np.isnan(blobs[0, 1]).all()
     obs = helpers._obs_array([[[1, 2], [None, None]], [[3.5, 4.5], [6, 7]]], 2)
     assert obs.shape == (2, 2, 2) and np.isnan(obs[0, 1]).all() and obs[1, 0, 0] == 3.5
@@ -224,17 +224,21 @@ def test_record_pack_roundtrip():
     assert all(np.array_equal(back[k], v) for k, v in (("n_out", n_out), ("xyz", xyz), ("err", err), ("corr", corr)))
 
 
-def test_pack_frame_refuses_coordinates_float32_cannot_carry():
-    """helpers.py:367-373 computes distances on image_points as given (int64 / float64); the C ABI's blob arrays are
+def test_pack_frame_carries_exactly_what_float32_can_and_says_when_it_rounds():
+    """helpers.py:367-373 computes distances on image_points as given (int64 / float64); the C ABI's frame path carries
     float32.  Integer centroids (the reference's own, helpers.py:153-154) and float32-valued sub-pixel centroids go
-    through unchanged; a float64 coordinate that would be rounded is refused, not silently changed."""
+    through unchanged; any other float64 coordinate is rounded to the nearest float32 and REPORTED (strict=True refuses
+    it instead); NaN / inf are always refused -- the reference's seam accepts float64 lists, so the default must not raise."""
     import pytest
     from mocap_core import helpers
-    b, c = helpers.pack_frame([[[12, 250], [319, 0]], [], [[1.5, 2.25]]])
-    assert b.dtype == np.float32 and c.tolist() == [[2, 0, 1]] and b[0, 2, 0].tolist() == [1.5, 2.25]
-    b, _ = helpers.pack_frame([[[float(np.float32(100.1)), 7.0]]])        # a float32 value held in a Python float
-    assert b[0, 0, 0, 0] == np.float32(100.1)
+    b, c, rounded = helpers.pack_frame([[[12, 250], [319, 0]], [], [[1.5, 2.25]]])
+    assert not rounded and b.dtype == np.float32 and c.tolist() == [[2, 0, 1]] and b[0, 2, 0].tolist() == [1.5, 2.25]
+    b, _, rounded = helpers.pack_frame([[[float(np.float32(100.1)), 7.0]]])        # a float32 value held in a Python float
+    assert not rounded and b[0, 0, 0, 0] == np.float32(100.1)
+    b, _, rounded = helpers.pack_frame([[[100.1, 7.0]]])                            # 100.1 is not a float32 value: rounded, flagged
+    assert rounded and b[0, 0, 0, 0] == np.float32(100.1)
+    assert helpers.pack_frame([[[2 ** 24 + 1, 0]]])[2]                              # nor is this integer
     with pytest.raises(ValueError, match="float32"):
-        helpers.pack_frame([[[100.1, 7.0]]])                               # 100.1 is not a float32 value
-    with pytest.raises(ValueError, match="float32"):
-        helpers.pack_frame([[[2 ** 24 + 1, 0]]])                           # nor is this integer
+        helpers.pack_frame([[[100.1, 7.0]]], strict=True)
+    with pytest.raises(ValueError, match="NaN"):
+        helpers.pack_frame([[[float("nan"), 7.0]]])
