@@ -12,7 +12,7 @@ done
 wait
 for spec in "$@"; do
   tag=${spec%%=*}
-  objs=$(ls build/*.o | grep -v "frame_bb" | tr '\n' ' ')
+  objs=$(ls build/*.o | grep -v "frame_bb" | grep -v "_v_\|pretest" | tr '\n' ' ')
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o lib/libmocap_core_$tag.so $objs build/frame_bb_$tag.o
   echo "built lib/libmocap_core_$tag.so ($spec)"
 done

@@ -12,7 +12,7 @@ done
 wait
 for spec in "$@"; do
   tag=${spec%%=*}
-  objs=$(ls build/*.o | grep -v "frame_kernel" | grep -v eigcheck | tr '\n' ' ')
+  objs=$(ls build/*.o | grep -v "frame_kernel" | grep -v "eigcheck\|frame_bb_" | tr '\n' ' ')
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o lib/libmocap_core_$tag.so $objs build/frame_kernel_v_$tag.o
   echo "built lib/libmocap_core_$tag.so ($spec)"
 done

@@ -3,7 +3,7 @@
 # variants that leave phases out (scripts/build_bb_variants.sh skip1 / skip3 / skip7).
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-O=$R/gpurun_out/r03; mkdir -p $O
+O=$R/gpurun_out/r04; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 for v in base skip1 skip3 skip7; do
   [ $v = base ] && unset MOCAP_CORE_LIB || export MOCAP_CORE_LIB=$R/low-cost-mocap_amd/lib/libmocap_core_$v.so
