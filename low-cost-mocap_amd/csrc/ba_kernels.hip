@@ -483,7 +483,10 @@ __global__ __launch_bounds__(kFusedThreads) void ba_fused_kernel(BaFusedArgs a) 
             go = 1;
             break;
           }
-          if (sq == -a.stamp || wall_clock64() - t0 > 250000000ull) break;
+          // ONLY the lead workgroup decides (its watchdog: 2 s after ITS start): the others wait for its verdict, +stamp or
+          // -stamp.  Their own clock is a last resort far beyond that (30 s: a workgroup that became resident long before
+          // the lead must not give up while the lead still accepts the point -- the completion counter would never fill).
+          if (sq == -a.stamp || wall_clock64() - t0 > 3000000000ull) break;
           __builtin_amdgcn_s_sleep(2);
         }
         sh_last = go;

@@ -591,7 +591,7 @@ int ba_linearize_fused(mocap_ctx* ctx, BaWork& w, const double* x, int f32, int 
   // (a few microseconds; an event query costs a driver call per poll)
   const size_t nG = (size_t)w.NP * w.NP;
   volatile double* done = w.h_fout + nG + 2;
-  const auto t0 = std::chrono::steady_clock::now();
+  auto t0 = std::chrono::steady_clock::now();  // (restarted when the linearisation is launched again below)
   auto t_prev = t0;
   for (long spins = 0; *done != stamp; spins++) {
     if (*done == -stamp) {
@@ -604,6 +604,7 @@ int ba_linearize_fused(mocap_ctx* ctx, BaWork& w, const double* x, int f32, int 
       rc = ba_fused_launch(ctx, w, x, f32, cauchy, rel_step, stamp);
       if (rc) return rc;
       w.prof_relaunches++;
+      t0 = std::chrono::steady_clock::now();
       continue;
     }
     if (w.prof && (spins & 0xff) == 0xff) {
