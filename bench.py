@@ -56,7 +56,7 @@ def algorithmic_bytes(counts, n_out, C, M):
     return F * (8 * C * M + 4 * C) + int(n_out.sum()) * (24 + 8 + 2 * C)
 
 
-PROFILE_TAG = "r03"           # profiles/<tag>_hbm_traffic.json, <tag>_fp64_mix.json (scripts/profile_frame_pmc.sh)
+PROFILE_TAG = "r04"           # profiles/<tag>_hbm_traffic.json, <tag>_fp64_mix.json (scripts/profile_frame_pmc.sh)
 
 
 def kernel_source_hash():

@@ -3,7 +3,7 @@
 # command, then one counter set per run (FP64 instruction mix; issue mix; FETCH_SIZE; WRITE_SIZE), and the two JSON
 # summaries bench.py reads (stamped with git HEAD + source hash).  usage: profile_frame_pmc.sh <git head> [tag]
 set -u
-HEAD=${1:-unknown}; TAG=${2:-r03}
+HEAD=${1:-unknown}; TAG=${2:-r04}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$TAG/prof; rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
