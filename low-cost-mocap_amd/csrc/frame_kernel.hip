@@ -56,6 +56,12 @@ namespace mocap {
 #ifndef MOCAP_WIDE_DEBUG_SKIP
 #define MOCAP_WIDE_DEBUG_SKIP 0
 #endif
+#ifndef MOCAP_WIDE_ACC
+#define MOCAP_WIDE_ACC 1  // (1: 32.4 -> 30.5 ms per 12 500 stress frames)
+#endif
+#ifndef MOCAP_WIDE_DEPTH_CUT
+#define MOCAP_WIDE_DEPTH_CUT 0
+#endif
 #ifndef MOCAP_WIDE_CHAIN_T
 #define MOCAP_WIDE_CHAIN_T 24  // wide frames: a chain step with fewer new roots than this keeps the blobs in registers and broadcasts the roots (swept: 8 +2 %, 0 +34 %, never = 24)
 #endif
@@ -607,6 +613,11 @@ struct FrameState {
           if (F32R) thr = __double2float_ru(p.gate_px * lden * (1.0 + 1e-12) + (2.5 * 0x1p-24) * (2.0 * om + fabs(lc)) * (1.0 + 1e-6));
           if (!have) thr = -1.0f;
           int np = 0, kk = 0;
+#if MOCAP_WIDE_ACC
+          // bookkeeping as four accumulators, one per position of a step: += 0x10000 + k0 when the blob passes, i.e. the
+          // count in the high half and the index (sum) in the low half -- a select and an add per blob
+          uint32_t acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
+#endif
           for (int k0 = 0; k0 < M4; k0 += 4) {  // scalar loop; four blobs per step, two broadcast reads
             const float4 X = *reinterpret_cast<const float4*>(wx + k0);
             const float4 Y = *reinterpret_cast<const float4*>(wy + k0);
@@ -614,6 +625,15 @@ struct FrameState {
             const float t2 = fmaf(a32, X.z, fmaf(b32, Y.z, c32)), t3 = fmaf(a32, X.w, fmaf(b32, Y.w, c32));
             const unsigned long long m0 = __ballot(fabsf(t0) <= thr), m1 = __ballot(fabsf(t1) <= thr);
             const unsigned long long m2 = __ballot(fabsf(t2) <= thr), m3 = __ballot(fabsf(t3) <= thr);
+#if MOCAP_WIDE_ACC
+            if ((m0 | m1) | (m2 | m3)) {
+              const uint32_t kb = 0x10000u + (uint32_t)k0;
+              acc0 += fabsf(t0) <= thr ? kb : 0u;
+              acc1 += fabsf(t1) <= thr ? kb : 0u;
+              acc2 += fabsf(t2) <= thr ? kb : 0u;
+              acc3 += fabsf(t3) <= thr ? kb : 0u;
+            }
+#else
             if ((m0 | m1) | (m2 | m3)) {  // some root of the batch has a candidate among these four (scalar branch)
               if (m0) {
                 const bool ps = fabsf(t0) <= thr;
@@ -636,7 +656,12 @@ struct FrameState {
                 kk = ps ? k0 + 3 : kk;
               }
             }
+#endif
           }
+#if MOCAP_WIDE_ACC
+          np = (int)((acc0 >> 16) + (acc1 >> 16) + (acc2 >> 16) + (acc3 >> 16));
+          kk = acc0 ? (int)(acc0 & 0xffffu) : (acc1 ? (int)(acc1 & 0xffffu) + 1 : (acc2 ? (int)(acc2 & 0xffffu) + 2 : (int)(acc3 & 0xffffu) + 3));  // (meaningful when np == 1)
+#endif
 #ifdef MOCAP_DEBUG_PRETEST  // self-check build: the exact decision (helpers.py:373,375) for EVERY blob the float32 pre-test
           if (have) {          // rejected; a blob inside the gate among them is a false negative (must never happen)
             int fneg = 0;
@@ -1175,7 +1200,10 @@ struct FrameState {
         } else if constexpr (TABLE)
           triangulate_and_score_tab<true, F32R>(cv, contrib, obs_ix, X, e, bound, ec);
         else if constexpr (WIDE)
-          triangulate_and_score<UNIFORM_K, true, F32R, MOCAP_WIDE_BATCH>(cv, wobs, wobs, X, e, bound, ec);
+          // (no depth form of the eigenvalue bound here: a wide frame's rival groups differ from the right one in one or two
+          // of ~60 views by a blob within the gate of the line -- near-winners no bound separates -- so that pass over the
+          // cameras, a sixth of a group's instructions, cut nothing; exactness is unaffected: a cut-off only ever skips work)
+          triangulate_and_score<UNIFORM_K, true, F32R, MOCAP_WIDE_BATCH, (MOCAP_WIDE_DEPTH_CUT != 0)>(cv, wobs, wobs, X, e, bound, ec);
         else
           triangulate_and_score<UNIFORM_K, true, F32R, 1>(cv, obs, obs, X, e, bound, ec);
 #ifdef MOCAP_DEBUG_EIGCHECK  // self-check of the cut-offs: a group that was cut must not beat the bound it was cut against

@@ -556,7 +556,7 @@ __device__ __forceinline__ void score_point(const View& cv, int v, Obs2&& obs2, 
 //   raw(c) -> the camera's 8 bytes, loaded unconditionally;  decode(raw, x, y) -> seen?;  operator()(c, x, y)
 // (a lambda that tests x before it reads y compiles to two dependent loads per view, each followed by a wait -- measured).
 // The views are still accumulated in camera order, so the result is the same to the bit.
-template <bool UNIFORM_K, bool PAIRWISE, bool F32R, int BATCH = 1, class View, class Obs1, class Obs2>
+template <bool UNIFORM_K, bool PAIRWISE, bool F32R, int BATCH = 1, bool DEPTH_CUT = true, class View, class Obs1, class Obs2>
 __device__ __forceinline__ int triangulate_and_score(const View& cv, Obs1&& obs1, Obs2&& obs2,
                                                      double (&X)[3], double& err,
                                                      double limit_e = __builtin_huge_val(), const EigCut& ec = EigCut{}) {
@@ -587,7 +587,7 @@ __device__ __forceinline__ int triangulate_and_score(const View& cv, Obs1&& obs1
     }
   }
   if (v <= 1) return v;  // helpers.py:300
-  solve_and_score<UNIFORM_K, PAIRWISE, F32R, true, BATCH>(cv, B, v, obs2, X, err, limit_e * (double)(2 * v) * (1.0 + 0x1p-40), ec);
+  solve_and_score<UNIFORM_K, PAIRWISE, F32R, DEPTH_CUT, BATCH>(cv, B, v, obs2, X, err, limit_e * (double)(2 * v) * (1.0 + 0x1p-40), ec);
   return v;
 }
 
