@@ -282,28 +282,41 @@ __global__ __launch_bounds__(256) void compact_add_block_offsets_kernel(CompactA
 }
 
 __global__ __launch_bounds__(256) void compact_scatter_kernel(CompactArgs a) {
-  // one lane per (frame, slot); a lane writes its whole record
+  // one lane per (frame, slot, 8-byte word of the record): consecutive lanes write consecutive words, so a record of any
+  // length leaves as full cache lines (one lane per record, round 2, was fine for 48-byte records and cost 40 % of a step
+  // at 64 cameras' 160 bytes)
+  const int parts = a.stride >> 3;
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t f = idx / a.K_max;
-  const int k = (int)(idx - f * a.K_max);
+  const int64_t slot = idx / parts;
+  const int part = (int)(idx - slot * parts);
+  const int64_t f = slot / a.K_max;
+  const int k = (int)(slot - f * a.K_max);
   if (f >= a.n_frames) return;
   int n = a.n_out[f];
   n = n < 0 ? 0 : (n > a.K_max ? a.K_max : n);
-  const int64_t off = a.offsets[f];
   if (k >= n) return;
-  const int64_t rec = off + k;
+  const int64_t rec = a.offsets[f] + k;
   if (rec >= a.capacity) return;
-  unsigned char* dst = a.records + (size_t)rec * a.stride;
+  unsigned long long* dst = (unsigned long long*)(a.records + (size_t)rec * a.stride) + part;
   const size_t o = (size_t)f * a.K_max + k;
-  double* d = (double*)dst;
-  d[0] = a.xyz[o * 3 + 0];
-  d[1] = a.xyz[o * 3 + 1];
-  d[2] = a.xyz[o * 3 + 2];
-  d[3] = a.err[o];
-  int16_t* c = (int16_t*)(dst + 32);
-  const int16_t* src = a.corr + o * a.C;
-  for (int j = 0; j < a.C; j++) c[j] = src[j];
-  for (int j = a.C; j < (a.stride - 32) / 2; j++) c[j] = 0;
+  unsigned long long w;
+  if (part < 3) {
+    w = (unsigned long long)__double_as_longlong(a.xyz[o * 3 + part]);
+  } else if (part == 3) {
+    w = (unsigned long long)__double_as_longlong(a.err[o]);
+  } else {
+    const int j0 = (part - 4) * 4;
+    const int16_t* src = a.corr + o * a.C;
+    if ((a.C & 3) == 0) {  // (j0 < C then: the words beyond the cameras exist only when C is not a multiple of 4)
+      w = *(const unsigned long long*)(src + j0);
+    } else {
+      w = 0;
+#pragma unroll
+      for (int q = 0; q < 4; q++)
+        if (j0 + q < a.C) w |= (unsigned long long)(uint16_t)src[j0 + q] << (16 * q);
+    }
+  }
+  *dst = w;
 }
 
 hipError_t launch_compact_tracks(const CompactArgs& a, hipStream_t stream) {
@@ -312,7 +325,7 @@ hipError_t launch_compact_tracks(const CompactArgs& a, hipStream_t stream) {
   hipLaunchKernelGGL(compact_scan_blocks_kernel, dim3(n_blocks), dim3(kScanBlock), 0, stream, a);
   hipLaunchKernelGGL(compact_scan_totals_kernel, dim3(1), dim3(kScanBlock), 0, stream, a, n_blocks);
   hipLaunchKernelGGL(compact_add_block_offsets_kernel, dim3((unsigned)((a.n_frames + 255) / 256)), dim3(256), 0, stream, a);
-  const int64_t lanes = a.n_frames * a.K_max;
+  const int64_t lanes = a.n_frames * a.K_max * (a.stride >> 3);
   hipLaunchKernelGGL(compact_scatter_kernel, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, stream, a);
   return hipGetLastError();
 }
