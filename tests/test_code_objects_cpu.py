@@ -62,3 +62,11 @@ def test_ba_and_blob_kernels_do_not_spill(kernels):
     for parts in (("ba_fused_kernelILb1ELb1E",), ("blob_mask_kernel",), ("blob_activity_kernel",)):
         k = _find(kernels, *parts)
         assert k["vgpr_spill_count"] == 0 and k["private_segment_fixed_size"] == 0, (parts, k)
+
+
+def test_wide_kernel_budget(kernels):
+    """frame_kernel<1024, uniformK, F32R, WIDE, MODE_ALL>: the 64 x 256 kernel.  Round 4 took its frame state out of a 1.4 MB
+    HBM workspace (57 spilled VGPRs, 164 B of scratch then); a change that pushes the spills back up shows here first."""
+    k = _find(kernels, "frame_kernelILi1024ELb1ELb1ELb1ELi3E")
+    assert k["vgpr_count"] <= 128, k
+    assert k["vgpr_spill_count"] <= 52 and k["private_segment_fixed_size"] <= 232, k

@@ -242,3 +242,34 @@ def test_pack_frame_carries_exactly_what_float32_can_and_says_when_it_rounds():
         helpers.pack_frame([[[100.1, 7.0]]], strict=True)
     with pytest.raises(ValueError, match="NaN"):
         helpers.pack_frame([[[float("nan"), 7.0]]])
+
+
+def test_object_points_payload_is_the_reference_dict():
+    """helpers.py:128-133: {"object_points": object_points.tolist(), "errors": errors.tolist(), "objects": [{k: (v.tolist() if
+    ndarray else v)}], "filtered_objects": filtered_objects} -- host formatting only, no GPU."""
+    import json
+    from mocap_core import helpers
+    pts = np.array([[0.1, 0.2, 0.3], [1.0, 2.0, 3.0]])
+    errs = np.array([0.5, 1.5])
+    objects = [{"pos": np.array([0.55, 1.1, 1.65]), "heading": -0.25, "error": 1.0, "droneIndex": 1}]
+    filtered = [{"pos": [0.5, 1.0, 1.6], "vel": [0.0, 0.0, 0.0], "heading": -0.2, "droneIndex": 1}]
+    got = helpers.object_points_payload(errs, pts, objects, filtered)
+    want = {"object_points": pts.tolist(), "errors": errs.tolist(),
+            "objects": [{k: (v.tolist() if isinstance(v, np.ndarray) else v) for (k, v) in o.items()} for o in objects],
+            "filtered_objects": filtered}
+    assert got == want and list(got) == ["object_points", "errors", "objects", "filtered_objects"]
+    json.dumps(got)
+    empty = helpers.object_points_payload(np.array([]), np.array([]), [])
+    assert empty == {"object_points": [], "errors": [], "objects": [], "filtered_objects": []}
+
+
+def test_bundle_adjustment_mode_context_manager_restores_the_mode():
+    from mocap_core import helpers
+    assert helpers._state["ba_mode"] == helpers.DEFAULT_BA_MODE == "scipy"
+    try:
+        with helpers.bundle_adjustment_mode("resident"):
+            assert helpers._state["ba_mode"] == "resident"
+            raise RuntimeError("inside")
+    except RuntimeError:
+        pass
+    assert helpers._state["ba_mode"] == "scipy"
