@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -905,6 +906,7 @@ extern "C" int mocap_match_triangulate_auto(mocap_ctx* ctx, int64_t n_frames, in
   if (n_resubmitted) *n_resubmitted = 0;
   int rc = mocap_match_triangulate(ctx, n_frames, M_max, blobs, counts, gate_px, K_max, G_cap, xyz, err, corr, n_out, status, n_cand);
   if (rc) return rc;
+  try {  // (staging vectors: an allocation failure must not leave a C entry point as an exception)
   std::vector<int64_t> bad;
   for (int64_t f = 0; f < n_frames; f++)
     if (status[f]) bad.push_back(f);
@@ -965,6 +967,9 @@ extern "C" int mocap_match_triangulate_auto(mocap_ctx* ctx, int64_t n_frames, in
   }
   if (n_resubmitted) *n_resubmitted = (int32_t)nb;
   return MOCAP_OK;
+  } catch (const std::exception& ex) {
+    return ctx->fail(MOCAP_E_HIP, "mocap_match_triangulate_auto: %s", ex.what());
+  }
 }
 
 // ------------------------------------------------------------------ double-precision centroids at the boundary
@@ -989,8 +994,14 @@ extern "C" int mocap_match_triangulate_f64(mocap_ctx* ctx, int64_t n_frames, int
     C = ctx->C;
   }
   const size_t per = (size_t)C * M_max * 2;
-  std::vector<float> b32((size_t)n_frames * per);
-  std::vector<uint8_t> rounded((size_t)n_frames, 0);
+  std::vector<float> b32;
+  std::vector<uint8_t> rounded;
+  try {
+    b32.resize((size_t)n_frames * per);
+    rounded.assign((size_t)n_frames, 0);
+  } catch (const std::exception& ex) {
+    return ctx->fail(MOCAP_E_HIP, "mocap_match_triangulate_f64: %s", ex.what());
+  }
   for (int64_t f = 0; f < n_frames; f++)
     for (int c = 0; c < C; c++) {
       int n = counts[(size_t)f * C + c];

@@ -104,16 +104,20 @@ __global__ __launch_bounds__(64) void track_export_kernel(LocateArgs a, TrackExp
     K = K < 0 ? 0 : (K > a.K_max ? a.K_max : K);
     const double* gP = a.xyz + (size_t)f * a.K_max * 3;
     const double* gE = a.err + (size_t)f * a.K_max;
+    const bool search = a.n_obj != nullptr && K <= 256;  // (the LDS copy holds 256 points: the hosts refuse more with the search on)
     __syncthreads();
-    for (int j = lane; j < 3 * K; j += 64) P[j] = gP[j];
-    for (int j = lane; j < K; j += 64) E[j] = gE[j];
+    if (search) {
+      for (int j = lane; j < 3 * K; j += 64) P[j] = gP[j];
+      for (int j = lane; j < K; j += 64) E[j] = gE[j];
+    }
     __syncthreads();
-    // ---- export of the frame path's own outputs (valid slots only; the caller's fill stays beyond)
+    // ---- export of the frame path's own outputs (valid slots only; the caller's fill stays beyond): straight from device
+    // memory, any K_max (without the object search a frame may hold up to 1 024 points)
     if (e.out_xyz) {
       double* oP = e.out_xyz + (size_t)f * a.K_max * 3;
-      for (int j = lane; j < 3 * K; j += 64) oP[j] = P[j];
+      for (int j = lane; j < 3 * K; j += 64) oP[j] = gP[j];
       double* oE = e.out_err + (size_t)f * a.K_max;
-      for (int j = lane; j < K; j += 64) oE[j] = E[j];
+      for (int j = lane; j < K; j += 64) oE[j] = gE[j];
       if (e.out_corr) {
         const int16_t* gc = e.corr + (size_t)f * a.K_max * e.C;
         int16_t* oc = e.out_corr + (size_t)f * a.K_max * e.C;
@@ -142,7 +146,7 @@ __global__ __launch_bounds__(64) void track_export_kernel(LocateArgs a, TrackExp
     }
     if (!a.n_obj) continue;  // is_locating_objects off (helpers.py:107)
     int no = 0;
-    if (K <= 256) {
+    if (search) {
       const int chunks = (K + 63) >> 6;
       unsigned long long matched[4] = {0, 0, 0, 0};
       for (int i = 0; i < K; i++) {

@@ -209,3 +209,22 @@ def test_double_precision_centroids_at_the_boundary(core):
         bad = sub64.copy()
         bad[3, 2, 0, 1] = np.nan
         core.match_triangulate_f64(bad, counts2, K_max=64)
+
+
+def test_track_frame_without_object_search_takes_more_than_256_points(core):
+    """The export wave stages points through LDS only for the object search (256 points, refused beyond by the host);
+    without it (Cameras.is_locating_objects off) a frame may carry up to 1 024 roots straight through."""
+    from mocap_core import synth
+    rig = synth.ring_rig(8)
+    blobs, counts, _ = synth.make_blob_stream(rig, 6, 48, seed=14, dropout=0.5)      # heavy dropout: many roots beyond camera 0
+    core.set_cameras(rig["K"], rig["R"], rig["t"])
+    K = 384
+    sep = core.match_triangulate(blobs, counts, K_max=K, G_cap=1 << 22)
+    one = core.track_frame(blobs, counts, K_max=K, G_cap=1 << 22, O_max=0)
+    ok = sep["status"] == 0
+    assert ok.any() and np.array_equal(one["status"], sep["status"]) and np.array_equal(one["n_pts"], sep["n_out"])
+    valid = (np.arange(K)[None, :] < sep["n_out"][:, None]) & ok[:, None]
+    for key in ("xyz", "err", "corr"):
+        assert np.array_equal(one[key][valid], sep[key][valid]), key
+    with pytest.raises(Exception, match="256"):
+        core.track_frame(blobs, counts, K_max=K, O_max=4)                                # with the search on: refused, not overrun
