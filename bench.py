@@ -526,15 +526,24 @@ def ba_bench(core, iters=200, cpu=True):
     ref_obs = synth.obs_to_reference_array(obs)
     poses0 = [{"R": init["R"][i].copy(), "t": init["t"][i].copy()} for i in range(CAMS)]
     helpers.set_core(core)
+    d_runs = []
     with helpers.bundle_adjustment_mode("scipy"):
-        t0 = time.perf_counter()
-        _, dinfo = helpers.bundle_adjustment(ref_obs, poses0, None, return_info=True)
-        d_dt = time.perf_counter() - t0
+        # one untimed solve first: bundle adjustment runs on its own lazily created context (mocap_create, allocations,
+        # first launches of every kernel) -- a one-off per process that is not part of a calibration's cost
+        helpers.bundle_adjustment(ref_obs, [dict(p) for p in poses0], None, return_info=True)
+        for _ in range(3):
+            t0 = time.perf_counter()
+            _, dinfo = helpers.bundle_adjustment(ref_obs, [dict(p) for p in poses0], None, return_info=True)
+            d_runs.append(time.perf_counter() - t0)
+    d_dt = sorted(d_runs)[1]
     default_mode = {"mode": helpers.DEFAULT_BA_MODE, "measured_mode": "scipy", "wall_s": d_dt, "njev": int(dinfo["njev"]),
                     "nfev": int(dinfo["nfev"]), "iterations_per_s": dinfo["njev"] / d_dt,
                     "residual_evaluations_per_s": (dinfo["nfev"] + dinfo["njev"] * x0.size) / d_dt,
-                    "note": "the seam's default: scipy.optimize.least_squares drives, every residual evaluation is one "
-                            "mocap_ba_residuals call (n + 1 of them per Jacobian, host round trip each); `value` above is mode "
+                    "runs_s": [round(r, 4) for r in d_runs], "statistic": "median of 3 solves after one untimed",
+                    "note": "the seam's default: scipy.optimize.least_squares drives; a trial point is one mocap_ba_residuals "
+                            "call, a Jacobian is ONE call too (jac= callable: the n perturbed parameter vectors of scipy's "
+                            "2-point rule as a batch, J formed with scipy's own float32-difference / float64-quotient "
+                            "expressions: same bits as the reference's n + 1 separate evaluations); `value` above is mode "
                             "\"resident\" (mocap_ba_solve), opt-in via helpers.set_bundle_adjustment_mode"}
     return {"metric": "BA iters/sec (8 cams, 1k pts)", "value": info["iterations"] / dt, "measured_mode": "resident",
             "default_mode": default_mode, "roofline": roofline,
@@ -686,11 +695,18 @@ def main():
     d_status = torch.zeros(F, dtype=torch.int32, device=dev)
     d_ncand = torch.zeros(F, dtype=torch.int32, device=dev)
 
-    def hot_path(lo=0, hi=None):
+    # {frames flagged by the first pass, frames re-run} per call of the hot path (device-side; read after the timed region)
+    d_resub = torch.zeros((64, 2), dtype=torch.int32, device=dev)
+
+    def hot_path(lo=0, hi=None, chunk=0):
+        # the product path for device buffers: frame kernel, then -- queued behind it, no host wait -- the frames that hit a
+        # cap re-run on the device with the largest caps (the reference has none, helpers.py:394-400) and scattered back.
+        # Inside the timed region, so a figure never excludes its heaviest frames.
         hi = F if hi is None else hi
-        core.match_triangulate_dev(hi - lo, M, d_blobs[lo:].data_ptr(), d_counts[lo:].data_ptr(), gate, K_MAX, G_CAP,
-                                   d_xyz[lo:].data_ptr(), d_err[lo:].data_ptr(), d_corr[lo:].data_ptr(),
-                                   d_nout[lo:].data_ptr(), d_status[lo:].data_ptr(), d_ncand[lo:].data_ptr())
+        core.match_triangulate_dev_auto(hi - lo, M, d_blobs[lo:].data_ptr(), d_counts[lo:].data_ptr(), gate, K_MAX, G_CAP,
+                                        d_xyz[lo:].data_ptr(), d_err[lo:].data_ptr(), d_corr[lo:].data_ptr(),
+                                        d_nout[lo:].data_ptr(), d_status[lo:].data_ptr(), d_ncand[lo:].data_ptr(),
+                                        d_resub[chunk % 64].data_ptr())
 
     # N > 1: the one exchange of the path: final tracks -> rank 0.  Only the valid points travel:
     # mocap_compact_tracks_dev packs them into 32 + 2C-byte records behind the frame kernel (1.1 KB instead of the
@@ -733,7 +749,7 @@ def main():
             if not multi:
                 hot_path()
             for c, (lo, hi) in enumerate(cb if multi else []):
-                hot_path(lo, hi)
+                hot_path(lo, hi, c)
                 cur = comps[c].compact(d_nout[lo:hi], d_xyz[lo:hi], d_err[lo:hi], d_corr[lo:hi], stream)
                 if prev is not None:               # chunk k's transfer is posted behind chunk k + 1's kernels
                     pending.append(post_exchange(*prev))
@@ -771,9 +787,11 @@ def main():
     n_out = d_nout.cpu().numpy()
     status = d_status.cpu().numpy()
     n_cand = d_ncand.cpu().numpy()
+    resub = d_resub[:max(n_chunks, 1)].cpu().numpy()        # the last step's calls
     local = torch.tensor([float(n_out.sum()), elapsed, float(status.astype(bool).sum()), float((status & 1).astype(bool).sum()),
                           float((status & 2).astype(bool).sum()), float((status & 4).astype(bool).sum()),
-                          float(exposed["ms"] or 0.0)], dtype=torch.float64, device=dev)
+                          float(exposed["ms"] or 0.0), float(resub[:, 0].sum()), float(resub[:, 1].sum())],
+                         dtype=torch.float64, device=dev)
     if world > 1:
         allv = [torch.zeros_like(local) for _ in range(world)]
         dist.all_gather(allv, local)
@@ -806,10 +824,14 @@ def main():
                        "parallelism": f"frame-shard x{world}", "frames_per_s": F * world * args.steps / t_max,
                        "markers_per_frame": total_markers / (F * world),
                        "candidates_per_frame": float(n_cand.mean()), "overflow_frames": int(allv[:, 2].sum()),
+                       "resubmitted_frames": int(allv[:, 8].sum()), "flagged_by_first_pass": int(allv[:, 7].sum()),
                        "overflow_by_cap": {"roots_K_max": int(allv[:, 3].sum()), "candidates_G_cap": int(allv[:, 4].sum()),
                                            "hits_per_root_and_camera": int(allv[:, 5].sum()),
-                                           "note": "frames whose status bit is set leave the kernel empty and are re-submitted with "
-                                                   "larger caps by match_triangulate_auto in the product path"},
+                                           "note": "AFTER the device-side re-submit (mocap_match_triangulate_dev_auto, inside the timed "
+                                                   "region): frames the first pass flagged (G_cap = 2^20 groups per root, K_max "
+                                                   "roots, hit cap) are re-run per step with the largest caps (2^24 groups per root, "
+                                                   "C x M roots, every hit) and scattered back; what is still counted here exceeds "
+                                                   "even those"},
                        "exchange": ({"format": "compact records (32 + 2C bytes per valid point) + n_out per frame, count-first "
                                                "point-to-point gather on rank 0",
                                      "bytes_per_rank_per_step": exchanged["bytes"] / max(args.steps, 1),

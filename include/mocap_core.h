@@ -143,6 +143,21 @@ int mocap_match_triangulate_dev(mocap_ctx* ctx, int64_t n_frames, int M_max, con
                                 double* d_xyz, double* d_err, int16_t* d_corr, int32_t* d_n_out,
                                 int32_t* d_status, int32_t* d_n_cand);
 
+/* mocap_match_triangulate_dev_auto: mocap_match_triangulate_dev, then -- queued behind it on the context's stream, without
+ * the host ever waiting -- every frame whose status is non-zero is re-run ON THE DEVICE with the largest caps the core has
+ * (root capacity C * M_max as far as a kernel's LDS holds it, G_cap = 2^24 groups per root, every gated hit of a (root,
+ * camera) pair kept): the reference enumerates the full product whatever its size (helpers.py:394-400).  The flagged
+ * frames are gathered into a scratch batch whose length stays on the device, the frame kernel runs on it, results that
+ * fit the caller's K_max slots are scattered back in place.  Status after the call has run: as
+ * mocap_match_triangulate_auto (MOCAP_ST_ROOT_OVERFLOW = the frame needs n_out[f] > K_max slots and nothing was written
+ * for it; consumers treat n_out > K_max as "no valid slot").  d_resubmitted (may be NULL): [2] device-accessible int32,
+ * {frames flagged by the first pass, frames re-run}; the two differ only when the scratch batch (one slot per frame up to
+ * MOCAP_RESUBMIT_SCRATCH_MB, default 8192) could not hold every flagged frame -- those keep their status: call again. */
+int mocap_match_triangulate_dev_auto(mocap_ctx* ctx, int64_t n_frames, int M_max, const float* d_blobs,
+                                     const int32_t* d_counts, double gate_px, int K_max, int64_t G_cap,
+                                     double* d_xyz, double* d_err, int16_t* d_corr, int32_t* d_n_out,
+                                     int32_t* d_status, int32_t* d_n_cand, int32_t* d_resubmitted);
+
 /* mocap_match_triangulate_auto: mocap_match_triangulate, then every frame whose status is non-zero is re-submitted on the
  * GPU with the largest caps the core has (root capacity C * M_max, G_cap = 2^24 groups per root, every gated hit of a
  * (root, camera) pair kept) -- the reference enumerates the full product whatever its size (helpers.py:394-400).  After
@@ -239,12 +254,13 @@ int mocap_locate_objects_dev(mocap_ctx* ctx, int64_t n_frames, int K_max, const 
  *   when O_max > 0 = Cameras.is_locating_objects) -> everything the `object-points` event carries (helpers.py:128-133).
  * One enqueue (frame kernel, then one wave per frame that runs the object search and exports the valid slots into pinned
  * host memory), one event wait; frames that hit a candidate / hit-list cap are re-submitted with the core's largest caps
- * before the call returns.  Meant for one or a few frames per call (host buffers; for batches use the _dev form).
+ * before the call returns -- those frames only, root-capacity overflow included.  Meant for one or a few frames per call
+ * (host buffers; for batches use the _dev form).
  *   blobs, counts, gate_px, K_max, G_cap, xyz, err, corr (may be NULL), status   as mocap_match_triangulate
  *   n_pts [F]      points of the frame (mocap_match_triangulate's n_out)
  *   O_max          object slots per frame; 0 = no object search (pos .. n_obj may then be NULL)
  *   pos [F][O_max][3], heading [F][O_max], oerr [F][O_max], drone [F][O_max], n_obj [F]   as mocap_locate_objects
- * status & MOCAP_ST_ROOT_OVERFLOW after return: K_max was too small for that frame (call again with K_max = C * M_max). */
+ * status & MOCAP_ST_ROOT_OVERFLOW after return: the frame has n_pts[f] > K_max points (call again with that K_max). */
 int mocap_track_frame(mocap_ctx* ctx, int64_t n_frames, int M_max, const float* blobs, const int32_t* counts,
                       double gate_px, int K_max, int64_t G_cap, double* xyz, double* err, int16_t* corr,
                       int32_t* n_pts, int32_t* status, int O_max, double* pos, double* heading, double* oerr,
@@ -257,8 +273,8 @@ int mocap_track_frame_images(mocap_ctx* ctx, int64_t n_frames, const uint8_t* im
                              int K_max, int64_t G_cap, float* blobs, int32_t* counts, int32_t* blob_status,
                              double* xyz, double* err, int16_t* corr, int32_t* n_pts, int32_t* status, int O_max,
                              double* pos, double* heading, double* oerr, int32_t* drone, int32_t* n_obj);
-/* device-pointer form for batches: frame kernel + object search enqueued on the context's stream (no re-submission:
- * check d_status). */
+/* device-pointer form for batches: frame kernel, device-side re-submission of the frames that hit a cap (as
+ * mocap_match_triangulate_dev_auto) and object search, all enqueued on the context's stream. */
 int mocap_track_frame_dev(mocap_ctx* ctx, int64_t n_frames, int M_max, const float* d_blobs, const int32_t* d_counts,
                           double gate_px, int K_max, int64_t G_cap, double* d_xyz, double* d_err, int16_t* d_corr,
                           int32_t* d_n_pts, int32_t* d_status, int O_max, double* d_pos, double* d_heading,

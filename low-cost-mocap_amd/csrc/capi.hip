@@ -120,6 +120,9 @@ extern "C" void mocap_destroy(mocap_ctx* ctx) {
   ctx->ba_fused.release();
   ctx->compact_ws.release();
   ctx->frame_ws.release();
+  ctx->resub.release();
+  ctx->live_stage.release();
+  ctx->resub_ctr.release();
   if (ctx->live_pin) (void)hipHostFree(ctx->live_pin);
   if (ctx->live_event) (void)hipEventDestroy(ctx->live_event);
   ctx->img_map.release();
@@ -491,10 +494,54 @@ extern "C" int mocap_reproject(mocap_ctx* ctx, int64_t N, const double* obs, con
 }
 
 // ------------------------------------------------------------------ frame path
+namespace {
+// which kernel a frame batch of this shape takes (the decision is per launch and never changes a result)
+struct FramePlan {
+  int T = 256, hit_cap = 1;
+  bool wide = false, use_bb = false;
+  size_t lds = 0;
+};
+FramePlan plan_frame(const mocap_ctx* ctx, int M_max, int K_max, int hit_cap_override) {
+  FramePlan pl;
+  // automatic workgroup size: tiny frames (4 x 4: a handful of candidates) are latency-bound, one wave
+  // per frame keeps 4x more frames in flight per CU; everything else wants 256 lanes per frame
+  pl.T = ctx->frame_threads ? ctx->frame_threads : (ctx->C * M_max <= 32 ? 64 : 256);
+  const int cap = hit_cap_override > 0 ? hit_cap_override : ctx->hit_cap;
+  pl.hit_cap = cap < 1 ? 1 : (cap > M_max ? M_max : cap);
+  // (a narrow frame with identical intrinsics keeps blob indices in one byte with 0xFF = none: 256 slots go wide)
+  pl.wide = ctx->force_wide != 0 || (M_max > 255 && ctx->cv.uniformK);
+  // The realistic rigs go to their own kernel (csrc/frame_bb.hip: exact branch and bound): identical plain intrinsics
+  // (the eigenvalue bounds need K = [[fx,0,cx],[0,fy,cy],[0,0,1]]), <= 16 cameras, <= 64 blobs per camera, <= 255 roots,
+  // frames big enough for a 256-lane workgroup (or 256 lanes asked for: MOCAP_FRAME_THREADS / mocap_set_tuning).  Everything
+  // else -- and MOCAP_EVAL_BB=0 -- takes the exhaustive walk.  (Decided before narrow / wide: its layout has no odometer columns and fits where the general narrow one does not.)
+  pl.use_bb = ctx->eval_bb && !pl.wide && ctx->cv.uniformK && ctx->prune && ctx->eigcut && ctx->p3max2 > 0.0 && ctx->p3max2c > 0.0 &&
+              (ctx->frame_threads == 256 || (ctx->frame_threads == 0 && ctx->C * M_max > 32)) && ctx->frame_launches != 3 &&
+              frame_bb_fits(ctx->C, M_max, K_max);
+  if (pl.use_bb) {
+    pl.T = 256;
+    pl.lds = frame_bb_lds_bytes(ctx->C, M_max, K_max);
+  } else if (!pl.wide) {
+    pl.lds = frame_lds_bytes(ctx->C, M_max, K_max, pl.T, pl.hit_cap, false, ctx->cv.uniformK != 0);
+    while (pl.lds > 160 * 1024 && pl.T > 64) {
+      pl.T /= 2;
+      pl.lds = frame_lds_bytes(ctx->C, M_max, K_max, pl.T, pl.hit_cap, false, ctx->cv.uniformK != 0);
+    }
+    pl.wide = pl.lds > 160 * 1024;  // the frame state does not fit LDS: big tables go to an HBM workspace
+  }
+  if (pl.wide) {
+    pl.T = kWideThreads;
+    pl.lds = frame_lds_bytes(ctx->C, M_max, K_max, pl.T, pl.hit_cap, true, false);
+  }
+  return pl;
+}
+}  // namespace
+
+// hit_cap_override > 0: the hit-list cap of THIS launch (the re-submit pass keeps every gated hit) -- an argument, never a
+// change of the context's state.  n_frames_dev != null: the batch is min(*n_frames_dev, n_frames) frames long.
 static int match_dev_locked(mocap_ctx* ctx, int64_t n_frames, int M_max, const float* d_blobs,
                             const int32_t* d_counts, double gate_px, int K_max, int64_t G_cap, double* d_xyz,
                             double* d_err, int16_t* d_corr, int32_t* d_n_out, int32_t* d_status,
-                            int32_t* d_n_cand) {
+                            int32_t* d_n_cand, int hit_cap_override = 0, const int32_t* n_frames_dev = nullptr) {
   if (!ctx->C) return ctx->fail(MOCAP_E_NOCAMS, "mocap_set_cameras has not been called");
   if (n_frames < 0 || M_max < 1 || K_max < 1 || G_cap < 1)
     return ctx->fail(MOCAP_E_ARG, "mocap_match_triangulate: bad size argument");
@@ -506,6 +553,7 @@ static int match_dev_locked(mocap_ctx* ctx, int64_t n_frames, int M_max, const f
   FrameArgs a;
   a.cv = ctx->cv;
   a.n_frames = n_frames;
+  a.n_frames_dev = n_frames_dev;
   a.M = M_max;
   a.K_max = K_max;
   a.gate_px = gate_px;
@@ -519,38 +567,14 @@ static int match_dev_locked(mocap_ctx* ctx, int64_t n_frames, int M_max, const f
   a.status = d_status;
   a.n_cand = d_n_cand;
   a.world = ctx->world_on ? (const double*)ctx->world.ptr : nullptr;
-  // automatic workgroup size: tiny frames (4 x 4: a handful of candidates) are latency-bound, one wave
-  // per frame keeps 4x more frames in flight per CU; everything else wants 256 lanes per frame
-  int T = ctx->frame_threads ? ctx->frame_threads : (ctx->C * M_max <= 32 ? 64 : 256);
-  const int hit_cap = ctx->hit_cap < 1 ? 1 : (ctx->hit_cap > M_max ? M_max : ctx->hit_cap);
-  // (a narrow frame with identical intrinsics keeps blob indices in one byte with 0xFF = none: 256 slots go wide)
-  bool wide = ctx->force_wide != 0 || (M_max > 255 && ctx->cv.uniformK);
-  // The realistic rigs go to their own kernel (csrc/frame_bb.hip: exact branch and bound): identical plain intrinsics
-  // (the eigenvalue bounds need K = [[fx,0,cx],[0,fy,cy],[0,0,1]]), <= 16 cameras, <= 64 blobs per camera, <= 255 roots,
-  // frames big enough for a 256-lane workgroup (or 256 lanes asked for: MOCAP_FRAME_THREADS / mocap_set_tuning).  Everything
-  // else -- and MOCAP_EVAL_BB=0 -- takes the exhaustive walk.  (Decided before narrow / wide: its layout has no odometer columns and fits where the general narrow one does not.)
-  const bool use_bb = ctx->eval_bb && !wide && ctx->cv.uniformK && ctx->prune && ctx->eigcut && ctx->p3max2 > 0.0 && ctx->p3max2c > 0.0 &&
-                      (ctx->frame_threads == 256 || (ctx->frame_threads == 0 && ctx->C * M_max > 32)) && ctx->frame_launches != 3 &&
-                      frame_bb_fits(ctx->C, M_max, K_max);
-  size_t lds = 0;
-  if (use_bb) {
-    T = 256;
-    lds = frame_bb_lds_bytes(ctx->C, M_max, K_max);
-  } else if (!wide) {
-    lds = frame_lds_bytes(ctx->C, M_max, K_max, T, hit_cap, false, ctx->cv.uniformK != 0);
-    while (lds > 160 * 1024 && T > 64) {
-      T /= 2;
-      lds = frame_lds_bytes(ctx->C, M_max, K_max, T, hit_cap, false, ctx->cv.uniformK != 0);
-    }
-    wide = lds > 160 * 1024;  // the frame state does not fit LDS: big tables go to an HBM workspace
-  }
-  if (wide) {
-    T = kWideThreads;
-    lds = frame_lds_bytes(ctx->C, M_max, K_max, T, hit_cap, true, false);
-    if (lds > 160 * 1024)
-      return ctx->fail(MOCAP_E_LIMIT, "frame state needs %zu B of LDS (C=%d, M_max=%d, K_max=%d): lower K_max",
-                       lds, ctx->C, M_max, K_max);
-  }
+  const FramePlan pl = plan_frame(ctx, M_max, K_max, hit_cap_override);
+  int T = pl.T;
+  const int hit_cap = pl.hit_cap;
+  const bool wide = pl.wide, use_bb = pl.use_bb;
+  size_t lds = pl.lds;
+  if (wide && lds > 160 * 1024)
+    return ctx->fail(MOCAP_E_LIMIT, "frame state needs %zu B of LDS (C=%d, M_max=%d, K_max=%d): lower K_max",
+                     lds, ctx->C, M_max, K_max);
   if (const char* pad = getenv("MOCAP_DEBUG_LDS_PAD")) lds += (size_t)atoi(pad);  // occupancy experiments only
   a.H = hit_cap;
   a.wide = wide ? 1 : 0;
@@ -658,6 +682,100 @@ static int match_dev_locked(mocap_ctx* ctx, int64_t n_frames, int M_max, const f
   return MOCAP_OK;
 }
 
+// does a frame batch with these sizes fit one of the frame kernels?  (the size logic of plan_frame, hit lists uncapped)
+static bool frame_shape_fits(const mocap_ctx* ctx, int M_max, int K) {
+  if (frame_bb_fits(ctx->C, M_max, K) && ctx->cv.uniformK && !ctx->force_wide && M_max <= 255) return true;
+  const bool must_wide = ctx->force_wide != 0 || (M_max > 255 && ctx->cv.uniformK);
+  if (!must_wide && frame_lds_bytes(ctx->C, M_max, K, 64, M_max, false, ctx->cv.uniformK != 0) <= (size_t)160 * 1024) return true;
+  return frame_lds_bytes(ctx->C, M_max, K, kWideThreads, M_max, true, false) <= (size_t)160 * 1024;
+}
+
+// ------------------------------------------------------------------ re-submit on the device (uncapped enumeration)
+// The reference enumerates the full Cartesian product whatever its size (helpers.py:394-400); the frame path works under
+// caps (K_max roots, G_cap groups per root, hit_cap hits per pair of the wide variant) and reports per frame when one was
+// hit.  Behind a first pass that is already queued: the flagged frames are gathered, on the device, into a scratch batch
+// whose length stays on the device; the frame kernel runs on it with the largest caps the core has (root capacity C *
+// M_max as far as a kernel's LDS holds it, G_cap = 2^24 groups per root, every gated hit of a (root, camera) pair kept);
+// results that fit the caller's K_max slots are scattered back, the others report ROOT_OVERFLOW and the slots they need.
+// Nothing here waits for the GPU: three enqueues behind the first pass (an empty list costs ~15 us of GPU time).
+// d_info: null, or [2] device-accessible: {frames flagged, frames re-run}.
+static int resubmit_dev_locked(mocap_ctx* ctx, int64_t n_frames, int M_max, const float* d_blobs, const int32_t* d_counts,
+                               double gate_px, int K_max, double* d_xyz, double* d_err, int16_t* d_corr, int32_t* d_n_out,
+                               int32_t* d_status, int32_t* d_n_cand, int32_t* d_info) {
+  if (n_frames <= 0) return MOCAP_OK;
+  const int C = ctx->C;
+  // worst-case root capacity: every blob its own root (never less than the caller asked for) ...
+  int K_big = C * M_max < 1024 ? C * M_max : 1024;
+  if (K_big < K_max) K_big = K_max;
+  if (!frame_shape_fits(ctx, M_max, K_big)) {
+    // ... as far as the frame state fits a kernel (64 cameras x 256 blobs: the per-root tables of the wide variant end at
+    // a few hundred roots); a frame with more roots than that keeps its root-overflow status
+    int lo = K_max, hi = K_big;  // largest K in [K_max, K_big) that fits (K_max itself ran above)
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) / 2;
+      if (frame_shape_fits(ctx, M_max, mid)) lo = mid; else hi = mid - 1;
+    }
+    K_big = lo;
+  }
+  auto al = [](size_t x) { return (x + 255) / 256 * 256; };
+  const size_t per_frame = sizeof(float) * C * M_max * 2 + sizeof(int32_t) * C + (size_t)K_big * (32 + 2 * C) + 16;
+  // the scratch batch holds every frame of the caller's batch unless that takes more than MOCAP_RESUBMIT_SCRATCH_MB
+  // (default 8192); beyond it, flagged frames keep their status (d_info[0] > d_info[1] says so: call again)
+  size_t budget = (size_t)8192 << 20;
+  if (const char* e = getenv("MOCAP_RESUBMIT_SCRATCH_MB")) budget = (size_t)(atol(e) > 0 ? atol(e) : 1) << 20;
+  int64_t cap = n_frames;
+  if ((size_t)cap * per_frame > budget) cap = (int64_t)(budget / per_frame);
+  if (cap < 1) cap = 1;
+  const size_t F2 = (size_t)cap;
+  const size_t b_list = al(4 * F2), b_b2 = al(sizeof(float) * F2 * C * M_max * 2), b_c2 = al(4 * F2 * C),
+               b_x2 = al(8 * F2 * K_big * 3), b_e2 = al(8 * F2 * K_big), b_r2 = al(2 * F2 * K_big * C), b_i = al(4 * (F2 + 2));
+  if (ctx->resub.reserve(b_list + b_b2 + b_c2 + b_x2 + b_e2 + b_r2 + 3 * b_i))
+    return ctx->fail(MOCAP_E_HIP, "hipMalloc(re-submit scratch, %zu B) failed", b_list + b_b2 + b_c2 + b_x2 + b_e2 + b_r2 + 3 * b_i);
+  if (!ctx->resub_ctr.ptr) {
+    if (ctx->resub_ctr.reserve(256)) return ctx->fail(MOCAP_E_HIP, "hipMalloc(re-submit counters) failed");
+    HIP_TRY(ctx, hipMemsetAsync(ctx->resub_ctr.ptr, 0, 256, ctx->stream));
+  }
+  char* w = (char*)ctx->resub.ptr;
+  ResubmitArgs ra;
+  ra.n_frames = n_frames;
+  ra.cap = cap;
+  ra.C = C;
+  ra.M = M_max;
+  ra.K_max = K_max;
+  ra.K_big = K_big;
+  ra.status = d_status;
+  ra.blobs = d_blobs;
+  ra.counts = d_counts;
+  // two counters, 128 bytes apart, alternate between calls: this call's is zero (the previous call's gather cleared it)
+  int32_t* ctr = (int32_t*)ctx->resub_ctr.ptr;
+  const uint32_t par = ctx->resub_calls++ & 1u;
+  ra.count = ctr + 32 * par;
+  ra.count_next = ctr + 32 * (par ^ 1u);
+  ra.list = (int32_t*)w;   w += b_list;
+  ra.b2 = (float*)w;       w += b_b2;
+  ra.c2 = (int32_t*)w;     w += b_c2;
+  double* x2 = (double*)w;   w += b_x2;
+  double* e2 = (double*)w;   w += b_e2;
+  int16_t* r2 = (int16_t*)w; w += b_r2;
+  int32_t* n2 = (int32_t*)w; w += b_i;
+  int32_t* s2 = (int32_t*)w; w += b_i;   // (+ 2 slots: the self-check builds count in status[n_frames .. n_frames + 1])
+  int32_t* g2 = (int32_t*)w;
+  ra.x2 = x2;  ra.e2 = e2;  ra.r2 = r2;  ra.n2 = n2;  ra.s2 = s2;  ra.g2 = g2;
+  ra.xyz = d_xyz;
+  ra.err = d_err;
+  ra.corr = d_corr;
+  ra.n_out = d_n_out;
+  ra.status_out = d_status;
+  ra.n_cand = d_n_cand;
+  ra.info = d_info;
+  HIP_TRY(ctx, launch_resubmit_gather(ra, ctx->stream));
+  const int rc = match_dev_locked(ctx, cap, M_max, ra.b2, ra.c2, gate_px, K_big, (int64_t)1 << 24, x2, e2, r2, n2, s2, g2,
+                                  /*hit_cap_override=*/M_max, /*n_frames_dev=*/ra.count);
+  if (rc) return rc;
+  HIP_TRY(ctx, launch_resubmit_scatter(ra, ctx->stream));
+  return MOCAP_OK;
+}
+
 extern "C" int mocap_match_triangulate_dev(mocap_ctx* ctx, int64_t n_frames, int M_max, const float* d_blobs,
                                            const int32_t* d_counts, double gate_px, int K_max, int64_t G_cap,
                                            double* d_xyz, double* d_err, int16_t* d_corr, int32_t* d_n_out,
@@ -670,12 +788,27 @@ extern "C" int mocap_match_triangulate_dev(mocap_ctx* ctx, int64_t n_frames, int
   return rc ? rc : ctx->mark_enqueued();
 }
 
-extern "C" int mocap_match_triangulate(mocap_ctx* ctx, int64_t n_frames, int M_max, const float* blobs,
-                                       const int32_t* counts, double gate_px, int K_max, int64_t G_cap,
-                                       double* xyz, double* err, int16_t* corr, int32_t* n_out,
-                                       int32_t* status, int32_t* n_cand) {
+extern "C" int mocap_match_triangulate_dev_auto(mocap_ctx* ctx, int64_t n_frames, int M_max, const float* d_blobs,
+                                                const int32_t* d_counts, double gate_px, int K_max, int64_t G_cap,
+                                                double* d_xyz, double* d_err, int16_t* d_corr, int32_t* d_n_out,
+                                                int32_t* d_status, int32_t* d_n_cand, int32_t* d_resubmitted) {
   if (!ctx) return MOCAP_E_ARG;
   std::lock_guard<std::mutex> lk(ctx->mu);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  int rc = match_dev_locked(ctx, n_frames, M_max, d_blobs, d_counts, gate_px, K_max, G_cap, d_xyz, d_err, d_corr,
+                            d_n_out, d_status, d_n_cand);
+  if (rc) return rc;
+  rc = resubmit_dev_locked(ctx, n_frames, M_max, d_blobs, d_counts, gate_px, K_max, d_xyz, d_err, d_corr, d_n_out, d_status,
+                           d_n_cand, d_resubmitted);
+  return rc ? rc : ctx->mark_enqueued();
+}
+
+// host buffers in, host buffers out; resubmit: frames that hit a cap take the device-side second pass before the results
+// travel back (one lock, one synchronisation)
+static int match_host_locked(mocap_ctx* ctx, int64_t n_frames, int M_max, const float* blobs, const int32_t* counts,
+                             double gate_px, int K_max, int64_t G_cap, double* xyz, double* err, int16_t* corr,
+                             int32_t* n_out, int32_t* status, int32_t* n_cand, bool resubmit, int32_t* n_resubmitted) {
+  if (n_resubmitted) *n_resubmitted = 0;
   if (!ctx->C) return ctx->fail(MOCAP_E_NOCAMS, "mocap_set_cameras has not been called");
   if (n_frames < 0 || M_max < 1 || K_max < 1) return ctx->fail(MOCAP_E_ARG, "mocap_match_triangulate: bad size argument");
   if (n_frames == 0) return MOCAP_OK;
@@ -688,11 +821,13 @@ extern "C" int mocap_match_triangulate(mocap_ctx* ctx, int64_t n_frames, int M_m
                b_xyz = sizeof(double) * F * K_max * 3, b_err = sizeof(double) * F * K_max,
                b_corr = sizeof(int16_t) * F * K_max * C, b_i = sizeof(int32_t) * F;
   auto al = [](size_t x) { return (x + 255) / 256 * 256; };
-  const size_t total = al(b_xyz) + al(b_err) + al(b_blobs) + al(b_counts) + al(b_corr) + 3 * al(b_i);
-  if (total <= (size_t)256 * 1024) {
-    // Live tracking (one or a few frames per call, helpers.py:94): zero-copy through pinned host memory.
-    // The kernels read the blobs from, and write the points to, device-visible host memory; eight small
-    // copy-engine transfers and a sleeping stream synchronise cost several times the kernels themselves.
+  const size_t total = al(b_xyz) + al(b_err) + al(b_blobs) + al(b_counts) + al(b_corr) + 3 * al(b_i) + 256;
+  // Live tracking (one or a few frames per call, helpers.py:94): zero-copy through pinned host memory.
+  // The kernels read the blobs from, and write the points to, device-visible host memory; eight small
+  // copy-engine transfers and a sleeping stream synchronise cost several times the kernels themselves.
+  // Not for frames that go to the wide variant: it reads the blobs IN PLACE for every root batch and candidate view,
+  // which over PCIe from uncached host memory costs far more than one staged copy.
+  if (total <= (size_t)256 * 1024 && !plan_frame(ctx, M_max, K_max, 0).wide) {
     if (total > ctx->live_pin_cap) {
       if (ctx->live_pin) (void)hipHostFree(ctx->live_pin);
       ctx->live_pin = nullptr;
@@ -709,7 +844,9 @@ extern "C" int mocap_match_triangulate(mocap_ctx* ctx, int64_t n_frames, int M_m
     int16_t* h_corr = (int16_t*)p;    p += al(b_corr);
     int32_t* h_n_out = (int32_t*)p;   p += al(b_i);
     int32_t* h_status = (int32_t*)p;  p += al(b_i);
-    int32_t* h_n_cand = (int32_t*)p;
+    int32_t* h_n_cand = (int32_t*)p;  p += al(b_i);
+    int32_t* h_info = (int32_t*)p;
+    h_info[0] = h_info[1] = 0;
     memcpy(h_blobs, blobs, b_blobs);
     memcpy(h_counts, counts, b_counts);
     int rc = match_dev_locked(ctx, n_frames, M_max, h_blobs, h_counts, gate_px, K_max, G_cap, h_xyz, h_err, h_corr,
@@ -725,12 +862,21 @@ extern "C" int mocap_match_triangulate(mocap_ctx* ctx, int64_t n_frames, int M_m
         break;
       }
     }
+    bool flagged = false;
+    for (size_t f = 0; f < F && resubmit; f++) flagged |= h_status[f] != 0;
+    if (flagged) {  // rare: the second pass is queued only when the first one, already back, asks for it
+      rc = resubmit_dev_locked(ctx, n_frames, M_max, h_blobs, h_counts, gate_px, K_max, h_xyz, h_err, h_corr, h_n_out, h_status,
+                               h_n_cand, h_info);
+      if (rc) return rc;
+      HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+      if (n_resubmitted) *n_resubmitted = h_info[1];
+    }
     memcpy(n_out, h_n_out, b_i);
     memcpy(status, h_status, b_i);
     if (n_cand) memcpy(n_cand, h_n_cand, b_i);
     // only the slots the kernel wrote (n_out per frame) carry data; the caller's buffers keep their fill beyond
     for (size_t f = 0; f < F; f++) {
-      const size_t k = (size_t)(h_n_out[f] < 0 ? 0 : (h_n_out[f] > K_max ? K_max : h_n_out[f]));
+      const size_t k = (size_t)((h_n_out[f] < 0 || h_n_out[f] > K_max) ? 0 : h_n_out[f]);  // > K_max: needs more slots, nothing written
       memcpy(xyz + f * K_max * 3, h_xyz + f * K_max * 3, sizeof(double) * 3 * k);
       memcpy(err + f * K_max, h_err + f * K_max, sizeof(double) * k);
       memcpy(corr + f * K_max * C, h_corr + f * K_max * C, sizeof(int16_t) * C * k);
@@ -747,12 +893,20 @@ extern "C" int mocap_match_triangulate(mocap_ctx* ctx, int64_t n_frames, int M_m
   int16_t* d_corr = (int16_t*)p;    p += al(b_corr);
   int32_t* d_n_out = (int32_t*)p;   p += al(b_i);
   int32_t* d_status = (int32_t*)p;  p += al(b_i);
-  int32_t* d_n_cand = (int32_t*)p;
+  int32_t* d_n_cand = (int32_t*)p;  p += al(b_i);
+  int32_t* d_info = (int32_t*)p;
   HIP_TRY(ctx, hipMemcpyAsync(d_blobs, blobs, b_blobs, hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(d_counts, counts, b_counts, hipMemcpyHostToDevice, ctx->stream));
   int rc = match_dev_locked(ctx, n_frames, M_max, d_blobs, d_counts, gate_px, K_max, G_cap, d_xyz, d_err, d_corr,
                             d_n_out, d_status, d_n_cand);
   if (rc) return rc;
+  int32_t h_info[2] = {0, 0};
+  if (resubmit) {
+    rc = resubmit_dev_locked(ctx, n_frames, M_max, d_blobs, d_counts, gate_px, K_max, d_xyz, d_err, d_corr, d_n_out, d_status,
+                             d_n_cand, d_info);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(h_info, d_info, sizeof h_info, hipMemcpyDeviceToHost, ctx->stream));
+  }
   HIP_TRY(ctx, hipMemcpyAsync(xyz, d_xyz, b_xyz, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(err, d_err, b_err, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(corr, d_corr, b_corr, hipMemcpyDeviceToHost, ctx->stream));
@@ -760,7 +914,18 @@ extern "C" int mocap_match_triangulate(mocap_ctx* ctx, int64_t n_frames, int M_m
   HIP_TRY(ctx, hipMemcpyAsync(status, d_status, b_i, hipMemcpyDeviceToHost, ctx->stream));
   if (n_cand) HIP_TRY(ctx, hipMemcpyAsync(n_cand, d_n_cand, b_i, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (n_resubmitted) *n_resubmitted = h_info[1];
   return MOCAP_OK;
+}
+
+extern "C" int mocap_match_triangulate(mocap_ctx* ctx, int64_t n_frames, int M_max, const float* blobs,
+                                       const int32_t* counts, double gate_px, int K_max, int64_t G_cap,
+                                       double* xyz, double* err, int16_t* corr, int32_t* n_out,
+                                       int32_t* status, int32_t* n_cand) {
+  if (!ctx) return MOCAP_E_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  return match_host_locked(ctx, n_frames, M_max, blobs, counts, gate_px, K_max, G_cap, xyz, err, corr, n_out, status, n_cand,
+                           false, nullptr);
 }
 
 // ------------------------------------------------------------------ object locator
@@ -886,90 +1051,19 @@ extern "C" int mocap_locate_objects(mocap_ctx* ctx, int64_t n_frames, int K_max,
   return MOCAP_OK;
 }
 
-// does a frame batch with these sizes fit one of the frame kernels?  (the size logic of match_dev_locked, hit lists uncapped)
-static bool frame_shape_fits(const mocap_ctx* ctx, int M_max, int K) {
-  if (frame_bb_fits(ctx->C, M_max, K) && ctx->cv.uniformK && !ctx->force_wide && M_max <= 255) return true;
-  const bool must_wide = ctx->force_wide != 0 || (M_max > 255 && ctx->cv.uniformK);
-  if (!must_wide && frame_lds_bytes(ctx->C, M_max, K, 64, M_max, false, ctx->cv.uniformK != 0) <= (size_t)160 * 1024) return true;
-  return frame_lds_bytes(ctx->C, M_max, K, kWideThreads, M_max, true, false) <= (size_t)160 * 1024;
-}
-
 // ------------------------------------------------------------------ C-level re-submit (uncapped enumeration)
-// The reference enumerates the full Cartesian product whatever its size (helpers.py:394-400); the frame path works under
-// caps (K_max roots, G_cap groups per root, hit_cap hits per pair of the wide variant) and reports per frame when one was
-// hit.  mocap_match_triangulate_auto gives every caller of the C ABI what mocap_core/capi.py used to do in Python: frames
-// whose status is non-zero are re-submitted, on the GPU, with the largest caps the core has.
+// mocap_match_triangulate_auto gives every caller of the C ABI what mocap_core/capi.py used to do in Python: frames whose
+// status is non-zero are re-submitted, on the GPU, with the largest caps the core has -- under ONE acquisition of the
+// context lock, with the hit-list cap of the second pass an argument of its launch (round 4 flipped ctx->hit_cap between
+// two locked calls: a concurrent mocap_set_frame_limits was overwritten, a concurrent frame call ran under the foreign cap).
 extern "C" int mocap_match_triangulate_auto(mocap_ctx* ctx, int64_t n_frames, int M_max, const float* blobs,
                                             const int32_t* counts, double gate_px, int K_max, int64_t G_cap,
                                             double* xyz, double* err, int16_t* corr, int32_t* n_out, int32_t* status,
                                             int32_t* n_cand, int32_t* n_resubmitted) {
-  if (n_resubmitted) *n_resubmitted = 0;
-  int rc = mocap_match_triangulate(ctx, n_frames, M_max, blobs, counts, gate_px, K_max, G_cap, xyz, err, corr, n_out, status, n_cand);
-  if (rc) return rc;
-  try {  // (staging vectors: an allocation failure must not leave a C entry point as an exception)
-  std::vector<int64_t> bad;
-  for (int64_t f = 0; f < n_frames; f++)
-    if (status[f]) bad.push_back(f);
-  if (bad.empty()) return MOCAP_OK;
-  const int C = ctx->C;
-  const size_t nb = bad.size();
-  // worst-case root capacity: every blob its own root (never less than the caller asked for)
-  int K_big = C * M_max < 1024 ? C * M_max : 1024;
-  if (K_big < K_max) K_big = K_max;
-  {  // ... as far as the frame state fits a kernel (64 cameras x 256 blobs: the per-root tables of the wide variant end at
-     // a few hundred roots); a frame with more roots than that keeps its root-overflow status
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    if (!frame_shape_fits(ctx, M_max, K_big)) {
-      int lo = K_max, hi = K_big;  // largest K in [K_max, K_big) that fits (K_max itself ran, or failed, above)
-      while (lo < hi) {
-        const int mid = (lo + hi + 1) / 2;
-        if (frame_shape_fits(ctx, M_max, mid)) lo = mid; else hi = mid - 1;
-      }
-      K_big = lo;
-    }
-  }
-  const size_t fb = (size_t)C * M_max * 2;
-  std::vector<float> b2(nb * fb);
-  std::vector<int32_t> c2(nb * C), n2(nb), s2(nb), g2(nb);
-  std::vector<double> x2(nb * K_big * 3), e2(nb * K_big);
-  std::vector<int16_t> r2(nb * (size_t)K_big * C);
-  for (size_t j = 0; j < nb; j++) {
-    memcpy(&b2[j * fb], blobs + (size_t)bad[j] * fb, sizeof(float) * fb);
-    memcpy(&c2[j * C], counts + (size_t)bad[j] * C, sizeof(int32_t) * C);
-  }
-  int keep_cap;
-  {
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    keep_cap = ctx->hit_cap;
-    ctx->hit_cap = M_max;  // wide frames: every gated hit of a (root, camera) pair is kept
-  }
-  rc = mocap_match_triangulate(ctx, (int64_t)nb, M_max, b2.data(), c2.data(), gate_px, K_big, (int64_t)1 << 24, x2.data(),
-                               e2.data(), r2.data(), n2.data(), s2.data(), g2.data());
-  {
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    ctx->hit_cap = keep_cap;
-  }
-  if (rc) return rc;
-  for (size_t j = 0; j < nb; j++) {
-    const int64_t f = bad[j];
-    n_out[f] = n2[j];   // > K_max: the caller's arrays are too small for this frame -- status says so, n_out how many it needs
-    if (n_cand) n_cand[f] = g2[j];
-    if (s2[j] == 0 && n2[j] > K_max) {
-      status[f] = MOCAP_ST_ROOT_OVERFLOW;
-      continue;
-    }
-    status[f] = s2[j];
-    if (s2[j]) continue;
-    const size_t k = (size_t)n2[j];
-    memcpy(xyz + (size_t)f * K_max * 3, &x2[j * K_big * 3], sizeof(double) * 3 * k);
-    memcpy(err + (size_t)f * K_max, &e2[j * K_big], sizeof(double) * k);
-    memcpy(corr + (size_t)f * K_max * C, &r2[j * (size_t)K_big * C], sizeof(int16_t) * C * k);
-  }
-  if (n_resubmitted) *n_resubmitted = (int32_t)nb;
-  return MOCAP_OK;
-  } catch (const std::exception& ex) {
-    return ctx->fail(MOCAP_E_HIP, "mocap_match_triangulate_auto: %s", ex.what());
-  }
+  if (!ctx) return MOCAP_E_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  return match_host_locked(ctx, n_frames, M_max, blobs, counts, gate_px, K_max, G_cap, xyz, err, corr, n_out, status, n_cand,
+                           true, n_resubmitted);
 }
 
 // ------------------------------------------------------------------ double-precision centroids at the boundary
@@ -1162,29 +1256,35 @@ int track_locked(mocap_ctx* ctx, int64_t n_frames, const uint8_t* images, int M_
     ea.out_counts = h_counts;
     ea.out_blob_status = h_bstat;
   }
-  const float* in_blobs = images ? d_blobs : h_blobs;       // the frame kernel reads pinned host memory in place (zero-copy)
+  // the frame kernel reads pinned host memory in place (zero-copy) -- except when the shape goes to the wide variant, which
+  // re-reads the blobs for every root batch and candidate view: those are staged into device memory once
+  const float* in_blobs = images ? d_blobs : h_blobs;
   const int32_t* in_counts = images ? d_counts : h_counts;
-  const int keep_cap = ctx->hit_cap;
-  for (int pass = 0; pass < 2; pass++) {
-    // pass 1 (only when a cap was hit): the largest caps the core has -- the reference has none (helpers.py:394-400)
-    const int64_t gc = pass ? ((int64_t)1 << 24) : G_cap;
-    if (pass) ctx->hit_cap = M_max;
-    int rc = match_dev_locked(ctx, n_frames, M_max, in_blobs, in_counts, gate_px, K_max, gc, d_xyz, d_err, d_corr, d_n,
+  if (!images && plan_frame(ctx, M_max, K_max, 0).wide) {
+    DevBuf& st = ctx->live_stage;
+    if (st.reserve(b_blobs + b_counts)) return ctx->fail(MOCAP_E_HIP, "hipMalloc(%zu) failed", b_blobs + b_counts);
+    HIP_TRY(ctx, hipMemcpyAsync(st.ptr, h_blobs, sizeof(float) * F * C * M_max * 2, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync((char*)st.ptr + b_blobs, h_counts, sizeof(int32_t) * F * C, hipMemcpyHostToDevice, ctx->stream));
+    in_blobs = (const float*)st.ptr;
+    in_counts = (const int32_t*)((char*)st.ptr + b_blobs);
+  }
+  {
+    int rc = match_dev_locked(ctx, n_frames, M_max, in_blobs, in_counts, gate_px, K_max, G_cap, d_xyz, d_err, d_corr, d_n,
                               d_status, d_ncand);
-    ctx->hit_cap = keep_cap;
+    if (rc) return rc;
+    // frames that hit a cap (candidates, hit lists, roots): re-run, those frames only, with the largest caps the core has --
+    // the reference has none (helpers.py:394-400) -- before the export; queued behind the first pass, no host round trip
+    rc = resubmit_dev_locked(ctx, n_frames, M_max, in_blobs, in_counts, gate_px, K_max, d_xyz, d_err, d_corr, d_n, d_status,
+                             d_ncand, nullptr);
     if (rc) return rc;
     HIP_TRY(ctx, launch_track_export(la, ea, ctx->stream));
     rc = wait_live_event(ctx);
     if (rc) return rc;
-    bool again = false;
-    for (size_t f = 0; f < F; f++)
-      if (h_status[f] & (MOCAP_ST_CAND_OVERFLOW | MOCAP_ST_HIT_OVERFLOW)) again = true;
-    if (!again) break;
   }
   memcpy(o.n_pts, h_n, sizeof(int32_t) * F);
   memcpy(o.status, h_status, sizeof(int32_t) * F);
   for (size_t f = 0; f < F; f++) {
-    const size_t k = (size_t)(h_n[f] < 0 ? 0 : (h_n[f] > K_max ? K_max : h_n[f]));
+    const size_t k = (size_t)((h_n[f] < 0 || h_n[f] > K_max) ? 0 : h_n[f]);  // > K_max: needs more slots, nothing written
     memcpy(o.xyz + f * K_max * 3, h_xyz + f * K_max * 3, sizeof(double) * 3 * k);
     memcpy(o.err + f * K_max, h_err + f * K_max, sizeof(double) * k);
     if (o.corr) memcpy(o.corr + f * K_max * C, h_corr + f * K_max * C, sizeof(int16_t) * C * k);
@@ -1240,6 +1340,10 @@ extern "C" int mocap_track_frame_dev(mocap_ctx* ctx, int64_t n_frames, int M_max
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   int rc = match_dev_locked(ctx, n_frames, M_max, d_blobs, d_counts, gate_px, K_max, G_cap, d_xyz, d_err, d_corr, d_n_pts,
                             d_status, nullptr);
+  if (rc) return rc;
+  // frames that hit a cap are re-run on the device with the largest caps before the object search reads the points
+  rc = resubmit_dev_locked(ctx, n_frames, M_max, d_blobs, d_counts, gate_px, K_max, d_xyz, d_err, d_corr, d_n_pts, d_status,
+                           nullptr, nullptr);
   if (rc) return rc;
   if (O_max > 0) {
     rc = locate_dev_locked(ctx, n_frames, K_max, d_xyz, d_err, d_n_pts, O_max, d_pos, d_heading, d_oerr, d_drone, nullptr, d_n_obj);

@@ -76,6 +76,10 @@ struct mocap_ctx {
   int blob_skip_dark = 1;     // exact early-out for tiles whose source bytes span a range <= 2 (mocap_set_blob_options)
   DevBuf compact_ws;        // block totals of the track-compaction scan
   DevBuf frame_ws;          // wide-frame workspace: [workgroup][hit lists | group columns | ...]
+  DevBuf live_stage;        // mocap_track_frame: device copy of a wide frame's blobs (narrow frames are read from pinned host memory in place)
+  DevBuf resub;             // device-side re-submit: counters | frame list | gathered inputs | second-pass outputs
+  DevBuf resub_ctr;         // ... its two alternating counters (never re-allocated while a call is in flight)
+  uint32_t resub_calls = 0; // ... parity selects the counter of the current call
   DevBuf scratch[4];        // [0] host-API staging, [1..3] bundle adjustment workspace
 
   int fail(int code, const char* fmt, ...);

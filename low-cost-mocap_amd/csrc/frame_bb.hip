@@ -612,7 +612,7 @@ struct BBState {
       if (om > 0.0f) atomicMax(&misc[MI_OMAX], __float_as_int(om));
       if (tid == 64) {
         const int it = q_add(&p.q.counters[QC_NEXT_FRAME], 1);
-        misc[MI_NEXT] = it < p.n_frames ? it : -1;
+        misc[MI_NEXT] = it < frame_count(p) ? it : -1;
       }
     }
     __syncthreads();
@@ -1050,7 +1050,7 @@ __global__ __launch_bounds__(kBBThreads, MOCAP_BB_WAVES_PER_EU) void frame_bb_ke
   // into the spare LDS buffer
   if (tid == 0) {
     const int it = q_add(&q.counters[QC_NEXT_FRAME], 1);
-    st.misc[MI_ITEM] = it < p.n_frames ? it : -1;
+    st.misc[MI_ITEM] = it < frame_count(p) ? it : -1;
   }
   __syncthreads();
   int item = st.misc[MI_ITEM];

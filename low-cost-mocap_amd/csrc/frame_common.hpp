@@ -33,6 +33,16 @@ __device__ __forceinline__ Tp q_ld(const Tp* p) { return __hip_atomic_load(p, __
 template <class Tp>
 __device__ __forceinline__ void q_st(Tp* p, Tp v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+// Frames of the batch: FrameArgs::n_frames, or fewer when the count lives on the device (the re-submit pass).  Read where
+// it is used (the queue pull of one lane), never hoisted: nothing of it stays in registers across a frame.
+__device__ __forceinline__ int64_t frame_count(const FrameArgs& p) {
+  if (p.n_frames_dev) {
+    const int64_t v = q_load(p.n_frames_dev);
+    return v < p.n_frames ? v : p.n_frames;
+  }
+  return p.n_frames;
+}
+
 // per-root epipolar line record in LDS: a, b, c, sqrt(a^2+b^2), its reciprocal, pad
 constexpr int kLineStride = 6;
 

@@ -1354,7 +1354,7 @@ __global__ __launch_bounds__(T, MOCAP_FRAME_WAVES_PER_EU) void frame_kernel(Fram
             chunk_end = chunk_next + q.frame_chunk;
           }
           item = chunk_next++;
-          if (item >= p.n_frames) {
+          if (item >= frame_count(p)) {
             item = -1;
             frames_left = false;
             if (done_local) {  // the frames of a chunk that reached past the end of the batch
@@ -1376,7 +1376,7 @@ __global__ __launch_bounds__(T, MOCAP_FRAME_WAVES_PER_EU) void frame_kernel(Fram
             }
             // a producer publishes its slices BEFORE it counts its frame as done: once every frame is done, an
             // unpublished ticket will never be published (and neither will any later one)
-            if (q_load(&q.counters[QC_FRAMES_DONE]) >= (int)p.n_frames) {
+            if (q_load(&q.counters[QC_FRAMES_DONE]) >= (int)frame_count(p)) {
               if (q_load(&q.slice_gen[s]) == q.gen) {
                 kind = 2;
                 item = s;
@@ -1532,7 +1532,7 @@ __global__ __launch_bounds__(T, MOCAP_FRAME_WAVES_PER_EU) void frame_kernel(Fram
           chunk_end = chunk_next + q.frame_chunk;
         }
         item = chunk_next++;
-        if (item >= p.n_frames) item = -1;
+        if (item >= frame_count(p)) item = -1;
       } else if (MODE == MODE_SLICE) {
         int n = q.counters[QC_N_SLICES];
         if (n > q.W_cap) n = q.W_cap;

@@ -60,6 +60,8 @@ struct FrameArgs {
   double bb_c0[3]; // branch and bound: origin of the frame its bounds are taken in (a point inside the working volume)
   double p3max2c;  // ... (1 + 1e-5) * max |P[2] M|^2 in that frame
   double p3max2;  // EigCut: (1 + 1e-5) * max |P[2]|^2 over the cameras, 0 = eigenvalue cut-off off (see mocap_device.hpp)
+  const int32_t* n_frames_dev;  // null, or a device-side frame count: the batch is min(*n_frames_dev, n_frames) frames long
+                                // (the re-submit pass of mocap_match_triangulate_dev_auto: its length is only known on the device)
 };
 
 constexpr int kWideThreads = 1024;  // workgroup size of the wide-frame variant (one workgroup per CU)
@@ -128,6 +130,38 @@ struct CompactArgs {
   int64_t* total;           // null, or [1] out (e.g. pinned host memory)
 };
 hipError_t launch_compact_tracks(const CompactArgs& a, hipStream_t stream);
+
+// device-side re-submit of the frames that hit a cap (mocap_match_triangulate_dev_auto, csrc/post_kernels.hip): the flagged
+// frames' inputs are gathered into a scratch batch whose length lives on the device, the frame kernel runs on it with the
+// largest caps, and the results that fit the caller's K_max slots are scattered back
+struct ResubmitArgs {
+  int64_t n_frames;          // frames of the caller's batch
+  int64_t cap;               // frames the scratch batch holds
+  int C, M, K_max, K_big;    // K_big: root / output capacity of the second pass
+  const int32_t* status;     // [F] first pass
+  const float* blobs;        // [F][C][M][2]
+  const int32_t* counts;     // [F][C]
+  int32_t* list;             // [cap] flagged frames (unordered)
+  int32_t* count;            // [1] number of flagged frames (may exceed cap); zero on entry
+  int32_t* count_next;       // [1] the NEXT call's counter: zeroed by the gather kernel (no memset between calls)
+  float* b2;                 // [cap][C][M][2]
+  int32_t* c2;               // [cap][C]
+  const double* x2;          // [cap][K_big][3] second pass
+  const double* e2;          // [cap][K_big]
+  const int16_t* r2;         // [cap][K_big][C]
+  const int32_t* n2;         // [cap]
+  const int32_t* s2;         // [cap]
+  const int32_t* g2;         // [cap]
+  double* xyz;               // the caller's outputs ([F][K_max] slots)
+  double* err;
+  int16_t* corr;
+  int32_t* n_out;
+  int32_t* status_out;
+  int32_t* n_cand;           // or null
+  int32_t* info;             // null, or [2] out: {frames flagged, frames re-run}
+};
+hipError_t launch_resubmit_gather(const ResubmitArgs& a, hipStream_t stream);
+hipError_t launch_resubmit_scatter(const ResubmitArgs& a, hipStream_t stream);
 
 // blob extraction, the step before the frame path (reference helpers.py:68-82, 143-163), csrc/blob_kernels.hip
 constexpr int BLOB_ST_POINT_OVERFLOW_ = 1;  // more centroids than M_max: the first M_max are kept

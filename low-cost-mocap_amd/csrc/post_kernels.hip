@@ -25,7 +25,7 @@ __global__ __launch_bounds__(64) void locate_objects_kernel(LocateArgs a) {
     const double* P = a.xyz + (size_t)f * a.K_max * 3;
     const double* E = a.err + (size_t)f * a.K_max;
     int K = a.n_pts[f];
-    K = K < 0 ? 0 : (K > a.K_max ? a.K_max : K);
+    K = (K < 0 || K > a.K_max) ? 0 : K;  // > K_max: a re-submitted frame that needs more slots than the caller gave (nothing was written)
     unsigned long long matched[4] = {0, 0, 0, 0};  // already_matched_points, K <= 256
     int no = 0;
     for (int i = 0; i < K; i++) {
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(64) void track_export_kernel(LocateArgs a, TrackExp
   const int lane = threadIdx.x;
   for (int64_t f = blockIdx.x; f < a.n_frames; f += gridDim.x) {
     int K = a.n_pts[f];
-    K = K < 0 ? 0 : (K > a.K_max ? a.K_max : K);
+    K = (K < 0 || K > a.K_max) ? 0 : K;  // > K_max: a re-submitted frame that needs more slots than the caller gave (nothing was written)
     const double* gP = a.xyz + (size_t)f * a.K_max * 3;
     const double* gE = a.err + (size_t)f * a.K_max;
     const bool search = a.n_obj != nullptr && K <= 256;  // (the LDS copy holds 256 points: the hosts refuse more with the search on)
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(kScanBlock) void compact_scan_blocks_kernel(Compact
   int64_t v = 0;
   if (f < a.n_frames) {
     const int n = a.n_out[f];
-    v = n < 0 ? 0 : (n > a.K_max ? a.K_max : n);
+    v = (n < 0 || n > a.K_max) ? 0 : n;  // > K_max: a re-submitted frame that needs more slots (nothing was written)
   }
   // inclusive scan inside the wave, then across the block's 16 waves
   int64_t x = v;
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(256) void compact_scatter_kernel(CompactArgs a) {
   const int k = (int)(slot - f * a.K_max);
   if (f >= a.n_frames) return;
   int n = a.n_out[f];
-  n = n < 0 ? 0 : (n > a.K_max ? a.K_max : n);
+  n = (n < 0 || n > a.K_max) ? 0 : n;
   if (k >= n) return;
   const int64_t rec = a.offsets[f] + k;
   if (rec >= a.capacity) return;
@@ -331,6 +331,76 @@ hipError_t launch_compact_tracks(const CompactArgs& a, hipStream_t stream) {
   hipLaunchKernelGGL(compact_add_block_offsets_kernel, dim3((unsigned)((a.n_frames + 255) / 256)), dim3(256), 0, stream, a);
   const int64_t lanes = a.n_frames * a.K_max * (a.stride >> 3);
   hipLaunchKernelGGL(compact_scatter_kernel, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, stream, a);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- device-side re-submit (mocap_match_triangulate_dev_auto)
+// The reference enumerates the full Cartesian product whatever its size (helpers.py:394-400); the frame kernels work
+// under caps and flag the frames that hit one.  Three enqueues repair them without the host ever learning how many
+// there were: (1) below, the flagged frames' inputs gathered into a scratch batch + their number, on the device;
+// (2) the frame kernel on that batch (FrameArgs::n_frames_dev) with the largest caps; (3) the scatter back.
+__global__ __launch_bounds__(256) void resubmit_gather_kernel(ResubmitArgs a) {
+  // one wave per 64 consecutive frames: ballot of the flagged ones, one atomic for the wave's slots, then the whole
+  // wave copies each flagged frame's blobs (C x M x 2 floats) and counts
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (wave == 0 && lane == 0) *a.count_next = 0;
+  const int64_t f0 = wave * 64;
+  if (f0 >= a.n_frames) return;
+  const int64_t f = f0 + lane;
+  const bool flagged = f < a.n_frames && a.status[f] != 0;
+  unsigned long long m = __ballot(flagged);
+  if (!m) return;
+  int base = 0;
+  if (lane == 0) base = atomicAdd(a.count, __popcll(m));
+  base = __builtin_amdgcn_readfirstlane(base);
+  const int per = a.C * a.M * 2;
+  for (int j = base; m; m &= m - 1, j++) {
+    if (j >= a.cap) break;  // more flagged frames than the scratch batch holds: they keep their status
+    const int64_t src = f0 + (__ffsll((long long)m) - 1);
+    if (lane == 0) a.list[j] = (int32_t)src;
+    const float* sb = a.blobs + (size_t)src * per;
+    float* db = a.b2 + (size_t)j * per;
+    for (int i = lane; i < per; i += 64) db[i] = sb[i];
+    if (lane < a.C) a.c2[(size_t)j * a.C + lane] = a.counts[(size_t)src * a.C + lane];
+  }
+}
+
+__global__ __launch_bounds__(256) void resubmit_scatter_kernel(ResubmitArgs a) {
+  // one workgroup per re-run frame (grid-stride): header by lane 0, then the valid slots word by word
+  int total = *a.count;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && a.info) {
+    a.info[0] = total;
+    a.info[1] = total < a.cap ? total : (int)a.cap;
+  }
+  if (total > a.cap) total = (int)a.cap;
+  for (int j = blockIdx.x; j < total; j += gridDim.x) {
+    const int64_t f = a.list[j];
+    const int n = a.n2[j], s = a.s2[j];
+    if (threadIdx.x == 0) {
+      a.n_out[f] = n;  // > K_max: the caller's arrays are too small for this frame -- status says so, n_out how many it needs
+      if (a.n_cand) a.n_cand[f] = a.g2[j];
+      a.status_out[f] = (s == 0 && n > a.K_max) ? MOCAP_ST_ROOT_OVERFLOW_ : s;
+    }
+    if (s != 0 || n > a.K_max) continue;  // (uniform)
+    const size_t so = (size_t)j * a.K_big, dd = (size_t)f * a.K_max;
+    for (int i = threadIdx.x; i < 3 * n; i += blockDim.x) a.xyz[dd * 3 + i] = a.x2[so * 3 + i];
+    for (int i = threadIdx.x; i < n; i += blockDim.x) a.err[dd + i] = a.e2[so + i];
+    for (int i = threadIdx.x; i < n * a.C; i += blockDim.x) a.corr[dd * a.C + i] = a.r2[so * a.C + i];
+  }
+}
+
+hipError_t launch_resubmit_gather(const ResubmitArgs& a, hipStream_t stream) {
+  if (a.n_frames <= 0) return hipSuccess;
+  const int64_t waves = (a.n_frames + 63) / 64;
+  hipLaunchKernelGGL(resubmit_gather_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_resubmit_scatter(const ResubmitArgs& a, hipStream_t stream) {
+  if (a.n_frames <= 0) return hipSuccess;
+  const int64_t blocks = a.cap < 1024 ? (a.cap < 1 ? 1 : a.cap) : 1024;
+  hipLaunchKernelGGL(resubmit_scatter_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a);
   return hipGetLastError();
 }
 

@@ -48,6 +48,7 @@ SIGNATURES = {
     "mocap_triangulate_dev": (_i32, [_vp, _i64, _vp, _vp, _vp]),
     "mocap_match_triangulate": (_i32, [_vp, _i64, _i32, _vp, _vp, _dbl, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mocap_match_triangulate_dev": (_i32, [_vp, _i64, _i32, _vp, _vp, _dbl, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mocap_match_triangulate_dev_auto": (_i32, [_vp, _i64, _i32, _vp, _vp, _dbl, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mocap_match_triangulate_auto": (_i32, [_vp, _i64, _i32, _vp, _vp, _dbl, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mocap_match_triangulate_f64": (_i32, [_vp, _i64, _i32, _vp, _vp, _dbl, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mocap_track_frame": (_i32, [_vp, _i64, _i32, _vp, _vp, _dbl, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
@@ -120,6 +121,7 @@ class MocapCore:
         self.device_id = int(device_id)
         self.C = 0
         self._hit_cap, self._force_wide = 32, False
+        self.f32_rounding = True     # MOCAP_OPT_F32_ROUNDING, the library's default
 
     def close(self):
         if getattr(self, "_h", None):
@@ -152,6 +154,7 @@ class MocapCore:
 
     def set_options(self, f32_rounding=True):
         self._check(self.lib.mocap_set_options(self._h, OPT_F32_ROUNDING if f32_rounding else 0))
+        self.f32_rounding = bool(f32_rounding)
 
     def set_tuning(self, frame_threads=0, heavy_threshold=-1, slice_size=0):
         self._check(self.lib.mocap_set_tuning(self._h, int(frame_threads), int(heavy_threshold), int(slice_size)))
@@ -294,8 +297,10 @@ class MocapCore:
                                                    _p(o["xyz"]), _p(o["err"]), _p(o["corr"]), _p(o["n_pts"]), _p(o["status"]),
                                                    int(O_max), _p(o["pos"]), _p(o["heading"]), _p(o["error"]),
                                                    _p(o["droneIndex"]), _p(o["n_obj"])))
-            if (o["status"] & ST_ROOT_OVERFLOW).any() and K_max < min(C * M, 256 if O_max else 1024):
-                K_max = min(C * M, 256 if O_max else 1024)        # every blob its own root
+            need = (o["status"] & ST_ROOT_OVERFLOW).astype(bool) & (o["n_pts"] > K_max)
+            if need.any() and K_max < min(C * M, 256 if O_max else 1024):
+                # the core re-ran those frames itself and says how many slots they need (n_pts)
+                K_max = min(int(o["n_pts"][need].max()), 256 if O_max else 1024)
                 continue
             return o
 
@@ -314,8 +319,9 @@ class MocapCore:
                                                           _p(o["err"]), _p(o["corr"]), _p(o["n_pts"]), _p(o["status"]), int(O_max),
                                                           _p(o["pos"]), _p(o["heading"]), _p(o["error"]), _p(o["droneIndex"]),
                                                           _p(o["n_obj"])))
-            if (o["status"] & ST_ROOT_OVERFLOW).any() and K_max < min(C * M_max, 256 if O_max else 1024):
-                K_max = min(C * M_max, 256 if O_max else 1024)
+            need = (o["status"] & ST_ROOT_OVERFLOW).astype(bool) & (o["n_pts"] > K_max)
+            if need.any() and K_max < min(C * M_max, 256 if O_max else 1024):
+                K_max = min(int(o["n_pts"][need].max()), 256 if O_max else 1024)
                 continue
             return o
 
@@ -397,6 +403,16 @@ class MocapCore:
         self._check(self.lib.mocap_match_triangulate_dev(
             self._h, int(n_frames), int(M_max), _vp(d_blobs), _vp(d_counts), float(gate_px), int(K_max),
             int(G_cap), _vp(d_xyz), _vp(d_err), _vp(d_corr), _vp(d_n_out), _vp(d_status), _vp(d_n_cand or 0)))
+
+    def match_triangulate_dev_auto(self, n_frames, M_max, d_blobs, d_counts, gate_px, K_max, G_cap, d_xyz, d_err,
+                                   d_corr, d_n_out, d_status, d_n_cand=0, d_resubmitted=0):
+        """mocap_match_triangulate_dev_auto: the same, then the frames that hit a cap are re-run ON THE DEVICE with the largest
+        caps and scattered back -- three more enqueues, no host wait.  d_resubmitted: 0, or a device-accessible int32[2]
+        {frames flagged, frames re-run}."""
+        self._check(self.lib.mocap_match_triangulate_dev_auto(
+            self._h, int(n_frames), int(M_max), _vp(d_blobs), _vp(d_counts), float(gate_px), int(K_max),
+            int(G_cap), _vp(d_xyz), _vp(d_err), _vp(d_corr), _vp(d_n_out), _vp(d_status), _vp(d_n_cand or 0),
+            _vp(d_resubmitted or 0)))
 
     def compact_tracks_dev(self, n_frames, K_max, d_n_out, d_xyz, d_err, d_corr, d_offsets, d_records, capacity, d_total=0):
         """Valid points of a frame batch -> fixed-stride records + exclusive prefix of n_out (device pointers)."""

@@ -171,7 +171,7 @@ def compact_tracks_reference(n_out, xyz, err, corr):
     F, K = err.shape
     C = corr.shape[2]
     stride = track_record_bytes(C)
-    n = np.clip(n_out, 0, K).astype(np.int64)
+    n = np.where((n_out < 0) | (n_out > K), 0, n_out).astype(np.int64)   # > K: a frame that needs more slots than it was given (nothing was written)
     offsets = np.zeros(F + 1, dtype=np.int64)
     np.cumsum(n, out=offsets[1:])
     valid = np.arange(K)[None, :] < n[:, None]
@@ -189,7 +189,7 @@ def unpack_compact(n_out, records, C, K_max, fill=np.nan):
     n_out = np.asarray(n_out).astype(np.int64)
     F = n_out.shape[0]
     rec = np.ascontiguousarray(np.asarray(records)).reshape(-1, track_record_bytes(C))
-    n = np.clip(n_out, 0, K_max)
+    n = np.where((n_out < 0) | (n_out > K_max), 0, n_out)
     valid = np.arange(K_max)[None, :] < n[:, None]
     assert int(n.sum()) == rec.shape[0], (int(n.sum()), rec.shape)
     xyz = np.full((F, K_max, 3), fill)

@@ -18,6 +18,7 @@ Intrinsics: the reference reads them from the `Cameras` singleton (helpers.py:21
 here `set_camera_params()` takes the same list of {"intrinsic_matrix": 3x3, ...} dicts
 (the content of api/camera-params.json).
 """
+import os
 import threading
 
 import numpy as np
@@ -475,7 +476,10 @@ def bundle_adjustment(image_points, camera_poses, socketio, return_info=False):
     with _state["lock"]:
         core = _ba_core()
         mode = _state["ba_mode"]
+        f32_rounding = get_core().f32_rounding      # options live in a context: the calibration's follows the frame path's
     with _state["ba_lock"]:
+        if core.f32_rounding != f32_rounding:
+            core.set_options(f32_rounding=f32_rounding)
         core.set_cameras(K, R, t)
         if mode == "resident":
             core.set_ba_progress(emit if socketio is not None else None)
@@ -485,13 +489,53 @@ def bundle_adjustment(image_points, camera_poses, socketio, return_info=False):
                 core.set_ba_progress(None)
         else:
             from scipy import optimize
+            from scipy.optimize._numdiff import _compute_absolute_step
+
+            last = {"x": None, "r": None}
 
             def residual_function(params):
                 r = core.ba_residuals(params, obs)[0]
                 emit(params)                                    # helpers.py:274
-                return r[~np.isnan(r)].astype(np.float32)       # helpers.py:273
+                r = r[~np.isnan(r)].astype(np.float32)          # helpers.py:273
+                last["x"], last["r"] = np.array(params, dtype=np.float64), r
+                return r
 
-            res = optimize.least_squares(residual_function, x0, verbose=0, loss="cauchy", ftol=1e-2)
+            def jacobian(params):
+                """The Jacobian least_squares would difference itself (jac='2-point': scipy _numdiff.approx_derivative ->
+                _dense_difference), with its n residual evaluations made by ONE call of the core: the n perturbed parameter
+                vectors x + h_i e_i go through mocap_ba_residuals as a batch.  Same step vector (SciPy's own
+                _compute_absolute_step: float32 residuals -> sqrt(eps_float32) relative step), same residual bits (the batch
+                is the single call's kernel per parameter vector), same NumPy expressions for `df / dx` (float32
+                difference, float64 quotient) => the same J bit for bit, hence the same iterates, nfev, njev and poses as
+                the reference's call on the solver goldens (tests/test_gpu_ba.py).  The reference's residual_function
+                emits the poses at every one of those evaluations (helpers.py:274): so does this."""
+                x0_ = np.array(params, dtype=np.float64)
+                if last["x"] is not None and np.array_equal(last["x"], x0_):
+                    f0 = last["r"]                              # trf hands approx_derivative the f it just evaluated at x
+                    X = np.repeat(x0_[None, :], x0_.size, axis=0)
+                    first = 0
+                else:                                           # (not reached from trf: f0 rides along in the batch)
+                    X = np.repeat(x0_[None, :], x0_.size + 1, axis=0)
+                    first = 1
+                    f0 = None
+                h = _compute_absolute_step(None, x0_, last["r"] if f0 is None else f0, "2-point")
+                idx = np.arange(x0_.size)
+                X[first + idx, idx] = x0_ + h                   # x1[i] += h[i]
+                dx = X[first + idx, idx] - x0_                  # "recompute dx as exactly representable number"
+                R = core.ba_residuals(X, obs)
+                if f0 is None:
+                    f0 = R[0][~np.isnan(R[0])].astype(np.float32)
+                J_T = np.empty((x0_.size, f0.size))
+                for i in range(x0_.size):
+                    emit(X[first + i])
+                    ri = R[first + i]
+                    df = ri[~np.isnan(ri)].astype(np.float32) - f0   # (a mask that moved raises here, as it would in the reference)
+                    J_T[i] = df / dx[i]
+                return J_T.T
+
+            use_batched = os.environ.get("MOCAP_BA_BATCHED_JAC", "1") != "0"
+            res = optimize.least_squares(residual_function, x0, jac=jacobian if use_batched else "2-point", verbose=0,
+                                         loss="cauchy", ftol=1e-2)
             x, info = res.x, {"iterations": res.njev, "njev": res.njev, "nfev": res.nfev, "status": res.status,
                        "cost": res.cost, "optimality": res.optimality}
     poses = _params_to_camera_poses(x)

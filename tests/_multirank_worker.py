@@ -20,7 +20,7 @@ def run_shard(core, dev, blobs, counts, K, gate=5.0):
     out = dict(xyz=torch.empty((F, K, 3), dtype=torch.float64, device=dev), err=torch.empty((F, K), dtype=torch.float64, device=dev),
                corr=torch.empty((F, K, C), dtype=torch.int16, device=dev), n_out=torch.zeros(F, dtype=torch.int32, device=dev),
                status=torch.zeros(F, dtype=torch.int32, device=dev))
-    core.match_triangulate_dev(F, M, d_b.data_ptr(), d_c.data_ptr(), gate, K, 1 << 20, out["xyz"].data_ptr(), out["err"].data_ptr(),
+    core.match_triangulate_dev_auto(F, M, d_b.data_ptr(), d_c.data_ptr(), gate, K, 1 << 20, out["xyz"].data_ptr(), out["err"].data_ptr(),
                                out["corr"].data_ptr(), out["n_out"].data_ptr(), out["status"].data_ptr())
     return out
 

@@ -482,3 +482,169 @@ def test_ba_solve_keeps_its_8_double_info_abi(core):
                 1e-8, 0, 1, 1, info.ctypes.data_as(ctypes.c_void_p), *extra)
         assert rc in (0, -5)
         assert np.all(info[n_written:] == -7.0) and info[0] >= 1 and info[6] > 0
+
+
+# ----------------------------------------------------------------------------- BASELINE configs[3]'s own size
+# "Bundle-adjustment calibration: 8 cams, 2000 frames x 8 markers": 16 000 points.  The launch takes another grid and a
+# deeper reduction tree than anything at 1 000 points (250 chunks of 64 points, two levels of the 16-ary last-arriver
+# tree; no launch-ahead: N > 2048), so the three rungs of the ladder are repeated at that size.
+N_CALIB = 16_000
+
+
+@pytest.fixture(scope="module")
+def calib16k():
+    from mocap_core import helpers, synth
+    rig = synth.ring_rig(8)
+    rng = np.random.default_rng(81)
+    obs, _ = synth.make_ba_observations(rig, N_CALIB, seed=81, dropout=0.05)
+    init = synth.perturb_rig(rig, rng)
+    helpers.set_camera_params([{"intrinsic_matrix": k.tolist()} for k in rig["K"]])
+    x0 = helpers._ba_x0([{"R": init["R"][i], "t": init["t"][i]} for i in range(8)])
+    return rig, init, obs, x0
+
+
+def test_residuals_vs_c_oracle_16k_points(core, calib16k):
+    from oracle import c_oracle
+    rig, init, obs, x0 = calib16k
+    rng = np.random.default_rng(82)
+    core.set_cameras(rig["K"], init["R"], init["t"])
+    xs = np.stack([x0, x0 + rng.normal(0, 1e-3, x0.size)])
+    r = core.ba_residuals(xs, obs)
+    ref = c_oracle.COracle(rig["K"], init["R"], init["t"]).ba_residuals(xs, obs)
+    assert r.shape == (2, N_CALIB) and np.array_equal(np.isnan(r), np.isnan(ref))
+    ok = ~np.isnan(ref)
+    assert ok.sum() > 2 * 0.99 * N_CALIB
+    np.testing.assert_allclose(r[ok], ref[ok], rtol=1e-3, atol=1e-12)   # float32-boundary flips of cv.projectPoints' rounding
+    assert np.median(np.abs(r[ok] - ref[ok]) / ref[ok]) < 1e-9
+    assert (np.abs(r[ok] - ref[ok]) <= 1e-9 * ref[ok]).mean() > 0.99
+
+
+def test_gram_mfma_vs_numpy_16k_points(core, calib16k):
+    """J^T J / J^T f of the one-launch linearisation at 16 000 points (250 chunks, two-level reduction tree) against NumPy on
+    the J the same launch returned, in both residual precisions; J itself against SciPy's own float32 differencing."""
+    from scipy.optimize._lsq.common import scale_for_robust_loss_function
+    from scipy.optimize._lsq.least_squares import construct_loss_function
+    from scipy.optimize._numdiff import approx_derivative
+    rig, init, obs, x0 = calib16k
+    core.set_cameras(rig["K"], init["R"], init["t"])
+    dead = [0] + [1 + 7 * i for i in range(7)]
+    for f32 in (False, True):
+        ne = core.ba_normal_eq(x0, obs, f32_residuals=f32, use_cauchy=True, want_J=True)
+        J = ne["J"]
+        assert J.shape == (ne["m"], 50) and ne["m"] > 0.99 * N_CALIB
+        G = J.T @ J
+        np.testing.assert_allclose(ne["JtJ"], G, rtol=1e-11, atol=1e-12 * np.abs(G).max())
+        assert not J[:, dead].any() and not ne["JtJ"][dead].any()
+
+    def fun(x):                                                   # = the reference's residual_function
+        r = core.ba_residuals(x, obs)[0]
+        return r[~np.isnan(r)].astype(np.float32)
+
+    f0 = fun(x0)
+    J_ref = approx_derivative(fun, x0, method="2-point", f0=f0)
+    rho = construct_loss_function(f0.size, "cauchy", 1.0)(f0)
+    J_ref, f_ref = scale_for_robust_loss_function(J_ref, f0.copy(), rho)
+    assert ne["m"] == f0.size
+    np.testing.assert_allclose(ne["J"], J_ref, rtol=1e-13, atol=1e-13 * np.abs(J_ref).max())
+    np.testing.assert_allclose(ne["cost"], 0.5 * np.sum(rho[0]), rtol=2e-7)
+    g_ref = J_ref.T.dot(f_ref)
+    np.testing.assert_allclose(ne["Jtr"], g_ref, rtol=1e-10, atol=1e-11 * np.abs(g_ref).max())
+
+
+def test_trust_region_step_vs_scipy_16k_points(core, calib16k):
+    """One trust-region step on the 16 000-point normal equations against scipy's solve_lsq_trust_region on the SVD of the
+    same J (scipy _lsq/trf.py:448,495)."""
+    from scipy.linalg import svd
+    from scipy.optimize._lsq.common import solve_lsq_trust_region
+    rig, init, obs, x0 = calib16k
+    core.set_cameras(rig["K"], init["R"], init["t"])
+    ne = core.ba_normal_eq(x0, obs, f32_residuals=False, use_cauchy=True, want_J=True)
+    r0 = core.ba_residuals(x0, obs)[0]
+    f = r0[~np.isnan(r0)]
+    z = f * f
+    f_scaled = f * (1 / (1 + z)) / np.sqrt(np.maximum(1 / (1 + z) - 2 * z / (1 + z) ** 2, np.finfo(float).eps))
+    J = ne["J"]
+    m, n = J.shape
+    U, s, Vt = svd(J, full_matrices=False)
+    uf = U.T @ f_scaled
+    dead = [0] + [1 + 7 * i for i in range(7)]
+    live = np.setdiff1d(np.arange(n), dead)
+    np.testing.assert_allclose(ne["Jtr"], J.T @ f_scaled, rtol=1e-9, atol=1e-9 * np.abs(ne["Jtr"]).max())
+    for Delta in (np.linalg.norm(x0), 1e-2, 1e-4):
+        p_ref, a_ref, _ = solve_lsq_trust_region(n, m, uf, s, Vt.T, Delta, initial_alpha=0.0)
+        p, a, info = core.ba_trust_region_step(ne["JtJ"], ne["Jtr"], m, Delta, alpha=0.0, method=0)
+        assert info["live"] == n - len(dead) and not p[dead].any()
+        np.testing.assert_allclose(a, a_ref, rtol=1e-8)
+        np.testing.assert_allclose(p[live], p_ref[live], rtol=1e-7, atol=1e-8 * np.abs(p_ref).max())
+
+
+def test_resident_solve_16k_points_reduces_the_cost_like_scipy(core, calib16k):
+    """The whole loop at the calibration's own size: mocap_ba_solve and scipy.optimize.least_squares on GPU residuals
+    (reference settings) both stop on ftol = 1e-2, at costs within that tolerance's reach of each other."""
+    from scipy import optimize
+    rig, init, obs, x0 = calib16k
+    core.set_cameras(rig["K"], init["R"], init["t"])
+    x, info = core.ba_solve(x0, obs, ftol=1e-2, f32_residuals=True, use_cauchy=True)
+
+    def fun(p):
+        r = core.ba_residuals(p, obs)[0]
+        return r[~np.isnan(r)].astype(np.float32)
+
+    ref = optimize.least_squares(fun, x0, loss="cauchy", ftol=1e-2, max_nfev=12)
+    assert int(info["m"]) == fun(x0).size and info["cost"] < 0.5 * info["cost0"]
+    if ref.status > 0:
+        np.testing.assert_allclose(info["cost"], ref.cost, rtol=0.1)
+
+
+# ----------------------------------------------------------------------------- default mode: one call per Jacobian
+def test_batched_residuals_equal_single_calls_bit_for_bit(core):
+    """mocap_ba_residuals over P parameter vectors at once = P single calls, to the bit (the batch is what the default
+    mode's Jacobian rides on; grid.y = parameter vector, same kernel, same per-point arithmetic)."""
+    from mocap_core import helpers, synth
+    rig = synth.ring_rig(8)
+    rng = np.random.default_rng(91)
+    obs, _ = synth.make_ba_observations(rig, 1000, seed=91, dropout=0.08)
+    init = synth.perturb_rig(rig, rng)
+    core.set_cameras(rig["K"], init["R"], init["t"])
+    helpers.set_camera_params([{"intrinsic_matrix": k.tolist()} for k in rig["K"]])
+    x0 = helpers._ba_x0([{"R": init["R"][i], "t": init["t"][i]} for i in range(8)])
+    X = np.stack([x0 + rng.normal(0, 3e-4, x0.size) * (rng.random(x0.size) < 0.1) for _ in range(51)])
+    batch = core.ba_residuals(X, obs)
+    for p in range(X.shape[0]):
+        single = core.ba_residuals(X[p], obs)[0]
+        assert np.array_equal(batch[p], single, equal_nan=True), p
+
+
+@pytest.mark.parametrize("name", SOLVED_GOLDENS)
+def test_default_mode_batched_jacobian_is_scipys_own(core, name, monkeypatch):
+    """helpers.bundle_adjustment (mode "scipy") with its one-call Jacobian against the same call with SciPy differencing
+    by itself (jac="2-point": n + 1 host round trips per Jacobian, MOCAP_BA_BATCHED_JAC=0): identical OptimizeResult
+    statistics and identical poses -- bit for bit, not to a tolerance -- and n + 1 `camera-pose` events per Jacobian plus
+    one per trial point, as the reference emits (helpers.py:274)."""
+    class Sock:
+        def __init__(self):
+            self.n = 0
+
+        def emit(self, event, payload):
+            assert event == "camera-pose"
+            self.n += 1
+
+    from mocap_core import helpers, synth
+    g = load_golden(name)
+    C = g["K"].shape[0]
+    helpers.set_core(core)
+    helpers.set_camera_params([{"intrinsic_matrix": k.tolist()} for k in g["K"]])
+    out = {}
+    for batched in ("1", "0"):
+        monkeypatch.setenv("MOCAP_BA_BATCHED_JAC", batched)
+        poses0 = [{"R": g["R_init"][i].copy(), "t": g["t_init"][i].copy()} for i in range(C)]
+        sock = Sock()
+        with helpers.bundle_adjustment_mode("scipy"):
+            poses, info = helpers.bundle_adjustment(synth.obs_to_reference_array(g["obs"]), poses0, sock, return_info=True)
+        out[batched] = (np.array([np.asarray(p["R"], dtype=np.float64) for p in poses]),
+                        np.array([np.asarray(p["t"], dtype=np.float64).reshape(3) for p in poses]), info, sock.n)
+    (R1, t1, i1, e1), (R0, t0, i0, e0) = out["1"], out["0"]
+    assert [i1["nfev"], i1["njev"], i1["status"]] == [i0["nfev"], i0["njev"], i0["status"]] == g["ba_stats"].tolist()
+    assert i1["cost"] == i0["cost"] and np.array_equal(R1, R0) and np.array_equal(t1, t0)
+    n = 1 + 7 * (C - 1)
+    assert e1 == e0 == i1["nfev"] + n * i1["njev"] + 1          # + the final poses (index.py:277)

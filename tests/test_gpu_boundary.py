@@ -197,9 +197,10 @@ def test_stream_handover_is_ordered_on_the_device(core):
 def test_frame_calls_stay_fast_while_a_calibration_runs(core):
     """The reference's frame loop (helpers.py:68-135, MJPEG thread) keeps running while calculate_camera_pose ->
     bundle_adjustment (index.py:229-277) runs in a handler thread.  The mirror runs the calibration on its own context /
-    stream and never holds the module lock across a residual evaluation: frame calls issued while a default-mode
-    (scipy) 8-camera bundle adjustment is in flight keep their typical sub-millisecond latency and none of them waits for
-    the solve."""
+    stream and never holds the module lock across a residual evaluation: frame calls issued while default-mode (scipy)
+    8-camera bundle adjustments are in flight keep their sub-millisecond latency and none of them waits for a solve.
+    (Round 5: a default-mode solve is ~0.1 s since its Jacobian is one call -- the calibration thread repeats it for the
+    length of the measurement, and is in the library, GIL released, most of that time: a p99 bound holds again.)"""
     import sys
     import threading
     import time
@@ -209,21 +210,29 @@ def test_frame_calls_stay_fast_while_a_calibration_runs(core):
     C = g["K"].shape[0]
     helpers.set_core(core)
     helpers.set_camera_params([{"intrinsic_matrix": k.tolist()} for k in g["K"]])
-    poses0 = [{"R": g["R_init"][i].copy(), "t": g["t_init"][i].copy()} for i in range(C)]
     rig = synth.ring_rig(8)
     blobs, counts, _ = synth.make_blob_stream(rig, 64, 16, seed=4)
     frame_poses = synth.rig_to_pose_dicts(rig)
     frames = [synth.frame_to_reference_lists(blobs[f], counts[f], as_int=True) for f in range(64)]
     want = [helpers.find_point_correspondance_and_object_points([list(p) for p in fr], frame_poses, None)[1] for fr in frames]
-    result = {}
+    ref_obs = synth.obs_to_reference_array(g["obs"])
+    result = {"solves": 0}
+
+    def one_solve():
+        poses0 = [{"R": g["R_init"][i].copy(), "t": g["t_init"][i].copy()} for i in range(C)]
+        return helpers.bundle_adjustment(ref_obs, poses0, None, return_info=True)
+
+    one_solve()                            # the calibration context exists, its kernels have run once
 
     def calibrate():
         t0 = time.perf_counter()
-        result["poses"], result["info"] = helpers.bundle_adjustment(synth.obs_to_reference_array(g["obs"]), poses0, None, return_info=True)
+        while time.perf_counter() - t0 < 1.0:
+            result["poses"], result["info"] = one_solve()
+            result["solves"] += 1
         result["seconds"] = time.perf_counter() - t0
 
     old = sys.getswitchinterval()
-    sys.setswitchinterval(1e-4)            # the calibration thread is mostly Python: hand the GIL over quickly
+    sys.setswitchinterval(1e-4)            # hand the GIL over quickly
     try:
         th = threading.Thread(target=calibrate)
         th.start()
@@ -239,18 +248,140 @@ def test_frame_calls_stay_fast_while_a_calibration_runs(core):
         th.join()
     finally:
         sys.setswitchinterval(old)
-    assert result["seconds"] > 0.3 and len(lat) > 50, (result.get("seconds"), len(lat))       # the calibration really overlapped
+    assert result["solves"] >= 2 and len(lat) > 100, (result, len(lat))       # the calibrations really overlapped
     lat = np.sort(np.array(lat)) * 1e3
-    p50, p99 = lat[len(lat) // 2], lat[int(len(lat) * 0.99)]
-    print(f"frame calls during a calibration: n {len(lat)} p50 {p50:.3f} ms p99 {p99:.3f} ms max {lat[-1]:.3f} ms, solve {result['seconds']:.2f} s")
-    # What the library controls: no frame call waits behind the calibration (one shared lock would put ~a whole solve, a
-    # second, in front of the first call).  The typical call keeps its sub-millisecond latency; the tail of a Python caller
-    # also contains waits for the GIL (SciPy's optimizer thread holds it through its own NumPy / LAPACK calls) and, once per
-    # process, the runtime's dispatch hole after the first burst of launches (profiles/r03_ba_dispatch_hole.txt) -- so the
-    # tail is bounded against the solve's duration, not against a millisecond.
-    p90 = lat[int(len(lat) * 0.90)]
-    assert p50 < 0.5 and p90 < 1.0, (p50, p90, p99, lat[-1])
-    assert lat[-1] < 0.25 * 1e3 * result["seconds"], (lat[-1], result["seconds"])
+    p50, p90, p99 = lat[len(lat) // 2], lat[int(len(lat) * 0.90)], lat[int(len(lat) * 0.99)]
+    print(f"frame calls during calibrations: n {len(lat)} p50 {p50:.3f} ms p90 {p90:.3f} p99 {p99:.3f} ms max {lat[-1]:.3f} ms; "
+          f"{result['solves']} solves in {result['seconds']:.2f} s")
+    # No frame call waits behind a calibration (one shared lock would put a whole solve in front of it).  The calls go
+    # through Python (list marshalling under the GIL, which the other thread's SciPy code also wants): bounded well below
+    # one solve and far below the 8 ms of a 120 fps frame; the library's own share is measured without Python in between in
+    # test_two_contexts_raw_ctypes_frame_latency below.
+    assert p50 < 0.5 and p90 < 1.0 and p99 < 4.0, (p50, p90, p99, lat[-1])
+    assert lat[-1] < 0.5 * 1e3 * result["seconds"] / result["solves"], (lat[-1], result)
     # and the calibration's own answer is the reference's, as when it runs alone
     R = np.array([np.asarray(p["R"], dtype=np.float64) for p in result["poses"]])
     assert np.abs(R - g["R_ba"]).max() == 0.0 and int(result["info"]["nfev"]) == int(g["ba_stats"][0])
+
+
+def _raw_two_thread_latency(core, ba_call, seconds=1.0):
+    """Thread A: `ba_call()` in a tight loop (a ctypes call: the GIL is released for its whole duration).  Thread B (this
+    one): mocap_track_frame on the frame context through raw ctypes with every argument prepared beforehand -- no
+    marshalling, no NumPy between calls.  Returns B's latencies (ms, sorted) and A's call count."""
+    import ctypes
+    import threading
+    import time
+    from mocap_core import capi, synth
+    rig = synth.ring_rig(8)
+    blobs, counts, _ = synth.make_blob_stream(rig, 64, 16, seed=4)
+    core.set_cameras(rig["K"], rig["R"], rig["t"])
+    K = 64
+    o = core._track_outputs(1, K, 0)
+    fn = core.lib.mocap_track_frame
+    args = [[core._h, 1, 16, capi._p(blobs[f:f + 1]), capi._p(counts[f:f + 1]), ctypes.c_double(5.0), K, 1 << 20, capi._p(o["xyz"]),
+             capi._p(o["err"]), capi._p(o["corr"]), capi._p(o["n_pts"]), capi._p(o["status"]), 0, None, None, None, None, None]
+            for f in range(64)]
+    want = [core.track_frame(blobs[f:f + 1], counts[f:f + 1], K_max=K, O_max=0) for f in range(64)]
+    for a in args[:8]:
+        assert fn(*a) == 0
+    stop = threading.Event()
+    calls = {"n": 0, "err": None}
+
+    def hammer():
+        try:
+            while not stop.is_set():
+                ba_call()
+                calls["n"] += 1
+        except Exception as e:               # noqa: BLE001 -- reported by the caller
+            calls["err"] = e
+
+    th = threading.Thread(target=hammer)
+    th.start()
+    lat = []
+    t_end = time.perf_counter() + seconds
+    k = 0
+    try:
+        while time.perf_counter() < t_end:
+            a = args[k % 64]
+            t0 = time.perf_counter()
+            rc = fn(*a)
+            lat.append(time.perf_counter() - t0)
+            assert rc == 0
+            n = int(o["n_pts"][0])
+            assert n == int(want[k % 64]["n_pts"][0]) and np.array_equal(o["xyz"][0, :n], want[k % 64]["xyz"][0, :n])
+            k += 1
+    finally:
+        stop.set()
+        th.join()
+    assert calls["err"] is None, calls["err"]
+    return np.sort(np.array(lat)) * 1e3, calls["n"]
+
+
+def test_two_contexts_raw_ctypes_frame_latency(core):
+    """What the LIBRARY adds to a frame call while a calibration's residual evaluations run on another context (own
+    stream, own lock): nothing of the other context's work is ever waited for.  Raw ctypes on both threads, arguments
+    prepared beforehand: p99 < 0.5 ms, and -- one outlier tolerated for the runtime's once-per-process dispatch hole
+    (profiles/r03_ba_dispatch_hole.txt) -- no call above 2 ms.  Reference: the frame loop and the calculate-camera-pose
+    handler run concurrently (helpers.py:68-135 vs index.py:229-277)."""
+    import ctypes
+    from mocap_core import capi, helpers, synth
+    rig = synth.ring_rig(8)
+    obs, _ = synth.make_ba_observations(rig, 1000, seed=7)
+    init = synth.perturb_rig(rig, np.random.default_rng(7))
+    ba = capi.MocapCore(core.device_id)
+    try:
+        ba.set_cameras(rig["K"], init["R"], init["t"])
+        helpers.set_camera_params([{"intrinsic_matrix": k.tolist()} for k in rig["K"]])
+        x0 = helpers._ba_x0([{"R": init["R"][i], "t": init["t"][i]} for i in range(8)])
+        X = np.ascontiguousarray(np.repeat(x0[None, :], 51, axis=0))
+        obs_c = np.ascontiguousarray(obs, dtype=np.float64)
+        r = np.empty((51, obs_c.shape[0]))
+        fa = ba.lib.mocap_ba_residuals
+        a_args = (ba._h, 51, capi._p(X), obs_c.shape[0], capi._p(obs_c), capi._p(r))
+        assert fa(*a_args) == 0
+
+        def ba_call():
+            assert fa(*a_args) == 0
+
+        lat, n_ba = _raw_two_thread_latency(core, ba_call)
+    finally:
+        ba.close()
+    p50, p99 = lat[len(lat) // 2], lat[int(len(lat) * 0.99)]
+    print(f"raw ctypes: {len(lat)} frame calls next to {n_ba} batched residual evaluations: p50 {p50:.3f} ms p99 {p99:.3f} ms "
+          f"max {lat[-1]:.3f} ms")
+    assert n_ba > 100 and len(lat) > 1000
+    assert p99 < 0.5 and lat[-2] < 2.0, (p50, p99, lat[-3:])
+
+
+def test_frame_calls_next_to_the_resident_solver(core):
+    """The same with mode "resident" on the other context: mocap_ba_solve keeps a launched-ahead linearisation kernel
+    spinning on its mailbox (device watchdog: 2 s) while frame kernels from this context share the GPU.  The solves must
+    keep converging to the same answer, none of them through a relaunch, and the frame calls keep their latency."""
+    from mocap_core import capi, helpers, synth
+    rig = synth.ring_rig(8)
+    obs, _ = synth.make_ba_observations(rig, 1000, seed=7)
+    init = synth.perturb_rig(rig, np.random.default_rng(7))
+    ba = capi.MocapCore(core.device_id)
+    try:
+        ba.set_cameras(rig["K"], init["R"], init["t"])
+        helpers.set_camera_params([{"intrinsic_matrix": k.tolist()} for k in rig["K"]])
+        x0 = helpers._ba_x0([{"R": init["R"][i], "t": init["t"][i]} for i in range(8)])
+        x_alone, info_alone = ba.ba_solve(x0, obs, ftol=1e-2)
+        seen = []
+
+        def ba_call():
+            x, info = ba.ba_solve(x0, obs, ftol=1e-2)
+            seen.append((x, info))
+
+        lat, n_ba = _raw_two_thread_latency(core, ba_call)
+    finally:
+        ba.close()
+    p50, p99 = lat[len(lat) // 2], lat[int(len(lat) * 0.99)]
+    relaunches = sum(int(i.get("relaunches", 0)) for _, i in seen)
+    print(f"resident solver next to {len(lat)} frame calls: {n_ba} solves, {relaunches} relaunched linearisations; frame p50 {p50:.3f} ms "
+          f"p99 {p99:.3f} ms max {lat[-1]:.3f} ms")
+    assert n_ba >= 5
+    for x, info in seen:
+        assert int(info["status"]) == int(info_alone["status"]) and np.array_equal(x, x_alone)
+    assert relaunches == 0
+    assert p99 < 1.0 and lat[-2] < 5.0, (p50, p99, lat[-3:])

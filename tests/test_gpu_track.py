@@ -228,3 +228,157 @@ def test_track_frame_without_object_search_takes_more_than_256_points(core):
         assert np.array_equal(one[key][valid], sep[key][valid]), key
     with pytest.raises(Exception, match="256"):
         core.track_frame(blobs, counts, K_max=K, O_max=4)                                # with the search on: refused, not overrun
+
+
+# ----------------------------------------------------------------------------- re-submit on the device (round 5)
+def _dev_call(core, fn, blobs, counts, gate, K, G_cap, with_info=True):
+    """Run a _dev frame entry point on torch buffers; returns numpy copies after a synchronise."""
+    import torch
+    dev = torch.device("cuda", 0)
+    F, C, M, _ = blobs.shape
+    d_b, d_c = torch.from_numpy(blobs).to(dev), torch.from_numpy(counts).to(dev)
+    o = dict(xyz=torch.full((F, K, 3), float("nan"), dtype=torch.float64, device=dev),
+             err=torch.full((F, K), float("nan"), dtype=torch.float64, device=dev),
+             corr=torch.full((F, K, C), -1, dtype=torch.int16, device=dev), n_out=torch.zeros(F, dtype=torch.int32, device=dev),
+             status=torch.zeros(F, dtype=torch.int32, device=dev), n_cand=torch.zeros(F, dtype=torch.int32, device=dev),
+             info=torch.full((2,), -1, dtype=torch.int32, device=dev))
+    torch.cuda.synchronize(dev)
+    extra = (o["info"].data_ptr(),) if with_info else ()
+    fn(F, M, d_b.data_ptr(), d_c.data_ptr(), gate, K, G_cap, o["xyz"].data_ptr(), o["err"].data_ptr(), o["corr"].data_ptr(),
+       o["n_out"].data_ptr(), o["status"].data_ptr(), o["n_cand"].data_ptr(), *extra)
+    core.synchronize()
+    return {k: v.cpu().numpy() for k, v in o.items()}
+
+
+def test_device_side_resubmit_equals_an_uncapped_run(core):
+    """mocap_match_triangulate_dev_auto: frames over the candidate cap are gathered, re-run with the largest caps and
+    scattered back ON THE DEVICE (no host wait): afterwards the batch equals, bit for bit, a run whose caps were large
+    from the start -- the reference has no caps at all (helpers.py:394-400).  The plain _dev entry leaves them flagged."""
+    from mocap_core import capi, synth
+    rig = synth.ring_rig(8)
+    blobs, counts, _ = synth.make_blob_stream(rig, 3000, 16, seed=3)
+    core.set_cameras(rig["K"], rig["R"], rig["t"])
+    want = core.match_triangulate(blobs, counts, K_max=64, G_cap=1 << 24)
+    assert not want["status"].any()
+    plain = _dev_call(core, core.match_triangulate_dev, blobs, counts, 5.0, 64, 64, with_info=False)
+    n_flag = int(np.count_nonzero(plain["status"]))
+    assert n_flag > 20 and ((plain["status"] & capi.ST_CAND_OVERFLOW) != 0).sum() == n_flag and not plain["n_out"][plain["status"] != 0].any()
+    got = _dev_call(core, core.match_triangulate_dev_auto, blobs, counts, 5.0, 64, 64)
+    assert got["info"].tolist() == [n_flag, n_flag]
+    assert not got["status"].any() and np.array_equal(got["n_out"], want["n_out"]) and np.array_equal(got["n_cand"], want["n_cand"])
+    valid = np.arange(64)[None, :] < want["n_out"][:, None]
+    for key in ("xyz", "err", "corr"):
+        assert np.array_equal(got[key][valid], want[key][valid]), key
+    assert np.isnan(got["xyz"][~valid]).all()                    # nothing written beyond the valid slots
+    # nothing flagged: the three extra enqueues find an empty list
+    clean = _dev_call(core, core.match_triangulate_dev_auto, blobs, counts, 5.0, 64, 1 << 24)
+    assert clean["info"].tolist() == [0, 0] and np.array_equal(clean["xyz"][valid], want["xyz"][valid])
+    # twice in a row (the two alternating device counters), the second time flagged again
+    again = _dev_call(core, core.match_triangulate_dev_auto, blobs, counts, 5.0, 64, 64)
+    assert again["info"].tolist() == [n_flag, n_flag] and np.array_equal(again["xyz"][valid], want["xyz"][valid])
+
+
+def test_device_side_resubmit_root_capacity(core):
+    """Root capacity: K_max = 14 on 16-marker frames with 60 % dropout -- many frames have more ROOTS than slots (single-view
+    blobs are roots that yield no point).  The second pass runs with C * M root slots in scratch: frames whose POINTS fit
+    K_max come back complete, the others report ROOT_OVERFLOW and how many slots they need (n_out > K_max; nothing of
+    them is written, consumers count them as empty)."""
+    from mocap_core import capi, synth
+    from mocap_core import dist as mdist
+    rig = synth.ring_rig(8)
+    blobs, counts, _ = synth.make_blob_stream(rig, 400, 16, seed=13, dropout=0.6)
+    core.set_cameras(rig["K"], rig["R"], rig["t"])
+    want = core.match_triangulate(blobs, counts, K_max=128, G_cap=1 << 24)
+    K = 14
+    plain = _dev_call(core, core.match_triangulate_dev, blobs, counts, 5.0, K, 1 << 20, with_info=False)
+    flagged = (plain["status"] & capi.ST_ROOT_OVERFLOW) != 0
+    fits = want["n_out"] <= K
+    assert (flagged & fits).sum() > 50 and (flagged & ~fits).sum() > 50 and (~flagged).sum() > 20    # (C oracle: 106 / 233 / 61)
+    assert not (~flagged & ~fits).any()
+    got = _dev_call(core, core.match_triangulate_dev_auto, blobs, counts, 5.0, K, 1 << 20)
+    assert got["info"].tolist() == [int(flagged.sum())] * 2
+    assert np.array_equal(got["n_out"], want["n_out"])
+    assert not got["status"][fits].any() and (got["status"][~fits] == capi.ST_ROOT_OVERFLOW).all()
+    valid = (np.arange(K)[None, :] < want["n_out"][:, None]) & fits[:, None]
+    for key in ("xyz", "err", "corr"):
+        assert np.array_equal(got[key][valid], want[key][:, :K][valid]), key
+    assert np.isnan(got["xyz"][~fits]).all()                     # frames that need more slots: untouched
+    # downstream consumers treat n_out > K_max as "no valid slot"
+    rec, offsets = mdist.compact_tracks_reference(got["n_out"], got["xyz"], got["err"], got["corr"])
+    assert offsets[-1] == int(want["n_out"][fits].sum()) == rec.shape[0]
+    # the host-buffer form: the same, and the binding grows K_max to what the core says the frames need
+    auto = core.match_triangulate_auto(blobs, counts, K_max=K)
+    kk = int(want["n_out"].max())
+    assert auto["xyz"].shape[1] == kk and not auto["status"].any() and np.array_equal(auto["n_out"], want["n_out"])
+    vk = np.arange(kk)[None, :] < want["n_out"][:, None]
+    assert np.array_equal(auto["xyz"][vk], want["xyz"][:, :kk][vk]) and np.array_equal(auto["corr"][vk], want["corr"][:, :kk][vk])
+    # the live call: roots > K_max, points <= K_max: repaired in place ...
+    g = int(np.nonzero(flagged & fits & (want["n_out"] > 0))[0][0])
+    live = core.track_frame(blobs[g:g + 1], counts[g:g + 1], K_max=K, O_max=0)
+    k = int(want["n_out"][g])
+    assert int(live["status"][0]) == 0 and live["xyz"].shape[1] == K and np.array_equal(live["xyz"][0, :k], want["xyz"][g, :k])
+    # ... points > K_max: the core says how many, the binding calls again with that
+    f = int(np.nonzero(~fits)[0][0])
+    live = core.track_frame(blobs[f:f + 1], counts[f:f + 1], K_max=K, O_max=0)
+    k = int(want["n_out"][f])
+    assert int(live["status"][0]) == 0 and int(live["n_pts"][0]) == k and live["xyz"].shape[1] == k
+    assert np.array_equal(live["xyz"][0, :k], want["xyz"][f, :k])
+
+
+def test_device_side_resubmit_at_the_stress_shape_and_scratch_budget(core, monkeypatch):
+    """64 cameras x 256 blobs through the wide variant: candidate-cap overflow repaired on the device = the host-buffer
+    re-submit.  Then with a scratch budget that holds only a few frames: the frames that did not fit keep their status,
+    the counters say so (flagged > re-run), and a second call with the default budget repairs them."""
+    from mocap_core import capi, synth
+    rig = synth.stress_rig(64)
+    blobs, counts, _ = synth.make_stress_stream(rig, 10, 256, seed=31)
+    core.set_cameras(rig["K"], rig["R"], rig["t"])
+    gate = synth.STRESS_GATE_PX
+    auto = core.match_triangulate_auto(blobs, counts, gate_px=gate, K_max=384, G_cap=2)
+    assert auto["resubmitted"] == 10
+    got = _dev_call(core, core.match_triangulate_dev_auto, blobs, counts, gate, 384, 2)
+    assert core.last_frame_kernel() == "frame_kernel<1024, wide>"
+    assert got["info"].tolist() == [10, 10] and np.array_equal(got["status"], auto["status"]) and np.array_equal(got["n_out"], auto["n_out"])
+    ok = auto["status"] == 0
+    assert ok.sum() >= 8
+    valid = (np.arange(384)[None, :] < auto["n_out"][:, None]) & ok[:, None]
+    for key in ("xyz", "err", "corr"):
+        assert np.array_equal(got[key][valid], auto[key][valid]), key
+    monkeypatch.setenv("MOCAP_RESUBMIT_SCRATCH_MB", "1")          # ~ 3 frames of this shape
+    part = _dev_call(core, core.match_triangulate_dev_auto, blobs, counts, gate, 384, 2)
+    flagged, rerun = part["info"].tolist()
+    assert flagged == 10 and 1 <= rerun < 10
+    left = (part["status"] & capi.ST_CAND_OVERFLOW) != 0
+    assert 10 - rerun <= left.sum() <= 10 - rerun + (~ok).sum() and not part["n_out"][left].any()
+    done = ~left & ok
+    v2 = (np.arange(384)[None, :] < auto["n_out"][:, None]) & done[:, None]
+    assert np.array_equal(part["xyz"][v2], auto["xyz"][v2])
+
+
+def test_track_frame_dev_resubmits_before_the_object_search(core):
+    """mocap_track_frame_dev: frame kernel -> device-side re-submit -> locate_objects, all queued; equal to the same call
+    with caps that never bind."""
+    import torch
+    from mocap_core import synth
+    rig = synth.ring_rig(8)
+    blobs, counts, _ = synth.make_blob_stream(rig, 500, 16, seed=3)
+    core.set_cameras(rig["K"], rig["R"], rig["t"])
+    dev = torch.device("cuda", 0)
+    F, C, M, K, O = 500, 8, 16, 64, 4
+    d_b, d_c = torch.from_numpy(blobs).to(dev), torch.from_numpy(counts).to(dev)
+    outs = {}
+    for G in (1 << 24, 64):
+        o = dict(xyz=torch.zeros((F, K, 3), dtype=torch.float64, device=dev), err=torch.zeros((F, K), dtype=torch.float64, device=dev),
+                 corr=torch.zeros((F, K, C), dtype=torch.int16, device=dev), n=torch.zeros(F, dtype=torch.int32, device=dev),
+                 st=torch.zeros(F, dtype=torch.int32, device=dev), pos=torch.zeros((F, O, 3), dtype=torch.float64, device=dev),
+                 head=torch.zeros((F, O), dtype=torch.float64, device=dev), oerr=torch.zeros((F, O), dtype=torch.float64, device=dev),
+                 drone=torch.zeros((F, O), dtype=torch.int32, device=dev), nobj=torch.zeros(F, dtype=torch.int32, device=dev))
+        core.track_frame_dev(F, M, d_b.data_ptr(), d_c.data_ptr(), 5.0, K, G, o["xyz"].data_ptr(), o["err"].data_ptr(),
+                             o["corr"].data_ptr(), o["n"].data_ptr(), o["st"].data_ptr(), O, o["pos"].data_ptr(), o["head"].data_ptr(),
+                             o["oerr"].data_ptr(), o["drone"].data_ptr(), o["nobj"].data_ptr())
+        core.synchronize()
+        outs[G] = {k: v.cpu().numpy() for k, v in o.items()}
+    a, b = outs[1 << 24], outs[64]
+    assert not a["st"].any() and not b["st"].any() and np.array_equal(a["n"], b["n"]) and np.array_equal(a["nobj"], b["nobj"])
+    valid = np.arange(K)[None, :] < a["n"][:, None]
+    assert np.array_equal(a["xyz"][valid], b["xyz"][valid]) and np.array_equal(a["corr"][valid], b["corr"][valid])
