@@ -140,6 +140,23 @@ def cpu_baseline(rig, blobs, counts, budget_s=15.0, gpu=None):
     dt = time.perf_counter() - t0
     out = {"value": pts / dt, "unit": "markers/s", "cores": 1, "kind": "port",
            "sample": f"first {done} frames of the bench batch, C restatement (oracle/c), 1 thread, {dt:.1f}s"}
+    # what "port" is worth against the reference itself: measured once where /root/reference exists (the build container),
+    # same frames, one thread each (scripts/calibrate_cpu_baseline.py -> profiles/r05_cpu_baseline_calibration.json)
+    try:
+        with open(os.path.join(ROOT, "profiles", "r05_cpu_baseline_calibration.json")) as f:
+            cal = json.load(f)
+    except Exception:
+        cal = None
+    if cal:
+        k = cal["c_port"]["speed_vs_reference"]
+        out["sample"] += (f"; calibration (profiles/r05_cpu_baseline_calibration.json, build container, 1 thread): this C port runs "
+                          f"{k:.0f} x the reference's own find_point_correspondance_and_object_points on the same frames "
+                          f"(reference {cal['reference']['markers_per_s']:.1f}, Python port {cal['python_port']['markers_per_s']:.1f}, "
+                          f"C port {cal['c_port']['markers_per_s']:.0f} markers/s there)")
+        out["calibration"] = {"c_port_speed_vs_reference": k, "python_port_speed_vs_reference": cal["python_port"]["speed_vs_reference"],
+                              "reference_markers_per_s_build_container": cal["reference"]["markers_per_s"],
+                              "reference_equivalent_markers_per_s_this_core": (pts / dt) / k,
+                              "source": "profiles/r05_cpu_baseline_calibration.json"}
     # the same port frame-sharded over every host core (the reference itself is single-threaded; this is
     # the "whole box" figure SURVEY 8d asks for): one thread per core, ctypes releases the GIL in the C call
     try:
@@ -534,17 +551,21 @@ def ba_bench(core, iters=200, cpu=True):
         for _ in range(3):
             t0 = time.perf_counter()
             _, dinfo = helpers.bundle_adjustment(ref_obs, [dict(p) for p in poses0], None, return_info=True)
-            d_runs.append(time.perf_counter() - t0)
-    d_dt = sorted(d_runs)[1]
+            d_runs.append((time.perf_counter() - t0, float(dinfo.get("core_s", 0.0))))
+    d_dt, d_core = sorted(d_runs)[1]
     default_mode = {"mode": helpers.DEFAULT_BA_MODE, "measured_mode": "scipy", "wall_s": d_dt, "njev": int(dinfo["njev"]),
                     "nfev": int(dinfo["nfev"]), "iterations_per_s": dinfo["njev"] / d_dt,
                     "residual_evaluations_per_s": (dinfo["nfev"] + dinfo["njev"] * x0.size) / d_dt,
-                    "runs_s": [round(r, 4) for r in d_runs], "statistic": "median of 3 solves after one untimed",
+                    "runs_s": [round(r[0], 4) for r in d_runs], "statistic": "median of 3 solves after one untimed",
+                    "inside_core_calls_s": d_core, "scipy_own_s": d_dt - d_core,
                     "note": "the seam's default: scipy.optimize.least_squares drives; a trial point is one mocap_ba_residuals "
                             "call, a Jacobian is ONE call too (jac= callable: the n perturbed parameter vectors of scipy's "
                             "2-point rule as a batch, J formed with scipy's own float32-difference / float64-quotient "
                             "expressions: same bits as the reference's n + 1 separate evaluations); `value` above is mode "
-                            "\"resident\" (mocap_ba_solve), opt-in via helpers.set_bundle_adjustment_mode"}
+                            "\"resident\" (mocap_ba_solve), opt-in via helpers.set_bundle_adjustment_mode.  inside_core_calls_s = wall time spent "
+                            "inside mocap_ba_residuals (marshalling, GPU, copy back); scipy_own_s = the rest: SciPy's own "
+                            "per-iteration work on the host (SVD of the m x n Jacobian, Cauchy scaling, the step) which "
+                            "bit-identical poses oblige this mode to keep"}
     return {"metric": "BA iters/sec (8 cams, 1k pts)", "value": info["iterations"] / dt, "measured_mode": "resident",
             "default_mode": default_mode, "roofline": roofline,
             "cpu_baseline": out_cpu, "parity": ba_parity(core),

@@ -20,6 +20,7 @@ here `set_camera_params()` takes the same list of {"intrinsic_matrix": 3x3, ...}
 """
 import os
 import threading
+import time
 
 import numpy as np
 
@@ -492,9 +493,12 @@ def bundle_adjustment(image_points, camera_poses, socketio, return_info=False):
             from scipy.optimize._numdiff import _compute_absolute_step
 
             last = {"x": None, "r": None}
+            spent = {"core_s": 0.0}                             # wall time inside the core's calls (the rest is SciPy's own)
 
             def residual_function(params):
+                t0 = time.perf_counter()
                 r = core.ba_residuals(params, obs)[0]
+                spent["core_s"] += time.perf_counter() - t0
                 emit(params)                                    # helpers.py:274
                 r = r[~np.isnan(r)].astype(np.float32)          # helpers.py:273
                 last["x"], last["r"] = np.array(params, dtype=np.float64), r
@@ -522,7 +526,9 @@ def bundle_adjustment(image_points, camera_poses, socketio, return_info=False):
                 idx = np.arange(x0_.size)
                 X[first + idx, idx] = x0_ + h                   # x1[i] += h[i]
                 dx = X[first + idx, idx] - x0_                  # "recompute dx as exactly representable number"
+                t0 = time.perf_counter()
                 R = core.ba_residuals(X, obs)
+                spent["core_s"] += time.perf_counter() - t0
                 if f0 is None:
                     f0 = R[0][~np.isnan(R[0])].astype(np.float32)
                 J_T = np.empty((x0_.size, f0.size))
@@ -537,7 +543,7 @@ def bundle_adjustment(image_points, camera_poses, socketio, return_info=False):
             res = optimize.least_squares(residual_function, x0, jac=jacobian if use_batched else "2-point", verbose=0,
                                          loss="cauchy", ftol=1e-2)
             x, info = res.x, {"iterations": res.njev, "njev": res.njev, "nfev": res.nfev, "status": res.status,
-                       "cost": res.cost, "optimality": res.optimality}
+                       "cost": res.cost, "optimality": res.optimality, "core_s": spent["core_s"]}
     poses = _params_to_camera_poses(x)
     if socketio is not None:
         socketio.emit("camera-pose", {"camera_poses": camera_pose_to_serializable(poses)})
