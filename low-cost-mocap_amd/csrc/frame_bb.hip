@@ -52,6 +52,14 @@
 #ifndef MOCAP_BB_DEBUG_SKIP
 #define MOCAP_BB_DEBUG_SKIP 0
 #endif
+// round 5 (bit-identical by construction, each switchable for A/B timing): the offset inside a block decoded with the
+// correction-free small division; absent cameras add a record of zeros instead of sitting in an exec-mask region
+#ifndef MOCAP_BB_TINYDIV
+#define MOCAP_BB_TINYDIV 1
+#endif
+#ifndef MOCAP_BB_ZSLOT
+#define MOCAP_BB_ZSLOT 1
+#endif
 
 namespace mocap {
 
@@ -82,7 +90,7 @@ struct BBLayout {
     bxy = take(sizeof(float2) * (size_t)C * M, 16);
     bxy_nx = take(sizeof(float2) * (size_t)C * M, 16);  // the NEXT frame's blobs land here while this one is searched
     cnt_nx = take(4 * (size_t)C, 4);
-    bt = take(sizeof(double) * 10 * (size_t)C * M, 16);      // DLT contribution per (camera, blob): five b128 reads
+    bt = take(sizeof(double) * 10 * ((size_t)C * M + 1), 16);  // DLT contribution per (camera, blob): five b128 reads; + one record of zeros ("camera not in the group")
     rbound = take(8 * (size_t)R, 8);
     claimw = take(8 * (size_t)C, 8);
     // the search's block records and result slots: dead while matching -> phase B keeps the speculative epipolar
@@ -845,17 +853,35 @@ struct BBState {
             for (int k = 0; k < CW; k++) pk.w[k] = rpk[(size_t)lo * CW + k];
             const uint8_t* a = act + (size_t)r * C;
             const int nl = bnl[r];
-            for (int k = 0; k < nl; k++) {  // the block's open digits
+            for (int k = 0; k < nl; k++) {  // the block's open digits (rem < pl < 2^13, hit counts <= 64: divmod_tiny is exact)
               const int c = a[k];
               uint32_t qd, dgt;
+#if MOCAP_BB_TINYDIV
+              divmod_tiny(rem, nh[(size_t)r * C + c], qd, dgt);
+#else
               divmod_small(rem, nh[(size_t)r * C + c], qd, dgt);
+#endif
               rem = qd;
               pk.set(c, hits[((size_t)r * C + c) * M + dgt]);
             }
             double B[10];
-            int v = 0;
 #pragma unroll
             for (int ee = 0; ee < 10; ee++) B[ee] = 0.0;
+#if MOCAP_BB_ZSLOT
+            // cameras in ascending order: the one canonical rounding of B.  A camera that is not in the group adds the table's
+            // record of zeros: x + (+0.0) = x for every x the sum can hold (it starts at +0.0, so it is never -0.0) -- the same
+            // bits without a save-exec / branch / restore around every camera.  The views are the root's (every candidate of
+            // a root has the same cameras).
+            const int v = bv[r];
+#pragma unroll CT > 0 ? CT : 1
+            for (int c = 0; c < C; c++) {
+              const uint32_t k = pk.get(c);
+              const double* t = bt + (size_t)(k != 0xFFu ? (uint32_t)c * (uint32_t)M + k : (uint32_t)C * (uint32_t)M) * 10;
+#pragma unroll
+              for (int ee = 0; ee < 10; ee++) B[ee] = B[ee] + t[ee];
+            }
+#else
+            int v = 0;
 #pragma unroll CT > 0 ? CT : 1
             for (int c = 0; c < C; c++) {  // cameras in ascending order: the one canonical rounding of B
               const uint32_t k = pk.get(c);
@@ -866,6 +892,7 @@ struct BBState {
                 v++;
               }
             }
+#endif
             auto obs_p = [&](int c, double& x, double& y) -> bool {
               const uint32_t k = pk.get(c);
               if (k == 0xFFu) return false;
@@ -1052,6 +1079,7 @@ __global__ __launch_bounds__(kBBThreads, MOCAP_BB_WAVES_PER_EU) void frame_bb_ke
     const int it = q_add(&q.counters[QC_NEXT_FRAME], 1);
     st.misc[MI_ITEM] = it < frame_count(p) ? it : -1;
   }
+  if (tid < 10) st.bt[(size_t)st.cn() * st.M * 10 + tid] = 0.0;  // the table's record of zeros (never overwritten)
   __syncthreads();
   int item = st.misc[MI_ITEM];
   if (item >= 0) st.prefetch_lds(item);

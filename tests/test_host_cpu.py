@@ -273,3 +273,21 @@ def test_bundle_adjustment_mode_context_manager_restores_the_mode():
     except RuntimeError:
         pass
     assert helpers._state["ba_mode"] == "scipy"
+
+
+def test_divmod_tiny_is_exact_for_every_operand_the_block_decode_can_see():
+    """frame_common.hpp divmod_tiny: q = trunc(fma(float(rem), rcp(float(n)), 2^-8)) for rem < 2^13, n <= 64 (a candidate's
+    offset inside its block against a hit count, frame_bb.hip) -- the true quotient for every operand pair, also with the
+    hardware reciprocal (v_rcp_f32: 1 ulp) off by an ulp in either direction.  float64 holds rem * inv + 2^-8 exactly
+    (13 + 24 bits), so rounding it to float32 IS the fused multiply-add."""
+    rem = np.arange(1 << 13, dtype=np.int64)[:, None]
+    n = np.arange(1, 65, dtype=np.int64)[None, :]
+    inv0 = (np.float32(1.0) / n.astype(np.float32)).astype(np.float32)
+    for inv in (inv0, np.nextafter(inv0, np.float32(0)), np.nextafter(inv0, np.float32(2))):
+        q = (rem.astype(np.float64) * inv.astype(np.float64) + 2.0 ** -8).astype(np.float32).astype(np.int64)
+        assert np.array_equal(q, rem // n)
+    # the launch keeps the operands inside that range: block sizes are lowered until bb_pl * M_max < 2^13 (capi.hip), and
+    # the search kernel takes M_max <= 64 only (frame_bb_fits)
+    src = open(os.path.join(ROOT, "low-cost-mocap_amd", "csrc", "capi.hip")).read()
+    assert "(size_t)a.bb_pl * M_max * 2 * 256 >= ((size_t)1 << 22)" in src
+    assert "M <= 64" in open(os.path.join(ROOT, "low-cost-mocap_amd", "csrc", "frame_bb.hip")).read()
