@@ -54,6 +54,11 @@
 #endif
 // round 5 (bit-identical by construction, each switchable for A/B timing): the offset inside a block decoded with the
 // correction-free small division; absent cameras add a record of zeros instead of sitting in an exec-mask region
+// timing experiments only (same results, parts of the candidate evaluation run twice): bit 0 = the table sums, bit 1 = the
+// whole solve, bit 2 = the seed pass's block bounds; -DMOCAP_DEBUG_DOUBLE_REPROJECT: the reprojection pass
+#ifndef MOCAP_BB_DEBUG_DOUBLE
+#define MOCAP_BB_DEBUG_DOUBLE 0
+#endif
 #ifndef MOCAP_BB_TINYDIV
 #define MOCAP_BB_TINYDIV 1
 #endif
@@ -805,6 +810,17 @@ struct BBState {
           double s1d = __builtin_huge_val();  // a one-view partial group carries no information: never dropped, any seed
           float s1 = 0.0f;
           if (v >= 2) {
+#if MOCAP_BB_DEBUG_DOUBLE & 4
+            {
+              double B2[10], tr2;
+              Packed<CW> pk2;
+              uint32_t gh2 = gh;
+              asm volatile("" : "+v"(gh2));
+              group_matrix<true>(r, gh2, bnl[r], B2, pk2);
+              const double s2 = eigcut_s1_shifted(B2, c0, tr2);
+              asm volatile("" ::"v"(s2), "v"(tr2));
+            }
+#endif
             s1d = eigcut_s1_shifted(B, c0, tr);
             s1 = (float)fmin(s1d, 3e38);
           }
@@ -902,6 +918,37 @@ struct BBState {
               return true;
             };
             const double bound = __longlong_as_double((long long)rbound[r]);
+#if MOCAP_BB_DEBUG_DOUBLE & 1  // timing experiments only (same results): the table sums of a candidate once more
+            {
+              double B2[10];
+#pragma unroll
+              for (int ee = 0; ee < 10; ee++) B2[ee] = 0.0;
+              uint32_t w0 = (uint32_t)pk.w[0], w1 = (uint32_t)(pk.w[0] >> 32);
+              asm volatile("" : "+v"(w0), "+v"(w1));
+              const unsigned long long ww = ((unsigned long long)w1 << 32) | w0;
+#pragma unroll CT > 0 ? CT : 1
+              for (int c = 0; c < C; c++) {
+                const uint32_t k = (uint32_t)(ww >> (8 * (c & 7))) & 0xFFu;
+                const double* t = bt + (size_t)(k != 0xFFu ? (uint32_t)c * (uint32_t)M + k : (uint32_t)C * (uint32_t)M) * 10;
+#pragma unroll
+                for (int ee = 0; ee < 10; ee++) B2[ee] = B2[ee] + t[ee];
+              }
+#pragma unroll
+              for (int ee = 0; ee < 10; ee++) asm volatile("" ::"v"(B2[ee]));
+            }
+#endif
+#if MOCAP_BB_DEBUG_DOUBLE & 2  // ... the whole solve (factorisations, null vector, reprojection) once more
+            {
+              double B2[10], X2[3], e2 = inf;
+#pragma unroll
+              for (int ee = 0; ee < 10; ee++) {
+                B2[ee] = B[ee];
+                asm volatile("" : "+v"(B2[ee]));
+              }
+              solve_and_score<true, true, F32R, false>(cv, B2, v, obs_p, X2, e2, bound * (double)(2 * v) * (1.0 + 0x1p-40), ec);
+              asm volatile("" ::"v"(e2), "v"(X2[0]), "v"(X2[1]), "v"(X2[2]));
+            }
+#endif
             solve_and_score<true, true, F32R, false>(cv, B, v, obs_p, X, e, bound * (double)(2 * v) * (1.0 + 0x1p-40), ec);
 #ifdef MOCAP_DEBUG_EIGCHECK  // self-check build: a candidate whose evaluation was cut short must not beat the bound it was cut against
             if (!(e < inf)) {
