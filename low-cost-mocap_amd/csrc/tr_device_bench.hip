@@ -1,0 +1,219 @@
+// tr_device_bench.hip -- MEASUREMENT AID, not on the product path: what ONE wave needs for one value of the shift in the
+// trust-region subproblem's secular iteration at the metric's size (8 cameras: 42 live parameters) --
+//     L L^T = B + a I   (Cholesky),   L y = -g,   L^T p = y,   L w = p      (scipy solve_lsq_trust_region's phi, phi')
+// -- i.e. the unit of work a device-resident Levenberg-Marquardt loop would have to repeat 2-4 times per iteration instead
+// of handing the 42 x 42 system to the host (csrc/tr_host.cpp: 9.3 us for the WHOLE subproblem on one core).  DESIGN.md
+// 3.4 argued from an estimate (13-25 us per subproblem); this kernel is the measurement the round-4 verdict asked for.
+//
+// Layout (one wave, 64 lanes, lane i <-> row i): a row of the lower triangle in 42 VGPR pairs with compile-time indices
+// (fully unrolled right-looking factorisation: pivot row broadcast with v_readlane, one FMA per (column, lane)), the
+// transposed factor through LDS for the backward solve.  No other wave can help: the 42 pivots are a dependent chain.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <vector>
+#include <cmath>
+
+#include "ctx.hpp"
+#include "mocap_device.hpp"
+#include "../../include/mocap_core.h"
+
+#define HIP_TRY(ctx, expr)                                  \
+  do {                                                      \
+    hipError_t e__ = (expr);                                \
+    if (e__ != hipSuccess) return (ctx)->hip_fail(e__, #expr); \
+  } while (0)
+
+namespace mocap {
+
+constexpr int kTrN = 42;
+
+__device__ __forceinline__ double bcast(double v, int src) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readlane((int)(uint32_t)b, src);
+  const int hi = __builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), src);
+  return __longlong_as_double(((long long)hi << 32) | (uint32_t)lo);
+}
+
+// B [kTrN][kTrN] row-major, g [kTrN]; reps shifts a_k = a0 * (1 + k / 1024) one after the other (each one depends on the
+// previous result through `carry`, as the secular iteration's shifts do: nothing overlaps across repetitions);
+// out: p of the LAST shift [kTrN], then |p|^2, then p . (B + a I)^-1 p
+template <bool SOLVES>
+__global__ __launch_bounds__(64) void tr_wave_kernel(const double* __restrict__ B, const double* __restrict__ g, double a0, int reps,
+                                                     double* __restrict__ out) {
+  __shared__ double Lt[kTrN][kTrN + 1];  // the factor, transposed access for the backward solve
+  const int lane = threadIdx.x;
+  const int row = lane < kTrN ? lane : kTrN - 1;
+  double b[kTrN];
+#pragma unroll
+  for (int j = 0; j < kTrN; j++) b[j] = B[row * kTrN + j];
+  const double gi = lane < kTrN ? g[lane] : 0.0;
+  double carry = 0.0, p_last = 0.0, pn2 = 0.0, pw = 0.0;
+  for (int rep = 0; rep < reps; rep++) {
+    const double a = a0 * (1.0 + (double)rep * 0x1p-10) + carry * 0x1p-80;
+    double l[kTrN];
+#pragma unroll
+    for (int j = 0; j < kTrN; j++) l[j] = b[j];
+    // ---- right-looking Cholesky of B + a I, row i in lane i (entries j <= i are meaningful)
+#pragma unroll
+    for (int k = 0; k < kTrN; k++) {
+      if (lane == k) l[k] = l[k] + a;
+      const double dk = bcast(l[k], k);
+      const double r = rsqrt_pos(dk);
+      l[k] = l[k] * r;  // lanes i >= k: L[i][k];  lane k: sqrt(dk)
+#pragma unroll
+      for (int j = k + 1; j < kTrN; j++) {
+        const double ljk = bcast(l[k], j);
+        l[j] = fma(-l[k], ljk, l[j]);
+      }
+    }
+    if (SOLVES) {
+      // ---- L y = -g (lane i accumulates its own right-hand side; y_k leaves lane k in order)
+      double s = -gi, y = 0.0;
+      double invd = 1.0;
+#pragma unroll
+      for (int k = 0; k < kTrN; k++) {
+        const double dkk = bcast(l[k], k);
+        const double rk = recip_refined(dkk);
+        if (lane == k) invd = rk;
+        const double yk = bcast(s, k) * rk;
+        if (lane == k) y = yk;
+        s = fma(-l[k], yk, s);
+      }
+      // ---- the factor transposed through LDS: lane j then holds column j
+#pragma unroll
+      for (int j = 0; j < kTrN; j++)
+        if (lane < kTrN) Lt[j][lane] = l[j];  // Lt[j][i] = L[i][j]
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      double c[kTrN];  // c[i] = L[i][lane]
+#pragma unroll
+      for (int i = 0; i < kTrN; i++) c[i] = Lt[row][i];
+      // ---- L^T p = y: p_k = (y_k - sum_{i > k} L[i][k] p_i) / L[k][k]; lane k owns column k = the coefficients of p_k's row
+      double t = y, p = 0.0;
+#pragma unroll
+      for (int k = kTrN - 1; k >= 0; k--) {
+        const double pk = bcast(t, k) * bcast(invd, k);
+        if (lane == k) p = pk;
+        // t_j -= L[k][j] p_k for j < k: L[k][j] is element j of row k = element k of column j: c[k] in lane j
+        t = fma(-c[k], pk, t);
+      }
+      // ---- L w = p (phi' = -|w|^2 / |p|)
+      double s2 = p, w = 0.0;
+#pragma unroll
+      for (int k = 0; k < kTrN; k++) {
+        const double wk = bcast(s2, k) * bcast(invd, k);
+        if (lane == k) w = wk;
+        s2 = fma(-l[k], wk, s2);
+      }
+      double n2 = lane < kTrN ? p * p : 0.0, w2 = lane < kTrN ? w * w : 0.0;
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) {
+        n2 += __shfl_xor(n2, d);
+        w2 += __shfl_xor(w2, d);
+      }
+      carry = n2;
+      p_last = p;
+      pn2 = n2;
+      pw = w2;
+    } else {
+      carry = bcast(l[kTrN - 1], kTrN - 1);
+      p_last = l[0];
+    }
+  }
+  if (lane < kTrN) out[lane] = p_last;
+  if (lane == 0) {
+    out[kTrN] = pn2;
+    out[kTrN + 1] = pw;
+    out[kTrN + 2] = carry;
+  }
+}
+
+}  // namespace mocap
+
+// mocap_debug_tr_device_bench (include/mocap_core.h): times the kernel above on the context's stream with HIP events.
+//   us[0] = microseconds per factorisation alone, us[1] = per shift (factorisation + three triangular solves + norms),
+//   us[2] = max |p_device - p_host| / max |p_host| for the last shift (host: the same system in plain double loops).
+extern "C" int mocap_debug_tr_device_bench(mocap_ctx* ctx, int reps, double* us) {
+  using namespace mocap;
+  if (!ctx || !us || reps < 1) return MOCAP_E_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const int n = kTrN;
+  // a well-conditioned SPD system shaped like J^T J of the metric's problem: B = M^T M + I, g arbitrary
+  std::vector<double> M((size_t)n * n), B((size_t)n * n), g(n);
+  uint64_t st = 0x9E3779B97F4A7C15ull;
+  auto rnd = [&]() {
+    st ^= st << 13; st ^= st >> 7; st ^= st << 17;
+    return (double)(st >> 11) * (1.0 / 9007199254740992.0) - 0.5;
+  };
+  for (auto& v : M) v = rnd();
+  for (auto& v : g) v = rnd();
+  for (int i = 0; i < n; i++)
+    for (int j = 0; j < n; j++) {
+      double s = i == j ? 1.0 : 0.0;
+      for (int k = 0; k < n; k++) s += M[(size_t)k * n + i] * M[(size_t)k * n + j];
+      B[(size_t)i * n + j] = s;
+    }
+  const double a0 = 0.37;
+  double *dB = nullptr, *dg = nullptr, *dout = nullptr;
+  HIP_TRY(ctx, hipMalloc(&dB, sizeof(double) * n * n));
+  HIP_TRY(ctx, hipMalloc(&dg, sizeof(double) * n));
+  HIP_TRY(ctx, hipMalloc(&dout, sizeof(double) * (n + 3)));
+  HIP_TRY(ctx, hipMemcpy(dB, B.data(), sizeof(double) * n * n, hipMemcpyHostToDevice));
+  HIP_TRY(ctx, hipMemcpy(dg, g.data(), sizeof(double) * n, hipMemcpyHostToDevice));
+  hipEvent_t e0, e1;
+  HIP_TRY(ctx, hipEventCreate(&e0));
+  HIP_TRY(ctx, hipEventCreate(&e1));
+  float ms[2] = {0, 0};
+  for (int which = 0; which < 2; which++) {
+    for (int pass = 0; pass < 2; pass++) {  // the first pass warms the code object
+      HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
+      if (which == 0)
+        hipLaunchKernelGGL(tr_wave_kernel<false>, dim3(1), dim3(64), 0, ctx->stream, dB, dg, a0, reps, dout);
+      else
+        hipLaunchKernelGGL(tr_wave_kernel<true>, dim3(1), dim3(64), 0, ctx->stream, dB, dg, a0, reps, dout);
+      HIP_TRY(ctx, hipGetLastError());
+      HIP_TRY(ctx, hipEventRecord(e1, ctx->stream));
+      HIP_TRY(ctx, hipEventSynchronize(e1));
+      HIP_TRY(ctx, hipEventElapsedTime(&ms[which], e0, e1));
+    }
+  }
+  std::vector<double> out(n + 3);
+  HIP_TRY(ctx, hipMemcpy(out.data(), dout, sizeof(double) * (n + 3), hipMemcpyDeviceToHost));
+  (void)hipFree(dB); (void)hipFree(dg); (void)hipFree(dout);
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  // host check of the last shift: plain Cholesky + solves
+  const double a = a0 * (1.0 + (double)(reps - 1) * 0x1p-10);  // (carry * 2^-80 is below the last bit of a)
+  std::vector<double> L((size_t)n * n, 0.0), y(n), p(n);
+  for (int j = 0; j < n; j++) {
+    double d = B[(size_t)j * n + j] + a;
+    for (int k = 0; k < j; k++) d -= L[(size_t)j * n + k] * L[(size_t)j * n + k];
+    d = std::sqrt(d);
+    L[(size_t)j * n + j] = d;
+    for (int i = j + 1; i < n; i++) {
+      double s = B[(size_t)i * n + j];
+      for (int k = 0; k < j; k++) s -= L[(size_t)i * n + k] * L[(size_t)j * n + k];
+      L[(size_t)i * n + j] = s / d;
+    }
+  }
+  for (int i = 0; i < n; i++) {
+    double s = -g[i];
+    for (int k = 0; k < i; k++) s -= L[(size_t)i * n + k] * y[k];
+    y[i] = s / L[(size_t)i * n + i];
+  }
+  for (int i = n - 1; i >= 0; i--) {
+    double s = y[i];
+    for (int k = i + 1; k < n; k++) s -= L[(size_t)k * n + i] * p[k];
+    p[i] = s / L[(size_t)i * n + i];
+  }
+  double dev = 0.0, mx = 0.0;
+  for (int i = 0; i < n; i++) {
+    dev = std::fmax(dev, std::fabs(out[i] - p[i]));
+    mx = std::fmax(mx, std::fabs(p[i]));
+  }
+  us[0] = 1e3 * ms[0] / reps;
+  us[1] = 1e3 * ms[1] / reps;
+  us[2] = dev / mx;
+  return MOCAP_OK;
+}

@@ -52,7 +52,9 @@ def test_headline_kernel_budget(kernels):
     for rl in ("Li48E", "Li64E"):
         k = _find(kernels, "frame_bb_kernelILb1ELi1ELi8ELi16E" + rl)
         assert k["vgpr_count"] <= 128, k                      # 4 waves per SIMD
-        assert k["vgpr_spill_count"] <= 24 and k["private_segment_fixed_size"] <= 104, k   # round 3: 23 / 96-100 B, all outside the frame loop
+        # round 3: 23 / 96-100 B; round 5 (record of zeros + tiny division: 5.43 -> 5.28 ms): 26 / 108 B -- stored once before
+        # the frame loop (+ two stores in the output stage), reloaded at a handful of places per frame
+        assert k["vgpr_spill_count"] <= 26 and k["private_segment_fixed_size"] <= 108, k
         assert k["group_segment_fixed_size"] == 0, k          # LDS is dynamic: sized by frame_bb_lds_bytes for the launch
     general = _find(kernels, "frame_bb_kernelILb1ELi1ELi8ELi0ELi0E")
     assert general["vgpr_count"] <= 128 and general["vgpr_spill_count"] <= 48, general

@@ -648,3 +648,12 @@ def test_default_mode_batched_jacobian_is_scipys_own(core, name, monkeypatch):
     assert i1["cost"] == i0["cost"] and np.array_equal(R1, R0) and np.array_equal(t1, t0)
     n = 1 + 7 * (C - 1)
     assert e1 == e0 == i1["nfev"] + n * i1["njev"] + 1          # + the final poses (index.py:277)
+
+
+@pytest.mark.gpu
+def test_device_subproblem_microbench_solves_the_system(core):
+    """mocap_debug_tr_device_bench (measurement aid behind bench.py's ba.device_subproblem): the one-wave Cholesky +
+    triangular solves it times must actually solve (B + a I) p = -g -- against plain double loops on the host."""
+    r = core.tr_device_bench(reps=8)
+    assert r["p_max_rel_vs_host"] < 1e-11
+    assert 0.0 < r["us_per_factorisation"] < r["us_per_shift"] < 1e4
