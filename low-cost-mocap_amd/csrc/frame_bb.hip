@@ -59,6 +59,9 @@
 #ifndef MOCAP_BB_DEBUG_DOUBLE
 #define MOCAP_BB_DEBUG_DOUBLE 0
 #endif
+#ifndef MOCAP_BB_SPEC_COMPACT
+#define MOCAP_BB_SPEC_COMPACT 1  // speculative lines only for blobs the camera-0 roots left unclaimed
+#endif
 #ifndef MOCAP_BB_TINYDIV
 #define MOCAP_BB_TINYDIV 1
 #endif
@@ -524,6 +527,43 @@ struct BBState {
     double* sp_den = (double*)scr;
     float* sp_abc = (float*)(sp_den + NL);
     auto sp_base = [&](int j) { return M * ((j - 1) * (C - 1) - (j - 1) * j / 2); };  // lines of cameras 1 .. j-1
+#if MOCAP_BB_SPEC_COMPACT
+    // (round 5) ... but only of the blobs the camera-0 roots have NOT claimed: a claimed blob never becomes a root
+    // (helpers.py:402-406), and on the bench stream the camera-0 roots claim ~14 of every 16.  One more barrier (the claim
+    // words are complete behind it), then one lane per (unclaimed blob, later camera) pair: ~40 lines on one wave instead of
+    // 336 on all four (two passes).  The table keeps its layout, the chain its reads.
+    __syncthreads();
+    if (spec) {
+      int tot = 0;
+      for (int j = 1; j <= C - 2; j++) {
+        const int n = cnt[j];
+        const unsigned long long U = ~claimw[j] & (n >= 64 ? ~0ull : ((1ull << n) - 1ull));
+        tot += __popcll(U) * (C - 1 - j);
+      }
+      for (int l = tid; l < tot; l += T) {
+        int j = 1, acc = 0, span = C - 2;
+        unsigned long long U = 0ull;
+        for (; j <= C - 2; j++) {
+          const int n = cnt[j];
+          U = ~claimw[j] & (n >= 64 ? ~0ull : ((1ull << n) - 1ull));
+          span = C - 1 - j;
+          const int nj = __popcll(U) * span;
+          if (l < acc + nj) break;
+          acc += nj;
+        }
+        uint32_t ord, off;
+        divmod_tiny((uint32_t)(l - acc), (uint32_t)span, ord, off);  // (< 64 x 15, span <= 14)
+        for (uint32_t t = 0; t < ord; t++) U &= U - 1;
+        const int k = __ffsll((long long)U) - 1, i = j + 1 + (int)off;
+        const int ll = sp_base(j) + k * span + (int)off;
+        const Line L = epiline_of(j, k, i);
+        sp_den[ll] = L.den;
+        sp_abc[3 * ll + 0] = (float)L.a;
+        sp_abc[3 * ll + 1] = (float)L.b;
+        sp_abc[3 * ll + 2] = (float)L.c;
+      }
+    }
+#else
     if (spec) {
       for (int l = tid; l < NL; l += T) {
         int j = 1;
@@ -539,6 +579,7 @@ struct BBState {
         }
       }
     }
+#endif
     __syncthreads();
     if (wave == 0) {
       // B1: the chain over the cameras -- only the roots created on the way take part (camera-0 roots are done).
