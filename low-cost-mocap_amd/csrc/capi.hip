@@ -597,6 +597,12 @@ static int match_dev_locked(mocap_ctx* ctx, int64_t n_frames, int M_max, const f
   if (per_cu < 1) per_cu = 1;
   const int64_t full_grid = (int64_t)ctx->num_cus * per_cu;
   int64_t grid = full_grid < n_frames ? full_grid : n_frames;
+  if (use_bb && frame_bb_ws_bytes(ctx->C)) {
+    a.ws_stride = frame_bb_ws_bytes(ctx->C);
+    if (ctx->frame_ws.reserve((size_t)full_grid * a.ws_stride))
+      return ctx->fail(MOCAP_E_HIP, "hipMalloc(search workspace, %zu B) failed", (size_t)full_grid * a.ws_stride);
+    a.ws = (unsigned char*)ctx->frame_ws.ptr;
+  }
   if (wide) {
     a.ws_stride = frame_ws_bytes(ctx->C, M_max, K_max, T, hit_cap, true, false);
     if (ctx->frame_ws.reserve((size_t)full_grid * a.ws_stride))

@@ -59,6 +59,12 @@
 #ifndef MOCAP_BB_DEBUG_DOUBLE
 #define MOCAP_BB_DEBUG_DOUBLE 0
 #endif
+#ifndef MOCAP_BB_GM_ROLLED
+#define MOCAP_BB_GM_ROLLED 0  // group_matrix's camera loop kept rolled (code size: the kernel is 45 KB)
+#endif
+#ifndef MOCAP_BB_PROBE
+#define MOCAP_BB_PROBE 0  // seed blocks: one factorisation per candidate, the best one evaluated as the root's probe, the rest tested against it (measured: 5.27 -> 5.9-6.2 ms, see below; kept for the record, compiled out)
+#endif
 #ifndef MOCAP_BB_SPEC_COMPACT
 #define MOCAP_BB_SPEC_COMPACT 1  // speculative lines only for blobs the camera-0 roots left unclaimed
 #endif
@@ -694,26 +700,51 @@ struct BBState {
       nact[r] = (uint8_t)na;
       bv[r] = (uint8_t)views;
       rbound[r] = kInfBits;
-      gcnt[r] = (views > 1 && !over) ? (uint32_t)total : 0u;  // helpers.py:413-414 drops 1-view roots
+      const uint32_t g = (views > 1 && !over) ? (uint32_t)total : 0u;  // helpers.py:413-414 drops 1-view roots
+      gcnt[r] = g;
+      // the search's blocks of this root (phase D): the nl fastest digits stay open (pl >= bb_pl candidates per block), one
+      // block per value of the others.  Here rather than at the start of the search: the same lanes, no extra barrier pair.
+      {
+        const uint8_t* a = act + (size_t)r * C;
+        uint32_t pl = 1, nb = 1;
+        int nl = 0;
+        while (nl < na && pl < (uint32_t)p.bb_pl) pl *= nh[(size_t)r * C + a[nl++]];
+        for (int k = nl; k < na; k++) nb *= nh[(size_t)r * C + a[k]];
+        bpl[r] = (uint16_t)pl;
+        bnl[r] = (uint8_t)nl;
+        bnb[r] = g ? nb : 0u;
+        seedkey[r] = 0ull;  // (the speculative lines that lived here are dead: the chain is behind the barrier above)
+        seedgh[r] = 0xFFFFFFFFu;
+      }
     }
+    for (int s = tid; s < W * RS; s += T) {
+      slot_key[s] = ~0ull;
+      slot_g[s] = 0xFFFFFFFFu;
+    }
+    if (tid == 0) misc[MI_BBCTR] = misc[MI_BBCTR2] = 0;
     __syncthreads();
-    if (wave == 0) {  // candidate offsets and output slots: scans over the roots, 64 at a time (sums stay below 2^32: 255 x 2^24)
-      uint32_t carry = 0;
+    if (wave == 0) {  // candidate offsets, block offsets and output slots: scans over the roots, 64 at a time (sums stay below 2^32: 255 x 2^24)
+      uint32_t carry = 0, bcarry = 0;
       int slots = 0;
       for (int base = 0; base < nroots; base += 64) {
         const int r = base + lane;
         const uint32_t g = r < nroots ? gcnt[r] : 0u;
+        const uint32_t nb = r < nroots ? bnb[r] : 0u;
         const uint32_t incl = wave_inclusive_scan(g, lane);
+        const uint32_t bincl = wave_inclusive_scan(nb, lane);
         const unsigned long long nz = __ballot(g != 0u);
         if (r < nroots) {
           goff[r] = carry + incl - g;
+          boff[r] = bcarry + bincl - nb;
           outslot[r] = g ? slots + __popcll(nz & ((1ull << lane) - 1ull)) : -1;
         }
         carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        bcarry += (uint32_t)__builtin_amdgcn_readlane((int)bincl, 63);
         slots += __popcll(nz);
       }
       if (lane == 0) {
         goff[nroots] = carry;
+        boff[nroots] = bcarry;
         misc[MI_NOUT] = slots;
         misc[MI_G] = misc[MI_STATUS] ? 0 : (int32_t)carry;
       }
@@ -736,6 +767,9 @@ struct BBState {
 #pragma unroll
       for (int e = 0; e < 10; e++) B[e] = 0.0;
     }
+#if MOCAP_BB_GM_ROLLED
+#pragma nounroll
+#endif
     for (int c = 0; c < C; c++) {
       uint32_t k = 0xFFu;
       if (c == rc) {
@@ -767,10 +801,72 @@ struct BBState {
     return v;
   }
 
+  // Record r of the queue and candidate i of the expanded list -> the candidate's root, index, blob indices and DLT matrix
+  // (cameras in ascending order: the one canonical rounding of B; a camera that is not in the group adds the table's record
+  // of zeros: x + (+0.0) = x for every x the sum can hold -- it starts at +0.0, so it is never -0.0 -- the same bits
+  // without a save-exec / branch / restore around every camera).  Returns the views (the root's: every candidate of a root
+  // has the same cameras).
+  __device__ __forceinline__ int fetch_candidate(uint32_t lo, uint32_t i, int& r, uint32_t& gl, Packed<CW>& pk, double (&B)[10]) const {
+    const int C = cn();
+    const BRec rec = recs[lo];
+    r = (int)(rec.rs & 0xFFu);
+#pragma unroll
+    for (int k = 0; k < CW; k++) pk.w[k] = rpk[(size_t)lo * CW + k];
+    if (rec.rs >> 31) {
+      gl = rec.gh;  // a single candidate: its blob indices are complete
+    } else {
+      uint32_t rem = i - (rec.rs >> 8);
+      gl = rec.gh * (uint32_t)bpl[r] + rem;
+      const uint8_t* a = act + (size_t)r * C;
+      const int nl = bnl[r];
+      for (int k = 0; k < nl; k++) {  // the block's open digits (rem < pl < 2^13, hit counts <= 64: divmod_tiny is exact)
+        const int c = a[k];
+        uint32_t qd, dgt;
+#if MOCAP_BB_TINYDIV
+        divmod_tiny(rem, nh[(size_t)r * C + c], qd, dgt);
+#else
+        divmod_small(rem, nh[(size_t)r * C + c], qd, dgt);
+#endif
+        rem = qd;
+        pk.set(c, hits[((size_t)r * C + c) * M + dgt]);
+      }
+    }
+#pragma unroll
+    for (int ee = 0; ee < 10; ee++) B[ee] = 0.0;
+#if MOCAP_BB_ZSLOT
+#pragma unroll CT > 0 ? CT : 1
+    for (int c = 0; c < C; c++) {
+      const uint32_t k = pk.get(c);
+      const double* t = bt + (size_t)(k != 0xFFu ? (uint32_t)c * (uint32_t)M + k : (uint32_t)C * (uint32_t)M) * 10;
+#pragma unroll
+      for (int ee = 0; ee < 10; ee++) B[ee] = B[ee] + t[ee];
+    }
+    return bv[r];
+#else
+    int v = 0;
+#pragma unroll CT > 0 ? CT : 1
+    for (int c = 0; c < C; c++) {
+      const uint32_t k = pk.get(c);
+      if (k != 0xFFu) {
+        const double* t = bt + ((size_t)c * M + k) * 10;
+#pragma unroll
+        for (int ee = 0; ee < 10; ee++) B[ee] = B[ee] + t[ee];
+        v++;
+      }
+    }
+    return v;
+#endif
+  }
+
   __device__ void search(bool bound_tests) {
     const int C = cn();
+    (void)C;
     const int nroots = misc[MI_NROOTS];
-    int32_t* ctr = &misc[MI_BBCTR];  // queued blocks | their candidates << 10
+    // queued records | their candidates << 10.  Two words that take turns: a flush moves on to the other one (zero since the
+    // flush before), and lane 0 zeroes the one just used behind the round's barrier -- nobody touches it until the next
+    // flush has passed its own barrier: one barrier per evaluation round instead of two
+    int32_t* ctr = &misc[MI_BBCTR];
+    int32_t* ctr_other = &misc[MI_BBCTR2];
     const double inf = __builtin_huge_val();
     EigCut ec;
     {
@@ -779,38 +875,7 @@ struct BBState {
       ec.o2slack = (1100.0 * 0x1p-46) * (om * om);
     }
     const double c0[3] = {p.bb_c0[0], p.bb_c0[1], p.bb_c0[2]};  // origin of the frame the block bounds are taken in
-    const uint32_t PL = (uint32_t)p.bb_pl;
-    for (int r = tid; r < nroots; r += T) {
-      const uint8_t* a = act + (size_t)r * C;
-      const int na = nact[r];
-      uint32_t pl = 1, nb = 1;
-      int nl = 0;
-      while (nl < na && pl < PL) pl *= nh[(size_t)r * C + a[nl++]];
-      for (int k = nl; k < na; k++) nb *= nh[(size_t)r * C + a[k]];
-      bpl[r] = (uint16_t)pl;
-      bnl[r] = (uint8_t)nl;
-      bnb[r] = gcnt[r] ? nb : 0u;
-      seedkey[r] = 0ull;
-      seedgh[r] = 0xFFFFFFFFu;
-    }
-    for (int s = tid; s < W * RS; s += T) {
-      slot_key[s] = ~0ull;
-      slot_g[s] = 0xFFFFFFFFu;
-    }
-    if (tid == 0) *ctr = 0;
-    __syncthreads();
-    if (wave == 0) {
-      uint32_t carry = 0;
-      for (int base = 0; base < nroots; base += 64) {
-        const int r = base + lane;
-        const uint32_t g = r < nroots ? bnb[r] : 0u;
-        const uint32_t incl = wave_inclusive_scan(g, lane);
-        if (r < nroots) boff[r] = carry + incl - g;
-        carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-      }
-      if (lane == 0) boff[nroots] = carry;
-    }
-    __syncthreads();
+    // (blocks per root, their offsets, the result slots and the queue counters were set up with the candidate counts: match(), phase C)
     const uint32_t nblocks = boff[nroots];
     // root of block b0 + tid (consecutive blocks per wave): last root whose first block is <= b
     auto root_of_block = [&](uint32_t b_first_of_wave, uint32_t b) {
@@ -826,7 +891,21 @@ struct BBState {
 #pragma unroll
       for (int k = 0; k < CW; k++) rpk[(size_t)slot * CW + k] = pk.w[k];
     };
-    // EigCut's first test of a partial group of root r against the best error of the root so far
+#if MOCAP_BB_PROBE
+    // one candidate on its own (bit 31 of the record: gh IS the candidate index, the blob indices are complete)
+    auto push_single = [&](int r, uint32_t gl, const Packed<CW>& pk) {
+      const uint32_t old = (uint32_t)atomicAdd(ctr, (int32_t)((1u << 10) | 1u));
+      const uint32_t slot = old & 0x3FFu;
+      BRec rec;
+      rec.gh = gl;
+      rec.rs = (uint32_t)r | ((old >> 10) << 8) | 0x80000000u;
+      recs[slot] = rec;
+#pragma unroll
+      for (int k = 0; k < CW; k++) rpk[(size_t)slot * CW + k] = pk.w[k];
+    };
+#endif
+    auto rec_start = [&](int k) { return (recs[k].rs & 0x7FFFFFFFu) >> 8; };
+    // EigCut's first test of a (partial) group of root r against the best error of the root so far
     auto dropped = [&](int r, double s1, double tr) {
       const int vf = bv[r];
       const double bound = __longlong_as_double((long long)rbound[r]);
@@ -834,11 +913,57 @@ struct BBState {
       const double limit_adj = fma(1.002, limit, (double)(2 * vf) * ec.o2slack);
       return s1 * fma(2e-12, tr, p.p3max2c * limit_adj) < 1.0;
     };
+#if MOCAP_BB_PROBE
+    // ---- probe scheme (round 5): what a lane keeps of the seed blocks' candidates it looked at (kProbeHold per lane)
+    // across the evaluation of the probes
+    constexpr int kProbeHold = 2;
+    // ... parked in the workgroup's slice of a global workspace (L2-resident, [item][word][lane]: coalesced), not in registers:
+    // held across the probes' evaluation they cost the kernel 70 more spilled VGPRs, reloaded inside the evaluation
+    constexpr int kHoldWords = 4 + 2 * CW;  // candidate index, root (-1: none), s1, trace (floats, rounded up), blob indices
+    uint32_t* hold = (uint32_t*)(p.ws + (size_t)blockIdx.x * p.ws_stride);
+    auto hold_at = [&](int it, int w) -> uint32_t& { return hold[((size_t)it * kHoldWords + w) * T + tid]; };
+#endif
+    int stage = 0;  // 0: the plain loop; 1: the probes are queued (their flush comes first); 2: the second half of the seed tests is pending
+#if MOCAP_BB_PROBE
+    auto seed_test = [&](int it) {
+      const int r = (int)hold_at(it, 1);
+      if (r >= 0) {
+        const uint32_t probe = 0xFFFFFFFFu - (uint32_t)seedkey[r];
+        const uint32_t h_gl_ = hold_at(it, 0);
+        if (h_gl_ != probe) {
+          const bool drop = dropped(r, (double)__uint_as_float(hold_at(it, 2)), (double)__uint_as_float(hold_at(it, 3)));
+          if (!drop) {
+            Packed<CW> hpk;
+#pragma unroll
+            for (int k = 0; k < CW; k++) hpk.w[k] = ((unsigned long long)hold_at(it, 5 + 2 * k) << 32) | hold_at(it, 4 + 2 * k);
+            push_single(r, h_gl_, hpk);
+          }
+#ifdef MOCAP_DEBUG_EIGCHECK  // self-check build: a seed-block candidate dropped on its own bound is evaluated in full against it
+          if (drop) {
+            const double bound = __longlong_as_double((long long)rbound[r]);
+            double B2[10], X2[3], e2 = inf;
+            Packed<CW> pk2;
+            const int v2 = group_matrix<true>(r, h_gl_, 0, B2, pk2);
+            auto obs2 = [&](int c, double& x, double& y) -> bool {
+              const uint32_t k = pk2.get(c);
+              if (k == 0xFFu) return false;
+              const float2 w = bxy[(size_t)c * M + k];
+              x = (double)w.x;
+              y = (double)w.y;
+              return true;
+            };
+            solve_and_score<true, true, F32R>(cv, B2, v2, obs2, X2, e2);
+            atomicAdd(&p.status[p.n_frames + 1], 1);
+            if (e2 <= bound) printf("EIGCHECK seed candidate: root %d candidate %u bound %.17g true %.17g\n", r, h_gl_, bound, e2);
+          }
+#endif
+        }
+      }
+    };
+#endif
     if (bound_tests) {
       // ---- 1. seeds: s1 of every block (cached for the tests); per root the block with the largest s1 (smallest
-      // bound) is evaluated first.  (Measured and dropped, round 3: evaluating candidate 0 of every root -- the closest
-      // hit in every camera, usually the true match -- before the seeds, to have bounds for them: 6.2 -> 7.1 ms per
-      // 100 k frames; the sparse extra round costs more than the cheaper seed evaluations return.)
+      // bound) almost always holds the winner
       for (uint32_t s0 = 0; s0 < nblocks; s0 += T) {
         const uint32_t b = s0 + (uint32_t)tid;
         if (s0 + (uint32_t)(wave * 64) >= nblocks) continue;  // wave-uniform
@@ -874,6 +999,7 @@ struct BBState {
         if (bnb[r]) {
           const uint32_t gh = 0xFFFFFFFFu - (uint32_t)seedkey[r];
           seedgh[r] = gh;
+          seedkey[r] = 0ull;  // (next: the key of the root's probe)
           double B[10];
           Packed<CW> pk;
           group_matrix<false>(r, gh, bnl[r], B, pk);
@@ -881,75 +1007,100 @@ struct BBState {
         }
       }
       __syncthreads();
+#if MOCAP_BB_PROBE
+      // ---- 1b. probes (round 5).  Evaluating the seed blocks in full -- 16+ candidates per root with no bound to cut them
+      // short -- was 70 % of a frame's full evaluations.  Instead every candidate of the seed blocks takes only the table sums
+      // and ONE factorisation (s1 of its own matrix, the same bound the blocks are tested with); per root the candidate with
+      // the largest s1 -- the seed block's best in 98 % of the roots of the bench stream (scripts/model_probe.py) -- is
+      // evaluated in full (the probes: one dense round), and the others are tested against its error with the s1 they
+      // already have: the few that survive go to the queue as single candidates.  Nothing is dropped on anything but the
+      // bound every other cut of this file uses, so the results do not change by a bit (tests/test_gpu_bb_adversarial.py;
+      // the self-check build evaluates everything dropped here as well).  Frames with more seed candidates than the lanes
+      // can hold (kProbeHold per lane) keep the old order: their seed blocks are evaluated in full by the loop below.
+      {
+        const uint32_t cvs = (uint32_t)*ctr;
+        const uint32_t ns = cvs & 0x3FFu, ne = cvs >> 10;
+        if (ns && ne <= (uint32_t)(kProbeHold * T)) {  // (uniform)
+#pragma nounroll
+          for (int it = 0; it < kProbeHold; it++) {  // (one copy of the body: the kernel's code has to stay inside the instruction cache)
+            const uint32_t i0 = (uint32_t)(it * T), i = i0 + (uint32_t)tid;
+            const bool have = i < ne;
+            uint32_t lo = 0;
+            if (i0 + (uint32_t)(wave * 64) < ne)  // wave-uniform
+              lo = (uint32_t)coop_last_le(rec_start, (int)ns, i0 + (uint32_t)(wave * 64), have ? i : ne - 1, lane);
+            int r = -1;
+            uint32_t gl = 0;
+            float s1f = 0.f, trf = 0.f;
+            Packed<CW> pk;
+            pk.clear();
+            if (have) {
+              double B[10], tr = 0.0;
+              const int v = fetch_candidate(lo, i, r, gl, pk, B);
+              double s1d = __builtin_huge_val();
+              if (v >= 2) s1d = eigcut_s1_shifted(B, c0, tr);
+              s1f = __double2float_ru(s1d);  // rounded UP: a larger s1 or trace only ever keeps a candidate (safe side)
+              trf = __double2float_ru(tr);
+              atomicMax(&seedkey[r], ((unsigned long long)__float_as_uint((float)fmin(s1d, 3e38)) << 32) | (unsigned long long)(0xFFFFFFFFu - gl));
+            }
+            hold_at(it, 0) = gl;
+            hold_at(it, 1) = (uint32_t)r;
+            hold_at(it, 2) = __float_as_uint(s1f);
+            hold_at(it, 3) = __float_as_uint(trf);
+#pragma unroll
+            for (int k = 0; k < CW; k++) {
+              hold_at(it, 4 + 2 * k) = (uint32_t)pk.w[k];
+              hold_at(it, 5 + 2 * k) = (uint32_t)(pk.w[k] >> 32);
+            }
+          }
+          wait_own_stores();
+          __syncthreads();  // the seed blocks' records are consumed, the probes' keys complete
+          if (tid == 0) *ctr = 0;
+          {
+            int32_t* t = ctr;
+            ctr = ctr_other;
+            ctr_other = t;
+          }
+          // the probes go to the queue as single candidates, each from the lane that holds it
+#pragma nounroll
+          for (int it = 0; it < kProbeHold; it++) {
+            const int hr = (int)hold_at(it, 1);
+            const uint32_t hg = hold_at(it, 0);
+            if (hr >= 0 && hg == 0xFFFFFFFFu - (uint32_t)seedkey[hr]) {
+              Packed<CW> hpk;
+#pragma unroll
+              for (int k = 0; k < CW; k++) hpk.w[k] = ((unsigned long long)hold_at(it, 5 + 2 * k) << 32) | hold_at(it, 4 + 2 * k);
+              push_single(hr, hg, hpk);
+            }
+          }
+          __syncthreads();
+          stage = 1;
+        }
+      }
+#endif
     }
-    // ---- 2. the queued blocks' candidates (spread over all lanes, whatever root they belong to), then the next
+    // ---- 2. the queued records' candidates (spread over all lanes, whatever root they belong to), then the next
     // blocks' tests, until nothing is left
     uint32_t b0 = 0;
     while (true) {
       const uint32_t cv_ = (uint32_t)*ctr;
       const uint32_t ns = cv_ & 0x3FFu, ne = cv_ >> 10;
       const bool blocks_left = b0 < nblocks;
-      if (ns && (!blocks_left || ne >= (uint32_t)p.bb_flush || ns > (uint32_t)(kBBRecs - T))) {
+      const bool full = ns > (uint32_t)(kBBRecs - T);
+      if (ns && (stage == 1 || full || (stage == 0 && (!blocks_left || ne >= (uint32_t)p.bb_flush)))) {
         for (uint32_t i0 = 0; i0 < ne; i0 += T) {
           const uint32_t i = i0 + (uint32_t)tid;
           const bool have = i < ne;
           double e = inf, X[3] = {0, 0, 0};
           int r = 0;
           uint32_t gl = 0;
-          // the record (surviving block) that candidate i of the expanded list belongs to: last one starting at or before i
+          // the record that candidate i of the expanded list belongs to: last one starting at or before i
           uint32_t lo = 0;
           if (i0 + (uint32_t)(wave * 64) < ne)  // wave-uniform
-            lo = (uint32_t)coop_last_le([&](int k) { return recs[k].rs >> 8; }, (int)ns, i0 + (uint32_t)(wave * 64), have ? i : ne - 1, lane);
+            lo = (uint32_t)coop_last_le(rec_start, (int)ns, i0 + (uint32_t)(wave * 64), have ? i : ne - 1, lane);
           if (have) {
-            const BRec rec = recs[lo];
-            r = (int)(rec.rs & 0xFFu);
-            uint32_t rem = i - (rec.rs >> 8);
-            gl = rec.gh * (uint32_t)bpl[r] + rem;
             Packed<CW> pk;
-#pragma unroll
-            for (int k = 0; k < CW; k++) pk.w[k] = rpk[(size_t)lo * CW + k];
-            const uint8_t* a = act + (size_t)r * C;
-            const int nl = bnl[r];
-            for (int k = 0; k < nl; k++) {  // the block's open digits (rem < pl < 2^13, hit counts <= 64: divmod_tiny is exact)
-              const int c = a[k];
-              uint32_t qd, dgt;
-#if MOCAP_BB_TINYDIV
-              divmod_tiny(rem, nh[(size_t)r * C + c], qd, dgt);
-#else
-              divmod_small(rem, nh[(size_t)r * C + c], qd, dgt);
-#endif
-              rem = qd;
-              pk.set(c, hits[((size_t)r * C + c) * M + dgt]);
-            }
             double B[10];
-#pragma unroll
-            for (int ee = 0; ee < 10; ee++) B[ee] = 0.0;
-#if MOCAP_BB_ZSLOT
-            // cameras in ascending order: the one canonical rounding of B.  A camera that is not in the group adds the table's
-            // record of zeros: x + (+0.0) = x for every x the sum can hold (it starts at +0.0, so it is never -0.0) -- the same
-            // bits without a save-exec / branch / restore around every camera.  The views are the root's (every candidate of
-            // a root has the same cameras).
-            const int v = bv[r];
-#pragma unroll CT > 0 ? CT : 1
-            for (int c = 0; c < C; c++) {
-              const uint32_t k = pk.get(c);
-              const double* t = bt + (size_t)(k != 0xFFu ? (uint32_t)c * (uint32_t)M + k : (uint32_t)C * (uint32_t)M) * 10;
-#pragma unroll
-              for (int ee = 0; ee < 10; ee++) B[ee] = B[ee] + t[ee];
-            }
-#else
-            int v = 0;
-#pragma unroll CT > 0 ? CT : 1
-            for (int c = 0; c < C; c++) {  // cameras in ascending order: the one canonical rounding of B
-              const uint32_t k = pk.get(c);
-              if (k != 0xFFu) {
-                const double* t = bt + ((size_t)c * M + k) * 10;
-#pragma unroll
-                for (int ee = 0; ee < 10; ee++) B[ee] = B[ee] + t[ee];
-                v++;
-              }
-            }
-#endif
+            const int v = fetch_candidate(lo, i, r, gl, pk, B);
             auto obs_p = [&](int c, double& x, double& y) -> bool {
               const uint32_t k = pk.get(c);
               if (k == 0xFFu) return false;
@@ -1036,11 +1187,30 @@ struct BBState {
             wave_lds_sync();
           }
         }
-        __syncthreads();
+        __syncthreads();  // every lane is done with the records: new ones may be queued (through the other counter)
         if (tid == 0) *ctr = 0;
+        {
+          int32_t* t = ctr;
+          ctr = ctr_other;
+          ctr_other = t;
+        }
+#if MOCAP_BB_PROBE
+        if (stage == 1) {  // the probes have been evaluated: the seed blocks' other candidates against their errors (first half)
+          seed_test(0);
+          stage = 2;
+          __syncthreads();
+        }
+#endif
+        continue;
+      }
+#if MOCAP_BB_PROBE
+      if (stage == 2) {  // (second half: at most T more records, and the queue holds at most kBBRecs - T)
+        seed_test(1);
+        stage = 0;
         __syncthreads();
         continue;
       }
+#endif
       if (!blocks_left) break;
       const uint32_t b = b0 + (uint32_t)tid;
       const uint32_t bw = b0 + (uint32_t)(wave * 64);
@@ -1208,6 +1378,7 @@ __global__ __launch_bounds__(kBBThreads, MOCAP_BB_WAVES_PER_EU) void frame_bb_ke
 }
 
 int frame_bb_wg_per_cu_cap() { return MOCAP_BB_WAVES_PER_EU; }
+size_t frame_bb_ws_bytes(int C) { return MOCAP_BB_PROBE ? (size_t)2 * (4 + 2 * (C <= 8 ? 1 : 2)) * 4 * kBBThreads : 0; }
 
 hipError_t launch_frame_bb(const FrameArgs& a, int grid, hipStream_t stream) {
   const size_t lds = frame_bb_lds_bytes(a.cv.C, a.M, a.K_max);

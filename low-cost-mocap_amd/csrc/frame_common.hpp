@@ -69,7 +69,8 @@ __device__ __forceinline__ void wave_lds_sync() {
 // misc[] slots of a workgroup's frame state
 enum { MI_NROOTS = 0, MI_STATUS = 1, MI_NOUT = 2, MI_G = 3, MI_ITEM = 4, MI_DEFER = 5, MI_KIND = 6,
        MI_OMAX = 7 /* bit pattern of the largest |coordinate| among the frame's blobs (float >= 0) */,
-       MI_BBCTR = 8 /* frame_bb.hip: queued blocks | their candidates << 10 */, MI_NEXT = 9 /* frame_bb.hip: the next frame */ };
+       MI_BBCTR = 8 /* frame_bb.hip: queued blocks | their candidates << 10 */, MI_NEXT = 9 /* frame_bb.hip: the next frame */,
+       MI_BBCTR2 = 10 /* frame_bb.hip: MI_BBCTR's partner (the two take turns) */ };
 
 // inclusive prefix sum over the 64 lanes of a wave
 __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, int lane) {

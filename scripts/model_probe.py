@@ -1,7 +1,9 @@
 """CPU estimate (oracle arithmetic) on the 8 x 16 bench stream of a probe-first search: candidate 0 of every root (the
 closest hit in every camera) is evaluated before anything else and gives the root its first bound; blocks are tested
 against it; the candidates of the surviving blocks take their own first-factorisation test (stage 1) and only its
-survivors are evaluated in full (stage 2).  Compared with the kernel's seed-block scheme.  usage: model_probe.py [frames] [PL]"""
+survivors are evaluated in full (stage 2).  Compared with the kernel's seed-block scheme -- and (round 5, the "s1-probe" line) with
+the scheme csrc/frame_bb.hip keeps behind -DMOCAP_BB_PROBE: the seed block's candidates take one factorisation each, the one
+with the largest s1 is the probe, the others are tested against its error (profiles/r05_bb_eval_cost_decomposition.txt).  usage: model_probe.py [frames] [PL]"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -28,6 +30,7 @@ tot = roots_multi = 0
 seed_eval = seed_cut1 = 0          # current scheme: full evaluations, and how many of them the candidate-level test would cut
 pb_blocks = pb_stage1 = pb_stage2 = 0
 probe_is_best = 0
+sp_A = sp_probe_best = sp_blocks = sp_stage1 = sp_full = sp_seed_surv = 0
 t0 = time.time()
 for f in range(NF):
     omax = float(np.abs(blobs[f][np.arange(M)[None, :] < counts[f][:, None]]).max())
@@ -76,6 +79,21 @@ for f in range(NF):
         for gh in ev_blocks:
             for g in range(gh * pl, (gh + 1) * pl):
                 if dropped(*s1_of(g, 0), best): seed_cut1 += 1
+        # --- probe = the seed block's candidate with the largest candidate-level s1 (round A: s1 of the seed block's candidates)
+        cs1 = [s1_of(g, 0) for g in range(seed * pl, (seed + 1) * pl)]
+        sp_A += pl
+        pg = seed * pl + int(np.argmax([x[0] for x in cs1]))
+        sbest = error(pg)
+        sp_probe_best += int(sbest <= best)
+        sp_full += 1
+        for k, g in enumerate(range(seed * pl, (seed + 1) * pl)):
+            if g != pg and not dropped(*cs1[k], sbest): sp_full += 1; sp_seed_surv += 1
+        for gh in range(nblk):
+            if gh == seed or dropped(*s1b[gh], sbest): continue
+            sp_blocks += 1
+            for g in range(gh * pl, (gh + 1) * pl):
+                sp_stage1 += 1
+                if not dropped(*s1_of(g, 0), sbest): sp_full += 1
         # --- probe first
         pbest = error(0)
         probe_is_best += int(pbest <= min(error(g) for g in range(seed * pl, (seed + 1) * pl)))
@@ -91,3 +109,4 @@ print(f"frames {NF} PL {PL}: candidates {tot} ({tot/NF:.0f} per frame), roots wi
 print(f"  seed scheme: full evaluations {seed_eval/NF:.0f} per frame ({100*seed_eval/tot:.1f} %); of the non-seed ones the candidate-level test would cut {seed_cut1/NF:.0f}")
 print(f"  probe first: probe = best of its seed block in {100*probe_is_best/max(roots_multi,1):.0f} % of the roots; surviving blocks {pb_blocks/NF:.0f}, stage-1 tests {pb_stage1/NF:.0f}, "
       f"full evaluations {pb_stage2/NF:.0f} per frame; {time.time()-t0:.0f}s")
+print(f"  s1-probe: round A {sp_A/NF:.0f}, probe is the seed block's best in {100*sp_probe_best/max(roots_multi,1):.0f} %, seed-block survivors {sp_seed_surv/NF:.0f}, surviving non-seed blocks {sp_blocks/NF:.0f}, stage-1 tests {sp_stage1/NF:.0f}, full evaluations {sp_full/NF:.0f} per frame")
