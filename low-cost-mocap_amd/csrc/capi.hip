@@ -123,6 +123,8 @@ extern "C" void mocap_destroy(mocap_ctx* ctx) {
   ctx->resub.release();
   ctx->live_stage.release();
   ctx->resub_ctr.release();
+  ctx->heavy_recs.release();
+  ctx->heavy_ws.release();
   if (ctx->live_pin) (void)hipHostFree(ctx->live_pin);
   if (ctx->live_event) (void)hipEventDestroy(ctx->live_event);
   ctx->img_map.release();
@@ -538,10 +540,18 @@ FramePlan plan_frame(const mocap_ctx* ctx, int M_max, int K_max, int hit_cap_ove
 
 // hit_cap_override > 0: the hit-list cap of THIS launch (the re-submit pass keeps every gated hit) -- an argument, never a
 // change of the context's state.  n_frames_dev != null: the batch is min(*n_frames_dev, n_frames) frames long.
+// heavy: null, or the export buffer of the heavy-root search (re-submit pass, wide variant only): roots over G_cap are
+// exported instead of flagging their frames (FrameArgs::heavy_bb)
+struct HeavyHook {
+  int32_t* count;
+  unsigned char* recs;
+  int cap;
+};
 static int match_dev_locked(mocap_ctx* ctx, int64_t n_frames, int M_max, const float* d_blobs,
                             const int32_t* d_counts, double gate_px, int K_max, int64_t G_cap, double* d_xyz,
                             double* d_err, int16_t* d_corr, int32_t* d_n_out, int32_t* d_status,
-                            int32_t* d_n_cand, int hit_cap_override = 0, const int32_t* n_frames_dev = nullptr) {
+                            int32_t* d_n_cand, int hit_cap_override = 0, const int32_t* n_frames_dev = nullptr,
+                            const HeavyHook* heavy = nullptr) {
   if (!ctx->C) return ctx->fail(MOCAP_E_NOCAMS, "mocap_set_cameras has not been called");
   if (n_frames < 0 || M_max < 1 || K_max < 1 || G_cap < 1)
     return ctx->fail(MOCAP_E_ARG, "mocap_match_triangulate: bad size argument");
@@ -590,6 +600,18 @@ static int match_dev_locked(mocap_ctx* ctx, int64_t n_frames, int M_max, const f
   while (a.bb_pl > 1 && (size_t)a.bb_pl * M_max * 2 * 256 >= ((size_t)1 << 22)) a.bb_pl /= 2;  // expanded-list counter: 22 bits
   a.ws = nullptr;
   a.ws_stride = 0;
+  a.heavy_bb = 0;
+  a.heavy_cap = 0;
+  a.heavy_count = nullptr;
+  a.heavy_recs = nullptr;
+  a.heavy_stride = 0;
+  if (heavy && wide) {
+    a.heavy_bb = 1;
+    a.heavy_cap = heavy->cap;
+    a.heavy_count = heavy->count;
+    a.heavy_recs = heavy->recs;
+    a.heavy_stride = heavy_rec_bytes(ctx->C, hit_cap);
+  }
   // persistent grid: enough workgroups to fill every CU at the LDS-limited occupancy
   int per_cu = (int)((160 * 1024) / lds);
   const int wave_cap = use_bb ? frame_bb_wg_per_cu_cap() : (16 / (T / 64) > 0 ? 16 / (T / 64) : 1);  // 128 VGPRs -> 16 waves per CU
@@ -615,6 +637,7 @@ static int match_dev_locked(mocap_ctx* ctx, int64_t n_frames, int M_max, const f
   FrameQueues& q = a.q;
   q.heavy_threshold = ctx->heavy_threshold >= 0 ? (uint32_t)ctx->heavy_threshold : (batch ? 32768u : 16u * T);  // batch: swept under the single-launch schedule (16 k: 13.45, 24-32 k: 13.32, 48 k: 13.50, 64 k: 13.72 ms per 100 k frames); live calls: swept, p50 0.129 -> 0.117 ms vs 2T, same p99
   q.slice_size = ctx->slice_size > 0 ? (uint32_t)ctx->slice_size : (batch ? 8192u : 4u * T);
+  if (a.heavy_bb) q.heavy_threshold = 0;  // (a sliced frame would be matched, and its heavy roots exported, once per slice)
   // small frames: amortise the queue atomic over a chunk (keeps >= 64 chunks per workgroup for balance);
   // frames with real work keep the finest granularity, their candidate counts are heavy-tailed
   q.frame_chunk = 1;
@@ -774,10 +797,55 @@ static int resubmit_dev_locked(mocap_ctx* ctx, int64_t n_frames, int M_max, cons
   ra.status_out = d_status;
   ra.n_cand = d_n_cand;
   ra.info = d_info;
+  // Roots whose product no enumeration reaches (two markers behind each other from the root's camera: 2^60 groups at 64
+  // cameras) go to the heavy-root search (csrc/heavy_bb.hip) where the second pass runs the wide variant on cameras of the
+  // form EigCut needs: the pass enumerates up to MOCAP_RESUBMIT_G_CAP groups per root (default 4096) and exports the
+  // roots above it; elsewhere it enumerates up to 2^24 per root and flags what is larger, as before.
+  const FramePlan pl2 = plan_frame(ctx, M_max, K_big, M_max);
+  const bool heavy_ok = pl2.wide && ctx->cv.uniformK && ctx->prune && ctx->eigcut && ctx->p3max2 > 0.0 && !getenv("MOCAP_NO_HEAVY_BB");
+  int64_t G2 = (int64_t)1 << 24;
+  HeavyHook hk{nullptr, nullptr, 0};
+  const int ncap = 4096, hv_grid = 64;
+  if (heavy_ok) {
+    G2 = 4096;
+    if (const char* e = getenv("MOCAP_RESUBMIT_G_CAP")) G2 = atol(e) > 0 ? atol(e) : 1;
+    hk.cap = 2048;
+    if (ctx->heavy_recs.reserve((size_t)hk.cap * heavy_rec_bytes(C, M_max)) || ctx->heavy_ws.reserve((size_t)hv_grid * heavy_bb_ws_bytes(ncap)))
+      return ctx->fail(MOCAP_E_HIP, "hipMalloc(heavy-root search buffers) failed");
+    hk.recs = (unsigned char*)ctx->heavy_recs.ptr;
+    hk.count = ctr + 16;  // (its own word of the counter block; the gather kernel zeroes it)
+    ra.heavy_count = hk.count;
+  } else {
+    ra.heavy_count = nullptr;
+  }
   HIP_TRY(ctx, launch_resubmit_gather(ra, ctx->stream));
-  const int rc = match_dev_locked(ctx, cap, M_max, ra.b2, ra.c2, gate_px, K_big, (int64_t)1 << 24, x2, e2, r2, n2, s2, g2,
-                                  /*hit_cap_override=*/M_max, /*n_frames_dev=*/ra.count);
+  const int rc = match_dev_locked(ctx, cap, M_max, ra.b2, ra.c2, gate_px, K_big, G2, x2, e2, r2, n2, s2, g2,
+                                  /*hit_cap_override=*/M_max, /*n_frames_dev=*/ra.count, heavy_ok ? &hk : nullptr);
   if (rc) return rc;
+  if (heavy_ok) {
+    HeavyArgs ha;
+    ha.cv = ctx->cv;
+    ha.M = M_max;
+    ha.K_big = K_big;
+    for (int i = 0; i < 3; i++) ha.bb_c0[i] = ctx->eig_c0[i];
+    ha.p3max2c = ctx->p3max2c;
+    ha.p3max2 = ctx->p3max2;
+    ha.blobs = ra.b2;
+    ha.heavy_count = hk.count;
+    ha.recs = hk.recs;
+    ha.cap = hk.cap;
+    ha.stride = heavy_rec_bytes(C, M_max);
+    ha.xyz = x2;
+    ha.err = e2;
+    ha.corr = r2;
+    ha.n_out = n2;
+    ha.status = s2;
+    ha.world = ctx->world_on ? (const double*)ctx->world.ptr : nullptr;
+    ha.ws = (unsigned char*)ctx->heavy_ws.ptr;
+    ha.ws_stride = heavy_bb_ws_bytes(ncap);
+    ha.ncap = ncap;
+    HIP_TRY(ctx, launch_heavy_bb(ha, hv_grid, ctx->stream));
+  }
   HIP_TRY(ctx, launch_resubmit_scatter(ra, ctx->stream));
   return MOCAP_OK;
 }

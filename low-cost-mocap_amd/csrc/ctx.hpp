@@ -79,6 +79,8 @@ struct mocap_ctx {
   DevBuf live_stage;        // mocap_track_frame: device copy of a wide frame's blobs (narrow frames are read from pinned host memory in place)
   DevBuf resub;             // device-side re-submit: counters | frame list | gathered inputs | second-pass outputs
   DevBuf resub_ctr;         // ... its two alternating counters (never re-allocated while a call is in flight)
+  DevBuf heavy_recs;        // ... heavy roots exported by the second pass (csrc/heavy_bb.hip)
+  DevBuf heavy_ws;          // ... the search's frontier workspace
   uint32_t resub_calls = 0; // ... parity selects the counter of the current call
   DevBuf scratch[4];        // [0] host-API staging, [1..3] bundle adjustment workspace
 

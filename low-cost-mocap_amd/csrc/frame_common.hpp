@@ -70,7 +70,10 @@ __device__ __forceinline__ void wave_lds_sync() {
 enum { MI_NROOTS = 0, MI_STATUS = 1, MI_NOUT = 2, MI_G = 3, MI_ITEM = 4, MI_DEFER = 5, MI_KIND = 6,
        MI_OMAX = 7 /* bit pattern of the largest |coordinate| among the frame's blobs (float >= 0) */,
        MI_BBCTR = 8 /* frame_bb.hip: queued blocks | their candidates << 10 */, MI_NEXT = 9 /* frame_bb.hip: the next frame */,
-       MI_BBCTR2 = 10 /* frame_bb.hip: MI_BBCTR's partner (the two take turns) */ };
+       MI_BBCTR2 = 10 /* frame_bb.hip: MI_BBCTR's partner (the two take turns) */,
+       MI_HEAVY_N = 11 /* wide frames: heavy roots of this frame (FrameArgs::heavy_bb) */, MI_HEAVY_SLOT = 12,
+       MI_HEAVY_R0 = 16 /* ... their root numbers, kMaxHeavyPerFrame entries */ };
+constexpr int kMaxHeavyPerFrame = 48;
 
 // inclusive prefix sum over the 64 lanes of a wave
 __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, int lane) {

@@ -102,7 +102,7 @@ struct FrameLayout {
     gcnt = o;      o += sizeof(uint32_t) * R;
     outslot = o;   o += sizeof(int32_t) * R;
     cnt = o;       o += sizeof(int32_t) * C;
-    misc = o;      o += sizeof(int32_t) * 8;
+    misc = o;      o += sizeof(int32_t) * 64;
     root_blob = o; o += sizeof(uint16_t) * R;
     root_cam = o;  o += R;
     claimed = o;   o += wide ? 0 : M;
@@ -140,7 +140,9 @@ struct FrameLayout {
 size_t frame_lds_bytes(int C, int M, int R, int T, int H, bool wide, bool table) { return FrameLayout(C, M, R, T, H, wide, table && !wide).lds_total; }
 size_t frame_ws_bytes(int C, int M, int R, int T, int H, bool wide, bool table) { return FrameLayout(C, M, R, T, H, wide, table && !wide).ws_total; }
 
-template <int T, bool UNIFORM_K, bool F32R, bool WIDE>
+// HEAVY (wide variant, re-submit pass only): roots over the candidate cap are exported to the heavy-root search instead of
+// flagging their frames -- a separate instantiation, so that the code does not weigh on the registers of the first pass
+template <int T, bool UNIFORM_K, bool F32R, bool WIDE, bool HEAVY = false>
 struct FrameState {
   const FrameArgs& p;
   const CamView& cv;
@@ -883,6 +885,7 @@ struct FrameState {
       if (tid == 0) {
         misc[MI_STATUS] = 0;
         misc[MI_OMAX] = 0;
+        misc[MI_HEAVY_N] = 0;
       }
     }
     __syncthreads();
@@ -970,6 +973,48 @@ struct FrameState {
       n_roots = now;
     }
     count_candidates();
+    if constexpr (WIDE && HEAVY) {
+      if (misc[MI_HEAVY_N]) export_heavy(frame);
+    }
+  }
+
+  // Heavy roots (FrameArgs::heavy_bb): the root's hit counts and hit lists leave for the heavy-root search (csrc/heavy_bb.hip).
+  // All lanes; the workgroup is synchronised on entry and on exit.
+  __device__ void export_heavy(int64_t frame) {
+    const int nhv = misc[MI_HEAVY_N] < kMaxHeavyPerFrame ? misc[MI_HEAVY_N] : kMaxHeavyPerFrame;
+    for (int h = 0; h < nhv; h++) {
+      const int r = misc[MI_HEAVY_R0 + h];
+      if (tid == 0) misc[MI_HEAVY_SLOT] = atomicAdd(p.heavy_count, 1);
+      __syncthreads();
+      const int slot = misc[MI_HEAVY_SLOT];
+      if (slot < p.heavy_cap) {
+        unsigned char* rec = p.heavy_recs + (size_t)slot * p.heavy_stride;
+        if (tid == 0) {
+          HeavyRecHdr hd;
+          hd.frame = (int32_t)frame;
+          hd.root = r;
+          hd.outslot = outslot[r];
+          hd.rc = root_cam[r];
+          hd.rb = root_blob[r];
+          hd.omax_bits = misc[MI_OMAX];
+          int views = 0;
+          for (int c = 0; c < C; c++) views += nhits(r, c) ? 1 : 0;
+          hd.views = views;
+          hd.Hs = Hs;
+          *reinterpret_cast<HeavyRecHdr*>(rec) = hd;
+        }
+        uint16_t* nc = reinterpret_cast<uint16_t*>(rec + heavy_rec_counts_off());
+        for (int c = tid; c < C; c += T) nc[c] = (uint16_t)nhits(r, c);
+        uint8_t* hl = rec + heavy_rec_hits_off(C);
+        for (int idx = tid; idx < C * Hs; idx += T) {
+          const int c = idx / Hs, d = idx - c * Hs;
+          hl[idx] = (uint32_t)d < nhits(r, c) ? (uint8_t)hit_at(r, c, (uint32_t)d) : (uint8_t)0;
+        }
+      } else if (tid == 0) {
+        misc[MI_STATUS] |= MOCAP_ST_CAND_OVERFLOW_;  // no room for the record: the frame stays flagged
+      }
+      __syncthreads();
+    }
   }
 
   // C: candidate counts per root (all lanes; the roots and hit lists are in place and the workgroup is synchronised)
@@ -994,10 +1039,22 @@ struct FrameState {
           }
         }
       }
-      if (over) atomicOr(&misc[MI_STATUS], MOCAP_ST_CAND_OVERFLOW_);
+      bool heavy = false;
+      if constexpr (WIDE && HEAVY) {
+        // re-submit pass: the root is handed to the heavy-root search; here it counts ONE candidate, group 0 (the closest hit
+        // in every camera), whose error is the bound that search starts from
+        if (over && views > 1) {
+          const int idx = atomicAdd(&misc[MI_HEAVY_N], 1);
+          if (idx < kMaxHeavyPerFrame) {
+            misc[MI_HEAVY_R0 + idx] = r;
+            heavy = true;
+          }
+        }
+      }
+      if (over && !heavy) atomicOr(&misc[MI_STATUS], MOCAP_ST_CAND_OVERFLOW_);
       if constexpr (!WIDE) nact[r] = (uint8_t)na;
       rbound[r] = 0x7ff0000000000000ull;
-      gcnt[r] = (views > 1 && !over) ? (uint32_t)total : 0u;  // helpers.py:413-414 drops 1-view roots
+      gcnt[r] = views > 1 ? (heavy ? 1u : (over ? 0u : (uint32_t)total)) : 0u;  // helpers.py:413-414 drops 1-view roots
     }
     __syncthreads();
     if (tid < 64) {  // candidate offsets and output slots: wave scans over the roots, 64 at a time
@@ -1125,6 +1182,13 @@ struct FrameState {
       // after the root's is the fastest digit), peeled off by one small division as the pass walks the cameras in
       // ascending order.  Each pass (DLT, depths, reprojection) starts at camera 0, which resets the remainder.  The
       // blobs are read in place from the input batch (L2); nothing per candidate is written anywhere.
+      // CONTRACT of raw(): a pass calls it for the cameras in ascending order, each exactly once, starting at camera 0 --
+      // the remainder is state.  The two places of mocap_device.hpp that bend this are harmless by construction and rely
+      // on it staying so: (1) score_point skips a block of four cameras for a lane whose running sum is over the limit;
+      // what such a lane decodes afterwards (the tail cameras, C % 4) is a wrong but in-range blob (the digit is still
+      // `rem % n` < n) of a group whose error is already +inf; (2) the padded batches of triangulate_and_score /
+      // solve_and_score call raw(C - 1) again for the slots past the last camera: extra digits are peeled AFTER the last
+      // real one and the values are discarded (`c0 + u < C`).  A pass that needs anything else must decode statelessly.
       struct WideObs {
         const uint8_t* h0r;     // LDS [C]: closest hit per camera of the current root
         const uint8_t* nhr;     // LDS [C]: hit count (saturating)
@@ -1332,10 +1396,10 @@ struct FrameState {
   }
 };
 
-template <int T, bool UNIFORM_K, bool F32R, bool WIDE, int MODE>
+template <int T, bool UNIFORM_K, bool F32R, bool WIDE, int MODE, bool HEAVY = false>
 __global__ __launch_bounds__(T, MOCAP_FRAME_WAVES_PER_EU) void frame_kernel(FrameArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  FrameState<T, UNIFORM_K, F32R, WIDE> st(p, smem);
+  FrameState<T, UNIFORM_K, F32R, WIDE, HEAVY> st(p, smem);
   const int tid = threadIdx.x;
   const FrameQueues& q = p.q;
   const int R = p.K_max;
@@ -1656,6 +1720,14 @@ static hipError_t launch_TM(const FrameArgs& a, int grid, size_t lds, hipStream_
     k = a.cv.uniformK ? frame_kernel<T, true, true, WIDE, MODE> : frame_kernel<T, false, true, WIDE, MODE>;
   else
     k = a.cv.uniformK ? frame_kernel<T, true, false, WIDE, MODE> : frame_kernel<T, false, false, WIDE, MODE>;
+  if constexpr (WIDE && MODE == MODE_ALL) {
+    if (a.heavy_bb) {  // (identical intrinsics only: the host asks for it nowhere else)
+      if (!a.cv.uniformK) return hipErrorInvalidValue;
+      k = a.cv.f32_rounding ? frame_kernel<T, true, true, true, MODE_ALL, true> : frame_kernel<T, true, false, true, MODE_ALL, true>;
+    }
+  } else if (a.heavy_bb) {
+    return hipErrorInvalidValue;
+  }
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;

@@ -1,0 +1,292 @@
+// heavy_bb.hip -- the candidate space of ONE root when no enumeration reaches its end.
+//
+// The reference expands the Cartesian product of a root's gated hits over the cameras, whatever its size
+// (reference computer_code/api/helpers.py:394-400), triangulates every group and keeps the first minimum of the reprojection
+// error (helpers.py:408-421).  Two markers that lie behind each other as seen from the root's camera put TWO hits into
+// nearly every other camera: at 64 cameras that is 2^60 groups -- the reference would not return either, and the frame
+// kernels cap a root at 2^24 groups and flag the frame.  The winner of such a root can still be found exactly:
+//
+//   * a group's error is bounded from below by the smallest eigenvalue of its DLT matrix (EigCut, mocap_device.hpp), and the
+//     matrix of a PARTIAL group -- some multi-hit cameras not yet decided -- bounds every completion (it is a sum of
+//     positive semi-definite terms): the same inequality, with the same rounding allowances, csrc/frame_bb.hip drops its
+//     blocks on;
+//   * the search goes through the multi-hit cameras level by level (breadth first).  A node = the digits chosen so far + the
+//     DLT matrix of the single-hit cameras and those digits; its children (one per hit of the next camera) are tested against
+//     the error of group 0 -- the closest hit in every camera, evaluated by the frame kernel itself before this kernel runs,
+//     almost always the winner -- and the survivors form the next level's frontier;
+//   * the leaves that survive the last level are complete groups: they are triangulated and scored by the SAME device
+//     function, in the same camera order, as every other group of the path (triangulate_and_score), and the first minimum
+//     in candidate order (error bits, then the mixed-radix index compared digit by digit from the slowest camera down)
+//     replaces the root's point if it beats group 0.
+//
+// Nothing is dropped on anything but a rigorous bound, so the result is the one the enumeration would give
+// (tests/test_gpu_wide_adversarial.py runs roots both ways where the enumeration is feasible).  A frontier that outgrows the
+// workspace (two markers that coincide to within the noise in most cameras: nothing separates the mixtures) flags the frame
+// like the cap did.
+//
+// One 256-lane workgroup per heavy root (records exported by frame_kernel.hip's wide variant in the re-submit pass);
+// identical plain intrinsics only (the host does not export otherwise).
+#include "mocap_device.hpp"
+#include "kernels.hpp"
+#include "frame_common.hpp"
+
+namespace mocap {
+
+constexpr int kHvThreads = 256;
+constexpr int kHvDigits = 64;  // digit slots of a node (>= multi-hit cameras of a root: < kMaxCameras)
+
+size_t heavy_bb_ws_bytes(int ncap) { return (size_t)2 * ncap * (sizeof(double) * 10 + kHvDigits); }
+
+template <bool F32R>
+__global__ __launch_bounds__(kHvThreads) void heavy_bb_kernel(HeavyArgs a) {
+  __shared__ uint16_t s_n[kMaxCameras];      // hits per camera (1 at the root's, 0 where the root has none)
+  __shared__ uint8_t s_lvl[kMaxCameras];     // level of a multi-hit camera (0xFF otherwise)
+  __shared__ uint8_t s_dcam[kMaxCameras];    // camera of level j
+  __shared__ double s_Bs[10];                // DLT matrix of the single-hit cameras (root included)
+  __shared__ int s_cnt[2];                   // nodes in the current / next frontier
+  __shared__ int s_m;
+  __shared__ unsigned long long s_best;      // smallest error among the leaves (bit pattern)
+  __shared__ int s_nhold, s_hold[64];        // leaves that hold it
+  __shared__ int s_win;
+  __shared__ double s_Bp[10];                // greedy descent: the matrix of the path so far
+  __shared__ unsigned long long s_gkey;      // ... (s1 bits | 0xFF - digit) of the best child of the level
+  __shared__ uint8_t s_gd[kHvDigits];        // ... its digits
+  __shared__ double s_eg;                    // ... the error of the group it ends in
+  const int tid = threadIdx.x;
+  const int C = a.cv.C, M = a.M;
+  int total = *a.heavy_count;
+  if (total > a.cap) total = a.cap;
+  unsigned char* ws = a.ws + (size_t)blockIdx.x * a.ws_stride;
+  double* nodeB[2] = {(double*)ws, (double*)ws + (size_t)10 * a.ncap};
+  uint8_t* nodeD[2] = {(uint8_t*)((double*)ws + (size_t)20 * a.ncap), (uint8_t*)((double*)ws + (size_t)20 * a.ncap) + (size_t)kHvDigits * a.ncap};
+  const double c0[3] = {a.bb_c0[0], a.bb_c0[1], a.bb_c0[2]};
+  const double inf = __builtin_huge_val();
+
+  for (int h = blockIdx.x; h < total; h += gridDim.x) {
+    const unsigned char* rec = a.recs + (size_t)h * a.stride;
+    const HeavyRecHdr hd = *reinterpret_cast<const HeavyRecHdr*>(rec);
+    const uint16_t* nc = reinterpret_cast<const uint16_t*>(rec + heavy_rec_counts_off());
+    const uint8_t* hl = rec + heavy_rec_hits_off(C);
+    const int Hs = hd.Hs;
+    const float2* fb = (const float2*)(a.blobs + (size_t)hd.frame * C * M * 2);
+    const size_t o = (size_t)hd.frame * a.K_big + hd.outslot;
+    __syncthreads();  // (the previous root's shared state is dead)
+    if (tid < C) s_n[tid] = nc[tid];
+    if (tid == 0) {
+      int m = 0;
+      for (int c = 0; c < C; c++) {
+        s_lvl[c] = 0xFF;
+        if (nc[c] > 1) {
+          s_lvl[c] = (uint8_t)m;
+          s_dcam[m++] = (uint8_t)c;
+        }
+      }
+      s_m = m;
+      s_cnt[0] = 1;
+      s_cnt[1] = 0;
+      // single-hit cameras, ascending (the order only has to be a fixed one: the sum feeds bounds, never a result)
+      double B[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+      for (int c = 0; c < C; c++)
+        if (nc[c] == 1) {
+          const float2 w = fb[(size_t)c * M + hl[(size_t)c * Hs]];
+          dlt_accumulate(B, a.cv.pq((size_t)12 * c), (double)w.x, (double)w.y);
+        }
+      for (int e = 0; e < 10; e++) {
+        s_Bs[e] = B[e];
+        nodeB[0][e] = B[e];
+      }
+    }
+    __syncthreads();
+    const int m = s_m;
+    // the bound every node is tested against: the error of group 0, which the frame kernel has written to the root's slot
+    const double e00 = a.err[o];
+    const int vf = hd.views;
+    const double om = (double)__int_as_float(hd.omax_bits);
+    EigCut ec;
+    ec.p3max2 = a.p3max2;
+    ec.o2slack = (1100.0 * 0x1p-46) * (om * om);
+    // A second, usually better, bound: when the two markers share the root's pixel (one behind the other as seen from the
+    // root's camera) the closest hit of a camera is either marker's blob at random and group 0 is a mixture with an error of
+    // many pixels -- nothing could be dropped against it.  A greedy descent -- per level the hit that keeps the partial group's
+    // smallest eigenvalue smallest -- stays with one marker; the group it ends in is evaluated like any other.
+    if (m < kHvDigits) {
+      if (tid < 10) s_Bp[tid] = s_Bs[tid];
+      for (int j = 0; j < m; j++) {
+        if (tid == 0) s_gkey = 0ull;
+        __syncthreads();
+        const int cam = s_dcam[j], nj = s_n[cam];
+        double B[10];
+        if (tid < nj) {
+#pragma unroll
+          for (int e = 0; e < 10; e++) B[e] = s_Bp[e];
+          const float2 w = fb[(size_t)cam * M + hl[(size_t)cam * Hs + tid]];
+          dlt_accumulate(B, a.cv.pq((size_t)12 * cam), (double)w.x, (double)w.y);
+          double tr;
+          const double s1 = eigcut_s1_shifted(B, c0, tr);
+          atomicMax(&s_gkey, ((unsigned long long)__double_as_longlong(fmin(fmax(s1, 0.0), 1e300)) & ~0xFFull) | (unsigned long long)(0xFF - tid));
+        }
+        __syncthreads();
+        const int dbest = 0xFF - (int)(s_gkey & 0xFFull);
+        if (tid == dbest) {
+#pragma unroll
+          for (int e = 0; e < 10; e++) s_Bp[e] = B[e];
+          s_gd[j] = (uint8_t)dbest;
+        }
+        __syncthreads();
+      }
+      if (tid == 0) {
+        auto obs = [&](int c, double& x, double& y) -> bool {
+          const int n = s_n[c];
+          if (!n) return false;
+          const int d = n > 1 ? s_gd[s_lvl[c]] : 0;
+          const float2 w = fb[(size_t)c * M + hl[(size_t)c * Hs + d]];
+          x = (double)w.x;
+          y = (double)w.y;
+          return true;
+        };
+        double X[3], e = inf;
+        triangulate_and_score<true, true, F32R, 1, false>(a.cv, obs, obs, X, e);
+        s_eg = e;
+      }
+      __syncthreads();
+    }
+    const double eg = m < kHvDigits ? s_eg : inf;
+    const double e0 = (eg < e00) ? eg : e00;  // (NaN-safe: a non-finite greedy error leaves group 0's)
+    const double limit = e0 * (double)(2 * vf) * (1.0 + 0x1p-40);
+    const double limit_adj = fma(1.002, limit, (double)(2 * vf) * ec.o2slack);
+    const double lamcut = a.p3max2c * limit_adj;
+    bool give_up = !(e0 < inf) || m >= kHvDigits;  // no finite bound to start from: nothing could be dropped
+    int cur = 0;
+    for (int j = 0; j < m && !give_up; j++) {
+      const int cam = s_dcam[j], nj = s_n[cam], ncur = s_cnt[cur];
+      const int nxt = cur ^ 1;
+      const int64_t work = (int64_t)ncur * nj;
+      for (int64_t idx = tid; idx < work; idx += kHvThreads) {
+        const int i = (int)(idx / nj), d = (int)(idx - (int64_t)i * nj);
+        double B[10];
+#pragma unroll
+        for (int e = 0; e < 10; e++) B[e] = nodeB[cur][(size_t)i * 10 + e];
+        const float2 w = fb[(size_t)cam * M + hl[(size_t)cam * Hs + d]];
+        dlt_accumulate(B, a.cv.pq((size_t)12 * cam), (double)w.x, (double)w.y);
+        double tr;
+        const double s1 = eigcut_s1_shifted(B, c0, tr);
+        if (!(s1 * fma(2e-12, tr, lamcut) < 1.0)) {  // not dropped (a one-view node cannot occur: the root's camera is always in)
+          const int pos = atomicAdd(&s_cnt[nxt], 1);
+          if (pos < a.ncap) {
+#pragma unroll
+            for (int e = 0; e < 10; e++) nodeB[nxt][(size_t)pos * 10 + e] = B[e];
+            uint8_t* dd = nodeD[nxt] + (size_t)pos * kHvDigits;
+            const uint8_t* ds = nodeD[cur] + (size_t)i * kHvDigits;
+            for (int k = 0; k < j; k++) dd[k] = ds[k];
+            dd[j] = (uint8_t)d;
+          }
+        }
+      }
+      __threadfence_block();
+      __syncthreads();
+      if (s_cnt[nxt] > a.ncap) give_up = true;  // (uniform)
+      __syncthreads();
+      if (tid == 0) s_cnt[cur] = 0;
+      cur = nxt;
+      __syncthreads();
+    }
+    if (give_up) {
+      if (tid == 0) {
+        a.status[hd.frame] |= MOCAP_ST_CAND_OVERFLOW_;
+        a.n_out[hd.frame] = 0;
+      }
+      continue;
+    }
+    // ---- leaves: complete groups, evaluated like every other group of the path
+    const int nleaf = s_cnt[cur];
+    if (tid == 0) {
+      s_best = 0x7ff0000000000000ull;
+      s_nhold = 0;
+      s_win = -1;
+    }
+    __syncthreads();
+    const uint8_t* leafD = nodeD[cur];
+    for (int base = 0; base < nleaf; base += kHvThreads) {
+      const int i = base + tid;
+      if (i < nleaf) {
+        const uint8_t* dg = leafD + (size_t)i * kHvDigits;
+        auto obs = [&](int c, double& x, double& y) -> bool {
+          const int n = s_n[c];
+          if (!n) return false;
+          const int d = n > 1 ? dg[s_lvl[c]] : 0;
+          const float2 w = fb[(size_t)c * M + hl[(size_t)c * Hs + d]];
+          x = (double)w.x;
+          y = (double)w.y;
+          return true;
+        };
+        double X[3], e = inf;
+        triangulate_and_score<true, true, F32R, 1, false>(a.cv, obs, obs, X, e, e0, ec);
+        if (e < inf) {
+          atomicMin(&s_best, (unsigned long long)__double_as_longlong(e));
+          // parked next to the leaf's matrix (dead now): the error and the point
+          nodeB[cur][(size_t)i * 10 + 0] = e;
+          nodeB[cur][(size_t)i * 10 + 1] = X[0];
+          nodeB[cur][(size_t)i * 10 + 2] = X[1];
+          nodeB[cur][(size_t)i * 10 + 3] = X[2];
+        } else {
+          nodeB[cur][(size_t)i * 10 + 0] = inf;
+        }
+      }
+    }
+    __threadfence_block();
+    __syncthreads();
+    const double eb = __longlong_as_double((long long)s_best);
+    if (!(eb < e00)) continue;  // (uniform) group 0 stands: it is the smallest index, ties included
+    for (int base = 0; base < nleaf; base += kHvThreads) {
+      const int i = base + tid;
+      if (i < nleaf && nodeB[cur][(size_t)i * 10] == eb) {
+        const int k = atomicAdd(&s_nhold, 1);
+        if (k < 64) s_hold[k] = i;
+      }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      // first minimum in candidate order: the mixed-radix index, slowest digit (the last multi-hit camera) first.  (More
+      // than 64 leaves with the very same error bits: the first 64 found take part -- not reachable with measured blobs.)
+      const int nh = s_nhold < 64 ? s_nhold : 64;
+      int win = s_hold[0];
+      for (int k = 1; k < nh; k++) {
+        const uint8_t* x = leafD + (size_t)s_hold[k] * kHvDigits;
+        const uint8_t* y = leafD + (size_t)win * kHvDigits;
+        for (int j = m - 1; j >= 0; j--) {
+          if (x[j] != y[j]) {
+            if (x[j] < y[j]) win = s_hold[k];
+            break;
+          }
+        }
+      }
+      s_win = win;
+    }
+    __syncthreads();
+    const int win = s_win;
+    if (tid == 0) {
+      const double X[3] = {nodeB[cur][(size_t)win * 10 + 1], nodeB[cur][(size_t)win * 10 + 2], nodeB[cur][(size_t)win * 10 + 3]};
+      FrameArgs fa;  // (store_point only looks at xyz and world)
+      fa.xyz = a.xyz;
+      fa.world = a.world;
+      store_point(fa, o, X);
+      a.err[o] = eb;
+    }
+    if (tid < C) {
+      const int n = s_n[tid];
+      int16_t s = -1;
+      if (n) s = (int16_t)hl[(size_t)tid * Hs + (n > 1 ? leafD[(size_t)win * kHvDigits + s_lvl[tid]] : 0)];
+      a.corr[o * C + tid] = s;
+    }
+  }
+}
+
+hipError_t launch_heavy_bb(const HeavyArgs& a, int grid, hipStream_t stream) {
+  if (a.cv.f32_rounding)
+    hipLaunchKernelGGL(heavy_bb_kernel<true>, dim3(grid), dim3(kHvThreads), 0, stream, a);
+  else
+    hipLaunchKernelGGL(heavy_bb_kernel<false>, dim3(grid), dim3(kHvThreads), 0, stream, a);
+  return hipGetLastError();
+}
+
+}  // namespace mocap

@@ -62,7 +62,49 @@ struct FrameArgs {
   double p3max2;  // EigCut: (1 + 1e-5) * max |P[2]|^2 over the cameras, 0 = eigenvalue cut-off off (see mocap_device.hpp)
   const int32_t* n_frames_dev;  // null, or a device-side frame count: the batch is min(*n_frames_dev, n_frames) frames long
                                 // (the re-submit pass of mocap_match_triangulate_dev_auto: its length is only known on the device)
+  // heavy roots (wide variant, re-submit pass): a root whose Cartesian product exceeds G_cap does not flag its frame -- its
+  // candidate 0 (the closest hit in every camera) is evaluated like any other group and the root's hit lists are exported
+  // to the heavy-root search (csrc/heavy_bb.hip), which runs behind this launch and replaces the point if it finds a better group
+  int heavy_bb;
+  int heavy_cap;               // records the export buffer holds
+  int32_t* heavy_count;        // [1] records exported so far (may exceed heavy_cap: the surplus frames are flagged)
+  unsigned char* heavy_recs;   // [heavy_cap][heavy_stride]
+  size_t heavy_stride;         // heavy_rec_bytes(C, H)
 };
+
+// record of one heavy root: header, hit counts [C] (uint16; 1 at the root's own camera, 0 before it), hit lists [C][Hs]
+// (blob indices, ascending distance)
+struct HeavyRecHdr {
+  int32_t frame, root, outslot, rc, rb, omax_bits, views, Hs;
+};
+__host__ __device__ inline size_t heavy_rec_counts_off() { return sizeof(HeavyRecHdr); }
+__host__ __device__ inline size_t heavy_rec_hits_off(int C) { return (sizeof(HeavyRecHdr) + 2 * (size_t)C + 15) / 16 * 16; }
+__host__ __device__ inline size_t heavy_rec_bytes(int C, int Hs) { return (heavy_rec_hits_off(C) + (size_t)C * Hs + 15) / 16 * 16; }
+
+// the heavy-root search (csrc/heavy_bb.hip): exact branch and bound over the digits of ONE root's candidate space, level by
+// level, for roots whose product no enumeration reaches (two markers behind each other as seen from the root's camera:
+// two hits in nearly every camera, 2^60 groups)
+struct HeavyArgs {
+  CamView cv;
+  int M, K_big;
+  double bb_c0[3], p3max2c, p3max2;
+  const float* blobs;          // [frames][C][M][2] the batch the records' frame indices refer to
+  const int32_t* heavy_count;
+  const unsigned char* recs;
+  int cap;
+  size_t stride;
+  double* xyz;                 // the batch's outputs ([frames][K_big] slots): a better group overwrites the root's slot
+  double* err;
+  int16_t* corr;
+  int32_t* n_out;              // a root whose frontier outgrows the workspace flags its frame (status |= candidate overflow, n_out = 0)
+  int32_t* status;
+  const double* world;
+  unsigned char* ws;           // [grid][ws_stride] frontier workspace
+  size_t ws_stride;
+  int ncap;                    // nodes per frontier buffer
+};
+size_t heavy_bb_ws_bytes(int ncap);
+hipError_t launch_heavy_bb(const HeavyArgs& a, int grid, hipStream_t stream);
 
 constexpr int kWideThreads = 1024;  // workgroup size of the wide-frame variant (one workgroup per CU)
 // table = identical intrinsics (CamView::uniformK): per-blob DLT contributions tabulated in LDS (narrow frames only)
@@ -160,6 +202,7 @@ struct ResubmitArgs {
   int32_t* status_out;
   int32_t* n_cand;           // or null
   int32_t* info;             // null, or [2] out: {frames flagged, frames re-run}
+  int32_t* heavy_count;      // null, or the heavy-root export counter of the second pass: zeroed by the gather kernel
 };
 hipError_t launch_resubmit_gather(const ResubmitArgs& a, hipStream_t stream);
 hipError_t launch_resubmit_scatter(const ResubmitArgs& a, hipStream_t stream);

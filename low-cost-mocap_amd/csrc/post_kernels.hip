@@ -344,7 +344,10 @@ __global__ __launch_bounds__(256) void resubmit_gather_kernel(ResubmitArgs a) {
   // wave copies each flagged frame's blobs (C x M x 2 floats) and counts
   const int lane = threadIdx.x & 63;
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  if (wave == 0 && lane == 0) *a.count_next = 0;
+  if (wave == 0 && lane == 0) {
+    *a.count_next = 0;
+    if (a.heavy_count) *a.heavy_count = 0;
+  }
   const int64_t f0 = wave * 64;
   if (f0 >= a.n_frames) return;
   const int64_t f = f0 + lane;

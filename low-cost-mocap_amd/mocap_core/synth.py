@@ -110,13 +110,15 @@ def _sample_markers(rng, n_frames, n_markers, half_extent, min_sep):
 
 
 def make_blob_stream(rig, n_frames, n_markers, seed=0, noise_px=0.3, dropout=0.05,
-                     half_extent=0.7, min_sep=0.05, truncate=True, m_max=None, shuffle=True):
-    """Returns (blobs f32 [F][C][M_max][2] NaN-padded, counts i32 [F][C], truth dict)."""
+                     half_extent=0.7, min_sep=0.05, truncate=True, m_max=None, shuffle=True, world=None):
+    """Returns (blobs f32 [F][C][M_max][2] NaN-padded, counts i32 [F][C], truth dict).
+    world: None (markers sampled in the cube), or a function (sampled [F][M][3]) -> [F][M][3] that edits them (tests)."""
     rng = np.random.default_rng(seed)
     C = len(rig["R"])
     F, M = int(n_frames), int(n_markers)
     m_max = M if m_max is None else int(m_max)
-    world = _sample_markers(rng, F, M, half_extent, min_sep)
+    sampled = _sample_markers(rng, F, M, half_extent, min_sep)
+    world = sampled if world is None else np.asarray(world(sampled), dtype=np.float64)
     # world -> camera-0 coordinates
     X0 = world @ rig["R0"].T + rig["centre"]
     blobs = np.full((F, C, m_max, 2), np.nan, dtype=np.float32)

@@ -69,6 +69,12 @@ def test_ba_and_blob_kernels_do_not_spill(kernels):
 def test_wide_kernel_budget(kernels):
     """frame_kernel<1024, uniformK, F32R, WIDE, MODE_ALL>: the 64 x 256 kernel.  Round 4 took its frame state out of a 1.4 MB
     HBM workspace (57 spilled VGPRs, 164 B of scratch then); a change that pushes the spills back up shows here first."""
-    k = _find(kernels, "frame_kernelILi1024ELb1ELb1ELb1ELi3E")
+    k = _find(kernels, "frame_kernelILi1024ELb1ELb1ELb1ELi3ELb0E")   # (...Lb1E: the re-submit pass's instantiation, below)
     assert k["vgpr_count"] <= 128, k
     assert k["vgpr_spill_count"] <= 52 and k["private_segment_fixed_size"] <= 232, k
+    # round 5: the export of heavy roots (csrc/heavy_bb.hip) lives in an instantiation of its own -- it must not cost the
+    # first pass a register
+    heavy = _find(kernels, "frame_kernelILi1024ELb1ELb1ELb1ELi3ELb1E")
+    assert heavy["vgpr_count"] <= 128 and k["vgpr_spill_count"] < heavy["vgpr_spill_count"] + 40, heavy
+    hv = _find(kernels, "heavy_bb_kernelILb1E")
+    assert hv["vgpr_spill_count"] == 0 and hv["private_segment_fixed_size"] == 0, hv
