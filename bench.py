@@ -861,9 +861,14 @@ def main():
                                            "hits_per_root_and_camera": int(allv[:, 5].sum()),
                                            "note": "AFTER the device-side re-submit (mocap_match_triangulate_dev_auto, inside the timed "
                                                    "region): frames the first pass flagged (G_cap = 2^20 groups per root, K_max "
-                                                   "roots, hit cap) are re-run per step with the largest caps (2^24 groups per root, "
-                                                   "C x M roots, every hit) and scattered back; what is still counted here exceeds "
-                                                   "even those"},
+                                                   "roots, hit cap) are re-run per step with C x M roots and every hit; a root of more "
+                                                   "than 4096 groups goes to the heavy-root search (csrc/heavy_bb.hip: exact branch "
+                                                   "and bound over its multi-hit cameras, whatever the size of the product -- 2^60 for "
+                                                   "two markers behind each other).  What is still counted here: roots whose search "
+                                                   "frontier outgrew 4096 nodes -- a marker dropped out of some cameras where ANOTHER "
+                                                   "marker's blob is the root's only hit, so every group carries views hundreds of "
+                                                   "pixels off and no bound separates the mixtures (the reference's own answer for "
+                                                   "such a root is a point with an error of 1e4-1e6 px^2, after 2^20+ evaluations)"},
                        "exchange": ({"format": "compact records (32 + 2C bytes per valid point) + n_out per frame, count-first "
                                                "point-to-point gather on rank 0",
                                      "bytes_per_rank_per_step": exchanged["bytes"] / max(args.steps, 1),

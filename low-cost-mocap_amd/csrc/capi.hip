@@ -805,7 +805,9 @@ static int resubmit_dev_locked(mocap_ctx* ctx, int64_t n_frames, int M_max, cons
   const bool heavy_ok = pl2.wide && ctx->cv.uniformK && ctx->prune && ctx->eigcut && ctx->p3max2 > 0.0 && !getenv("MOCAP_NO_HEAVY_BB");
   int64_t G2 = (int64_t)1 << 24;
   HeavyHook hk{nullptr, nullptr, 0};
-  const int ncap = 4096, hv_grid = 64;
+  int ncap = 4096;  // (swept on the stress stream: 16 384 and 65 536 solve 1-3 more of ~30 hard roots per 12 500 frames and double the step)
+  const int hv_grid = 64;
+  if (const char* e = getenv("MOCAP_HEAVY_NCAP")) ncap = atoi(e) >= 64 ? atoi(e) : 64;
   if (heavy_ok) {
     G2 = 4096;
     if (const char* e = getenv("MOCAP_RESUBMIT_G_CAP")) G2 = atol(e) > 0 ? atol(e) : 1;
@@ -844,6 +846,7 @@ static int resubmit_dev_locked(mocap_ctx* ctx, int64_t n_frames, int M_max, cons
     ha.ws = (unsigned char*)ctx->heavy_ws.ptr;
     ha.ws_stride = heavy_bb_ws_bytes(ncap);
     ha.ncap = ncap;
+    ha.debug = getenv("MOCAP_HEAVY_DEBUG") ? 1 : 0;
     HIP_TRY(ctx, launch_heavy_bb(ha, hv_grid, ctx->stream));
   }
   HIP_TRY(ctx, launch_resubmit_scatter(ra, ctx->stream));

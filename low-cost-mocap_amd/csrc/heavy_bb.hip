@@ -32,7 +32,7 @@
 
 namespace mocap {
 
-constexpr int kHvThreads = 256;
+constexpr int kHvThreads = 1024;  // (one workgroup per CU: the frontier of a hard root is tens of thousands of nodes per level)
 constexpr int kHvDigits = 64;  // digit slots of a node (>= multi-hit cameras of a root: < kMaxCameras)
 
 size_t heavy_bb_ws_bytes(int ncap) { return (size_t)2 * ncap * (sizeof(double) * 10 + kHvDigits); }
@@ -109,14 +109,18 @@ __global__ __launch_bounds__(kHvThreads) void heavy_bb_kernel(HeavyArgs a) {
     // root's camera) the closest hit of a camera is either marker's blob at random and group 0 is a mixture with an error of
     // many pixels -- nothing could be dropped against it.  A greedy descent -- per level the hit that keeps the partial group's
     // smallest eigenvalue smallest -- stays with one marker; the group it ends in is evaluated like any other.
-    if (m < kHvDigits) {
+    double eg = inf;
+    for (int pass = 0; pass < 2 && m < kHvDigits; pass++) {
+      // (second descent: away from the first one's first digit -- the other marker's group, when there are two to choose from)
+      const int avoid = pass ? (int)s_gd[0] : -1;
+      __syncthreads();
       if (tid < 10) s_Bp[tid] = s_Bs[tid];
       for (int j = 0; j < m; j++) {
         if (tid == 0) s_gkey = 0ull;
         __syncthreads();
         const int cam = s_dcam[j], nj = s_n[cam];
         double B[10];
-        if (tid < nj) {
+        if (tid < nj && !(j == 0 && tid == avoid)) {
 #pragma unroll
           for (int e = 0; e < 10; e++) B[e] = s_Bp[e];
           const float2 w = fb[(size_t)cam * M + hl[(size_t)cam * Hs + tid]];
@@ -149,8 +153,8 @@ __global__ __launch_bounds__(kHvThreads) void heavy_bb_kernel(HeavyArgs a) {
         s_eg = e;
       }
       __syncthreads();
+      if (s_eg < eg) eg = s_eg;
     }
-    const double eg = m < kHvDigits ? s_eg : inf;
     const double e0 = (eg < e00) ? eg : e00;  // (NaN-safe: a non-finite greedy error leaves group 0's)
     const double limit = e0 * (double)(2 * vf) * (1.0 + 0x1p-40);
     const double limit_adj = fma(1.002, limit, (double)(2 * vf) * ec.o2slack);
@@ -190,6 +194,9 @@ __global__ __launch_bounds__(kHvThreads) void heavy_bb_kernel(HeavyArgs a) {
       cur = nxt;
       __syncthreads();
     }
+    if (a.debug && tid == 0)
+      printf("HEAVY rec %d frame %d root %d cam %d m %d views %d e_group0 %.6g e_greedy %.6g give_up %d frontier %d\n", h, hd.frame, hd.root, hd.rc, m, vf,
+             e00, eg, (int)give_up, s_cnt[cur]);
     if (give_up) {
       if (tid == 0) {
         a.status[hd.frame] |= MOCAP_ST_CAND_OVERFLOW_;

@@ -102,6 +102,7 @@ struct HeavyArgs {
   unsigned char* ws;           // [grid][ws_stride] frontier workspace
   size_t ws_stride;
   int ncap;                    // nodes per frontier buffer
+  int debug;                   // MOCAP_HEAVY_DEBUG: one printf per root
 };
 size_t heavy_bb_ws_bytes(int ncap);
 hipError_t launch_heavy_bb(const HeavyArgs& a, int grid, hipStream_t stream);
