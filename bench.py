@@ -30,7 +30,7 @@ from mocap_core import capi, dist as mdist, synth  # noqa: E402
 CAMS, MARKERS = 8, 16
 FRAMES_PER_GPU = 100_000      # BASELINE.json configs[2] / SURVEY.md 8d cfg3
 K_MAX = 48
-G_CAP = 1 << 20
+G_CAP = int(os.environ.get("MOCAP_BENCH_G_CAP", 1 << 20))   # groups per root the FIRST pass enumerates (the re-submit repairs what is flagged)
 # --workload selects one of BASELINE.json's configs; the default (the driver's) is the metric's own
 # configuration, 8 cams x 16 markers.  The others are secondary measurements of the same path.
 WORKLOADS = {
@@ -56,7 +56,7 @@ def algorithmic_bytes(counts, n_out, C, M):
     return F * (8 * C * M + 4 * C) + int(n_out.sum()) * (24 + 8 + 2 * C)
 
 
-PROFILE_TAG = "r04"           # profiles/<tag>_hbm_traffic.json, <tag>_fp64_mix.json (scripts/profile_frame_pmc.sh)
+PROFILE_TAG = "r05"           # profiles/<tag>_hbm_traffic.json, <tag>_fp64_mix.json (scripts/profile_frame_pmc.sh)
 
 
 def kernel_source_hash():
