@@ -251,9 +251,12 @@ class PendingCompactGather:
     tensor) in rank order; None elsewhere.  result() may be called more than once (the first call completes the
     transfers and materialises the concatenation, later calls return it)."""
 
-    def __init__(self, works, n_parts, r_parts, is_dst, alloc_stream=None):
+    def __init__(self, works, n_parts, r_parts, is_dst, alloc_stream=None, r_whole=None):
         self._works, self._n, self._r, self._is_dst = works, n_parts, r_parts, is_dst
         self._done, self._out = False, None
+        # r_whole: the root's ONE receive buffer -- r_parts are row ranges of it, in rank order, already in place when the
+        # transfers are complete (no concatenation of the records: at 8 ranks that copy was 0.8 GB per 8 x 16 step)
+        self._whole = r_whole
         # the stream gather_compact_async was called on: its caching-allocator pool owns the receive buffers
         self._alloc_stream = alloc_stream
 
@@ -265,7 +268,7 @@ class PendingCompactGather:
             self._works = []
             if self._is_dst:
                 # torch.cat copies: the result no longer aliases the compactor's buffers
-                self._out = (torch.cat(self._n), torch.cat(self._r))
+                self._out = (torch.cat(self._n), self._whole if self._whole is not None else torch.cat(self._r))
                 # The parts were allocated on the stream the exchange was posted on (bench.py: `comm`), the cat above
                 # runs on the CALLER's current stream (bench.py: the compute stream, queued behind a step's kernels).
                 # Dropping the parts returns their blocks to the allocation stream's pool at once, where the next
@@ -274,7 +277,7 @@ class PendingCompactGather:
                 if self._out[1].is_cuda:
                     cur = torch.cuda.current_stream(self._out[1].device)
                     if self._alloc_stream is None or cur != self._alloc_stream:
-                        for part in list(self._n) + list(self._r):
+                        for part in list(self._n) + list(self._r) + ([self._whole] if self._whole is not None else []):
                             if part.is_cuda and part.numel():
                                 part.record_stream(cur)
             self._n = self._r = None
@@ -328,16 +331,22 @@ def gather_compact_async(n_out, records, n_records, frames_per_rank, dst=0):
         counts = dict(zip(sorted(heads), (int(c) for c in cnt)))
     else:
         counts = {}
-    ops, n_parts, r_parts = [], [], []
+    # one receive buffer for all ranks' records, in rank order: every sender's rows land where the result wants them, and
+    # the root's own shard is copied in on the stream this was called on (behind its compaction)
+    counts[dst] = int(n_records)
+    whole = torch.empty((sum(counts[r] for r in range(world)), stride), dtype=torch.uint8, device=dev)
+    ops, n_parts, r_parts, row = [], [], [], 0
     for r in range(world):
+        rb = whole[row:row + counts[r]]
+        row += counts[r]
+        r_parts.append(rb)
         if r == dst:
             n_parts.append(n_out)
-            r_parts.append(rec)
+            if counts[r]:
+                rb.copy_(rec, non_blocking=True)
             continue
         n_parts.append(heads[r][COMPACT_HEADER_BYTES:].view(torch.int32))
-        rb = torch.empty((counts[r], stride), dtype=torch.uint8, device=dev)
-        r_parts.append(rb)
         if counts[r]:
             ops.append(dist.P2POp(dist.irecv, rb, r))
     works = list(dist.batch_isend_irecv(ops)) if ops else []
-    return PendingCompactGather(works, n_parts, r_parts, True, alloc_stream)
+    return PendingCompactGather(works, n_parts, r_parts, True, alloc_stream, r_whole=whole)
