@@ -30,7 +30,7 @@ from mocap_core import capi, dist as mdist, synth  # noqa: E402
 CAMS, MARKERS = 8, 16
 FRAMES_PER_GPU = 100_000      # BASELINE.json configs[2] / SURVEY.md 8d cfg3
 K_MAX = 48
-G_CAP = int(os.environ.get("MOCAP_BENCH_G_CAP", 1 << 20))   # groups per root the FIRST pass enumerates (the re-submit repairs what is flagged)
+G_CAP = 1 << 20           # groups per root a pass enumerates unless the workload says otherwise (WORKLOADS[...]["g_cap"], MOCAP_BENCH_G_CAP)
 # --workload selects one of BASELINE.json's configs; the default (the driver's) is the metric's own
 # configuration, 8 cams x 16 markers.  The others are secondary measurements of the same path.
 WORKLOADS = {
@@ -704,6 +704,9 @@ def main():
     wl = WORKLOADS[args.workload]
     C, M, F = wl["C"], wl["M"], (args.frames or wl["frames"])
     K_MAX = wl["K_max"]
+    # groups per root the FIRST pass enumerates; the device-side re-submit repairs what it flags (swept at the stress shape,
+    # a smaller cap makes the first pass faster and leaves more frames to a search that cannot solve all of them)
+    g_cap = int(os.environ["MOCAP_BENCH_G_CAP"]) if "MOCAP_BENCH_G_CAP" in os.environ else wl.get("g_cap", G_CAP)
     if wl["stress"]:
         rig = synth.stress_rig(C)
         blobs, counts, _ = synth.make_stress_stream(rig, F, M, seed=1 + rank)
@@ -735,7 +738,7 @@ def main():
         # cap re-run on the device with the largest caps (the reference has none, helpers.py:394-400) and scattered back.
         # Inside the timed region, so a figure never excludes its heaviest frames.
         hi = F if hi is None else hi
-        core.match_triangulate_dev_auto(hi - lo, M, d_blobs[lo:].data_ptr(), d_counts[lo:].data_ptr(), gate, K_MAX, G_CAP,
+        core.match_triangulate_dev_auto(hi - lo, M, d_blobs[lo:].data_ptr(), d_counts[lo:].data_ptr(), gate, K_MAX, g_cap,
                                         d_xyz[lo:].data_ptr(), d_err[lo:].data_ptr(), d_corr[lo:].data_ptr(),
                                         d_nout[lo:].data_ptr(), d_status[lo:].data_ptr(), d_ncand[lo:].data_ptr(),
                                         d_resub[chunk % 64].data_ptr())
@@ -852,7 +855,7 @@ def main():
             "ms_per_step": 1e3 * t_max / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": wl["desc"],
-                       "frames_per_gpu": F, "cams": C, "markers": M, "K_max": K_MAX, "gate_px": gate,
+                       "frames_per_gpu": F, "cams": C, "markers": M, "K_max": K_MAX, "gate_px": gate, "first_pass_G_cap": g_cap,
                        "parallelism": f"frame-shard x{world}", "frames_per_s": F * world * args.steps / t_max,
                        "markers_per_frame": total_markers / (F * world),
                        "candidates_per_frame": float(n_cand.mean()), "overflow_frames": int(allv[:, 2].sum()),
@@ -860,12 +863,13 @@ def main():
                        "overflow_by_cap": {"roots_K_max": int(allv[:, 3].sum()), "candidates_G_cap": int(allv[:, 4].sum()),
                                            "hits_per_root_and_camera": int(allv[:, 5].sum()),
                                            "note": "AFTER the device-side re-submit (mocap_match_triangulate_dev_auto, inside the timed "
-                                                   "region): frames the first pass flagged (G_cap = 2^20 groups per root, K_max "
+                                                   f"region): frames the first pass flagged (G_cap = {g_cap} groups per root, K_max "
                                                    "roots, hit cap) are re-run per step with C x M roots and every hit; a root of more "
                                                    "than 4096 groups goes to the heavy-root search (csrc/heavy_bb.hip: exact branch "
                                                    "and bound over its multi-hit cameras, whatever the size of the product -- 2^60 for "
-                                                   "two markers behind each other).  What is still counted here: roots whose search "
-                                                   "frontier outgrew 4096 nodes -- a marker dropped out of some cameras where ANOTHER "
+                                                   "two markers behind each other; a root the search gives up on is enumerated in "
+                                                   "place when its product is at most 2^16).  What is still counted here: larger roots whose "
+                                                   "search frontier outgrew 4096 nodes -- a marker dropped out of some cameras where ANOTHER "
                                                    "marker's blob is the root's only hit, so every group carries views hundreds of "
                                                    "pixels off and no bound separates the mixtures (the reference's own answer for "
                                                    "such a root is a point with an error of 1e4-1e6 px^2, after 2^20+ evaluations)"},

@@ -846,6 +846,8 @@ static int resubmit_dev_locked(mocap_ctx* ctx, int64_t n_frames, int M_max, cons
     ha.ws = (unsigned char*)ctx->heavy_ws.ptr;
     ha.ws_stride = heavy_bb_ws_bytes(ncap);
     ha.ncap = ncap;
+    ha.enum_cap = (int64_t)1 << 16;  // (2^20 in place costs tens of ms on one CU: the first pass, which slices such roots over 64 workgroups, is the place for them)
+    if (const char* e = getenv("MOCAP_HEAVY_ENUM_CAP")) ha.enum_cap = atol(e) >= 0 ? atol(e) : 0;
     ha.debug = getenv("MOCAP_HEAVY_DEBUG") ? 1 : 0;
     HIP_TRY(ctx, launch_heavy_bb(ha, hv_grid, ctx->stream));
   }

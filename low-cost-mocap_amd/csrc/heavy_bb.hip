@@ -33,6 +33,7 @@
 namespace mocap {
 
 constexpr int kHvThreads = 1024;  // (one workgroup per CU: the frontier of a hard root is tens of thousands of nodes per level)
+constexpr int kHvEnumDigits = 20;  // multi-hit cameras of a root the fall-back enumerates (product <= 2^20, two hits at least each)
 constexpr int kHvDigits = 64;  // digit slots of a node (>= multi-hit cameras of a root: < kMaxCameras)
 
 size_t heavy_bb_ws_bytes(int ncap) { return (size_t)2 * ncap * (sizeof(double) * 10 + kHvDigits); }
@@ -52,6 +53,7 @@ __global__ __launch_bounds__(kHvThreads) void heavy_bb_kernel(HeavyArgs a) {
   __shared__ unsigned long long s_gkey;      // ... (s1 bits | 0xFF - digit) of the best child of the level
   __shared__ uint8_t s_gd[kHvDigits];        // ... its digits
   __shared__ double s_eg;                    // ... the error of the group it ends in
+  __shared__ uint8_t s_dg[kHvEnumDigits][kHvThreads];  // enumeration fall-back: a lane's digits (column per lane)
   const int tid = threadIdx.x;
   const int C = a.cv.C, M = a.M;
   int total = *a.heavy_count;
@@ -198,9 +200,78 @@ __global__ __launch_bounds__(kHvThreads) void heavy_bb_kernel(HeavyArgs a) {
       printf("HEAVY rec %d frame %d root %d cam %d m %d views %d e_group0 %.6g e_greedy %.6g give_up %d frontier %d\n", h, hd.frame, hd.root, hd.rc, m, vf,
              e00, eg, (int)give_up, s_cnt[cur]);
     if (give_up) {
+      // The frontier outgrew the workspace (or there was no finite bound to start from).  A product that is still small
+      // enough is simply enumerated here -- every group through the path's own device function, the running best of the
+      // workgroup as cut-off, first minimum in candidate order -- so that whatever an enumeration CAN reach is never lost to the
+      // search's limits (a root of 2^15 groups with forced wrong views is enumerable and not searchable; HeavyArgs::enum_cap: 2^16 by default -- 2^20 groups in place would hold one CU for tens of milliseconds).
+      double prod = 1.0;
+      for (int j = 0; j < m; j++) prod *= (double)s_n[s_dcam[j]];
+      if (!(prod <= (double)a.enum_cap) || !(prod <= 1048576.0) || m > kHvEnumDigits) {
+        if (tid == 0) {
+          a.status[hd.frame] |= MOCAP_ST_CAND_OVERFLOW_;
+          a.n_out[hd.frame] = 0;
+        }
+        continue;
+      }
+      const uint32_t G = (uint32_t)prod;
+      __syncthreads();
       if (tid == 0) {
-        a.status[hd.frame] |= MOCAP_ST_CAND_OVERFLOW_;
-        a.n_out[hd.frame] = 0;
+        s_best = 0x7ff0000000000000ull;
+        s_gkey = ~0ull;  // (reused: the smallest candidate index among the groups that hold the best error)
+      }
+      __syncthreads();
+      double be = inf, bX[3] = {0, 0, 0};
+      uint32_t bg = 0;
+      for (uint32_t g = (uint32_t)tid; g < G; g += kHvThreads) {
+        // digits of g: the first multi-hit camera is the fastest one (helpers.py:394-400 order, as in frame_kernel.hip)
+        uint32_t rem = g;
+        for (int j = 0; j < m; j++) {
+          const uint32_t n = s_n[s_dcam[j]];
+          uint32_t qd, d;
+          divmod_small(rem, n, qd, d);
+          rem = qd;
+          s_dg[j][tid] = (uint8_t)d;
+        }
+        auto obs = [&](int c, double& x, double& y) -> bool {
+          const int n = s_n[c];
+          if (!n) return false;
+          const int d = n > 1 ? s_dg[s_lvl[c]][tid] : 0;
+          const float2 w = fb[(size_t)c * M + hl[(size_t)c * Hs + d]];
+          x = (double)w.x;
+          y = (double)w.y;
+          return true;
+        };
+        double X[3], e = inf;
+        const double bound = __longlong_as_double((long long)s_best);
+        triangulate_and_score<true, true, F32R, 1, false>(a.cv, obs, obs, X, e, bound, ec);
+        if (e < be) {  // strict <: the first minimum of this lane's ascending run
+          be = e;
+          bg = g;
+          bX[0] = X[0]; bX[1] = X[1]; bX[2] = X[2];
+          atomicMin(&s_best, (unsigned long long)__double_as_longlong(e));
+        }
+      }
+      __syncthreads();
+      const double ebest = __longlong_as_double((long long)s_best);
+      if (be == ebest && be < inf) atomicMin(&s_gkey, (unsigned long long)bg);
+      __syncthreads();
+      if (ebest < e00 && be == ebest && (unsigned long long)bg == s_gkey) {  // (one lane; group 0 stands on a tie: it is the smallest index)
+        FrameArgs fa;
+        fa.xyz = a.xyz;
+        fa.world = a.world;
+        store_point(fa, o, bX);
+        a.err[o] = ebest;
+        uint32_t rem = bg;
+        for (int j = 0; j < m; j++) {
+          uint32_t qd, d;
+          divmod_small(rem, (uint32_t)s_n[s_dcam[j]], qd, d);
+          rem = qd;
+          s_dg[j][tid] = (uint8_t)d;
+        }
+        for (int c = 0; c < C; c++) {
+          const int n = s_n[c];
+          a.corr[o * C + c] = n ? (int16_t)hl[(size_t)c * Hs + (n > 1 ? s_dg[s_lvl[c]][tid] : 0)] : (int16_t)-1;
+        }
       }
       continue;
     }

@@ -102,6 +102,7 @@ struct HeavyArgs {
   unsigned char* ws;           // [grid][ws_stride] frontier workspace
   size_t ws_stride;
   int ncap;                    // nodes per frontier buffer
+  int64_t enum_cap;            // a root the search gives up on is enumerated in place when its product is at most this
   int debug;                   // MOCAP_HEAVY_DEBUG: one printf per root
 };
 size_t heavy_bb_ws_bytes(int ncap);

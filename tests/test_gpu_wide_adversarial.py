@@ -219,18 +219,24 @@ def test_heavy_root_search_equals_the_enumeration(core):
     plain = core.match_triangulate(blobs, counts, gate_px=synth.STRESS_GATE_PX, K_max=384, G_cap=1 << 20)
     ok = plain["status"] == 0
     assert ok.sum() >= 20
-    os.environ["MOCAP_RESUBMIT_G_CAP"] = "8"
-    try:
-        auto = core.match_triangulate_auto(blobs, counts, gate_px=synth.STRESS_GATE_PX, K_max=384, G_cap=1)
-    finally:
-        del os.environ["MOCAP_RESUBMIT_G_CAP"]
-    assert auto["resubmitted"] >= 20 and not auto["status"][ok].any()
-    assert np.array_equal(auto["n_out"][ok], plain["n_out"][ok])
     valid = (np.arange(384)[None, :] < plain["n_out"][:, None]) & ok[:, None]
-    assert np.array_equal(auto["corr"][valid], plain["corr"][valid])
-    assert np.array_equal(auto["xyz"][valid], plain["xyz"][valid]) and np.array_equal(auto["err"][valid], plain["err"][valid])
-    # the search did run: roots with a choice count one candidate each now
-    assert (auto["n_cand"][ok] < plain["n_cand"][ok]).any()
+    # second leg: a frontier of 64 nodes -- the search gives up on most of these roots and its fall-back enumerates them in
+    # place (products up to 2^20): the same bits again
+    for ncap in (None, "64"):
+        os.environ["MOCAP_RESUBMIT_G_CAP"] = "8"
+        if ncap:
+            os.environ["MOCAP_HEAVY_NCAP"] = ncap
+        try:
+            auto = core.match_triangulate_auto(blobs, counts, gate_px=synth.STRESS_GATE_PX, K_max=384, G_cap=1)
+        finally:
+            del os.environ["MOCAP_RESUBMIT_G_CAP"]
+            os.environ.pop("MOCAP_HEAVY_NCAP", None)
+        assert auto["resubmitted"] >= 20 and not auto["status"][ok].any(), ncap
+        assert np.array_equal(auto["n_out"][ok], plain["n_out"][ok])
+        assert np.array_equal(auto["corr"][valid], plain["corr"][valid]), ncap
+        assert np.array_equal(auto["xyz"][valid], plain["xyz"][valid]) and np.array_equal(auto["err"][valid], plain["err"][valid]), ncap
+        # the search did run: roots with a choice count one candidate each now
+        assert (auto["n_cand"][ok] < plain["n_cand"][ok]).any()
 
 
 def test_two_markers_behind_each_other_as_seen_from_camera_0(core):
