@@ -781,6 +781,9 @@ struct BBState {
         } else if (n > 1) {
           if (ka >= skip) {
             uint32_t qd, dgt;
+#if MOCAP_BB_TINYDIV
+            if (rem < 8192u) divmod_tiny(rem, n, qd, dgt); else  // (the usual case for every lane of the wave: one path runs)
+#endif
             divmod_small(rem, n, qd, dgt);
             rem = qd;
             k = hr[(size_t)c * M + dgt];
@@ -964,6 +967,13 @@ struct BBState {
     if (bound_tests) {
       // ---- 1. seeds: s1 of every block (cached for the tests); per root the block with the largest s1 (smallest
       // bound) almost always holds the winner
+      // (a frame of at most T blocks -- the usual one -- takes one trip through this loop: the lane that turns out to hold its
+      // root's seed block queues it itself afterwards, with the blob indices it has, instead of one lane per root decoding them again)
+      int my_r = -1;
+      uint32_t my_gh = 0;
+      unsigned long long my_key = 0ull;
+      Packed<CW> my_pk;
+      my_pk.clear();
       for (uint32_t s0 = 0; s0 < nblocks; s0 += T) {
         const uint32_t b = s0 + (uint32_t)tid;
         if (s0 + (uint32_t)(wave * 64) >= nblocks) continue;  // wave-uniform
@@ -991,10 +1001,22 @@ struct BBState {
             s1 = (float)fmin(s1d, 3e38);
           }
           if (b < (uint32_t)ncache) bcache[b] = make_float2(__double2float_ru(s1d), __double2float_ru(tr));
-          atomicMax(&seedkey[r], ((unsigned long long)__float_as_uint(s1) << 32) | (unsigned long long)(0xFFFFFFFFu - gh));
+          my_key = ((unsigned long long)__float_as_uint(s1) << 32) | (unsigned long long)(0xFFFFFFFFu - gh);
+          my_r = r;
+          my_gh = gh;
+          my_pk = pk;
+          atomicMax(&seedkey[r], my_key);
         }
       }
       __syncthreads();
+#if !MOCAP_BB_PROBE
+      if (nblocks <= (uint32_t)T) {
+        if (my_r >= 0 && seedkey[my_r] == my_key) {  // (keys are unique inside a root: exactly one lane per root with blocks)
+          seedgh[my_r] = my_gh;
+          push_block(my_r, my_gh, my_pk);
+        }
+      } else
+#endif
       for (int r = tid; r < nroots; r += T) {
         if (bnb[r]) {
           const uint32_t gh = 0xFFFFFFFFu - (uint32_t)seedkey[r];
@@ -1309,8 +1331,13 @@ struct BBState {
       } else if (c > rc) {
         const uint32_t n = nh[(size_t)r * C + c];
         if (n) {
-          uint32_t qd, dgt;
-          divmod_small(rem, n, qd, dgt);
+          uint32_t qd = rem, dgt = 0;
+          if (n > 1) {  // (a single hit is digit 0 of radix 1: nothing to divide)
+#if MOCAP_BB_TINYDIV
+            if (rem < 8192u) divmod_tiny(rem, n, qd, dgt); else
+#endif
+            divmod_small(rem, n, qd, dgt);
+          }
           s = (int16_t)hits[((size_t)r * C + c) * M + dgt];
           rem = qd;
         }
