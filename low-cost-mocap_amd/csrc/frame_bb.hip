@@ -89,7 +89,7 @@ constexpr int kBBRecs = kBBThreads + 64;  // surviving blocks queued between two
 #endif
 struct BBLayout {
   size_t bxy, bxy_nx, cnt_nx, bt, rbound, seedkey, slot_key, slot_x, claimw, recs, rpk, scr, scr_bytes, goff, gcnt, outslot, boff, bnb, seedgh, slot_g, cnt,
-      misc, bpl, nh, hits, act, root_blob, root_cam, nact, bnl, bv, bcache, total;
+      misc, bpl, nh, hits, act, root_blob, root_cam, nact, bnl, bv, bcache, bpk, total;
   int ncache;
   __host__ __device__ static size_t al(size_t x, size_t a) { return (x + a - 1) / a * a; }
   __host__ __device__ BBLayout(int C, int M, int R, int CW) {
@@ -135,12 +135,14 @@ struct BBLayout {
     bv = take((size_t)R, 1);
     // cache of the blocks' bounds (seed pass -> test pass: {s1, trace} rounded UP to float, 8 bytes per block): as many
     // entries as fit below the next occupancy step of the 160 KB LDS (5, 4, 3, ... workgroups per CU), at most 1024
+    // (round 5: + the block's blob indices, 8 CW bytes: a surviving block is queued from the cache alone -- no second decode)
     bcache = take(0, 8);
     ncache = 0;
+    const size_t per_entry = 8 + 8 * (size_t)CW;
     for (int per_cu = 5; per_cu >= 1; per_cu--) {
       const size_t lim = ((size_t)160 * 1024 / per_cu - MOCAP_BB_LDS_SLACK) / 256 * 256;  // (slack: allocation granule, other LDS users)
-      if (lim >= o + 8 * 64) {
-        const size_t n = (lim - o) / 8;
+      if (lim >= o + per_entry * 64) {
+        const size_t n = (lim - o) / per_entry;
         ncache = (int)(n > 1024 ? 1024 : n);
         break;
       }
@@ -149,6 +151,8 @@ struct BBLayout {
     ncache = 0;
 #endif
     o += 8 * (size_t)ncache;
+    bpk = o;
+    o += 8 * (size_t)CW * ncache;
     total = al(o, 16);
   }
 };
@@ -171,7 +175,7 @@ static int frame_bb_root_slots(int C, int M, int R) {
 size_t frame_bb_lds_bytes(int C, int M, int R) { return BBLayout(C, M, frame_bb_root_slots(C, M, R), C <= 8 ? 1 : 2).total; }
 static size_t frame_bb_lds_bytes_min(int C, int M, int R) {
   const BBLayout L(C, M, frame_bb_root_slots(C, M, R), C <= 8 ? 1 : 2);
-  return L.total - 8 * (size_t)L.ncache;
+  return L.total - (8 + 8 * (size_t)(C <= 8 ? 1 : 2)) * (size_t)L.ncache;
 }
 bool frame_bb_fits(int C, int M, int R) {
   // blob indices and root numbers are bytes (0xFF = none); a (root, blob) group is at most one wave; the expanded
@@ -249,6 +253,7 @@ struct BBState {
   uint16_t* bpl;
   uint8_t *nh, *hits, *act, *root_blob, *root_cam, *nact, *bnl, *bv;
   float2* bcache;      // [ncache] {s1, trace} of the first blocks, rounded up (BBLayout::bcache)
+  unsigned long long* bpk;  // [ncache][CW] ... and their partial groups' blob indices
   int ncache;
   unsigned char* scr;  // phase B scratch = the search's records and slots (BBLayout::scr)
   size_t scr_bytes;
@@ -300,6 +305,7 @@ struct BBState {
     scr = smem + L.scr;
     scr_bytes = L.scr_bytes;
     bcache = (float2*)(smem + L.bcache);
+    bpk = (unsigned long long*)(smem + L.bpk);
     ncache = L.ncache;
   }
 
@@ -1000,7 +1006,11 @@ struct BBState {
             s1d = eigcut_s1_shifted(B, c0, tr);
             s1 = (float)fmin(s1d, 3e38);
           }
-          if (b < (uint32_t)ncache) bcache[b] = make_float2(__double2float_ru(s1d), __double2float_ru(tr));
+          if (b < (uint32_t)ncache) {
+            bcache[b] = make_float2(__double2float_ru(s1d), __double2float_ru(tr));
+#pragma unroll
+            for (int k = 0; k < CW; k++) bpk[(size_t)b * CW + k] = pk.w[k];
+          }
           my_key = ((unsigned long long)__float_as_uint(s1) << 32) | (unsigned long long)(0xFFFFFFFFu - gh);
           my_r = r;
           my_gh = gh;
@@ -1239,17 +1249,25 @@ struct BBState {
       b0 += T;
       int r = 0;
       if (bw < nblocks) r = root_of_block(bw, b < nblocks ? b : nblocks - 1);  // wave-uniform branch
+      // The tests first, the pushes behind a barrier.  Every lane read the queue counter at the top of this iteration; a wave that
+      // is through its tests early must not bump it before the slowest wave has read it -- that wave would see a different queue,
+      // take the other branch of the flush decision and the workgroup would fall apart (a window of a few dozen instructions
+      // when the cached blocks need no decode: found in round 5 as 1 wrong frame in ~10^4 with 2-candidate blocks).
+      bool do_push = false;
+      uint32_t gh = 0;
+      Packed<CW> pk;
+      pk.clear();
       if (b < nblocks) {
-        const uint32_t gh = b - boff[r];
+        gh = b - boff[r];
         if (gh != seedgh[r]) {
           double B[10], tr;
-          Packed<CW> pk;
           bool survive = true;
           if (bound_tests && b < (uint32_t)ncache) {
             // {s1, trace} from the seed pass, rounded up: a larger s1 or trace only ever keeps a block (safe side)
             const float2 sc = bcache[b];
             survive = !dropped(r, (double)sc.x, (double)sc.y);
-            if (survive) group_matrix<false>(r, gh, bnl[r], B, pk);
+#pragma unroll
+            for (int k = 0; k < CW; k++) pk.w[k] = bpk[(size_t)b * CW + k];
           } else if (bound_tests) {
             const int v = group_matrix<true>(r, gh, bnl[r], B, pk);
             if (v >= 2) {
@@ -1259,7 +1277,7 @@ struct BBState {
           } else {
             group_matrix<false>(r, gh, bnl[r], B, pk);
           }
-          if (survive) push_block(r, gh, pk);
+          do_push = survive;
 #ifdef MOCAP_DEBUG_EIGCHECK  // self-check build: EVERY candidate of a dropped block is evaluated in full against the bound it was dropped on
           if (!survive) {
             const double bound = __longlong_as_double((long long)rbound[r]);
@@ -1284,6 +1302,8 @@ struct BBState {
 #endif
         }
       }
+      __syncthreads();
+      if (do_push) push_block(r, gh, pk);
       __syncthreads();
     }
     __syncthreads();

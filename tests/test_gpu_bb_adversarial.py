@@ -207,6 +207,30 @@ def test_random_rigs_hypothesis(searchers):
     run()
 
 
+def test_two_candidate_blocks_on_heavy_frames_repeatedly(searchers):
+    """Regression for a race of the search's queue (round 5): every lane reads the queue counter at the top of a test
+    round; a wave that was through its block tests early (cached bounds, nothing to decode) could bump the counter before the
+    slowest wave had read it -- that wave then took the other branch of the flush decision.  It showed with 2-candidate
+    blocks (a thousand blocks per heavy frame: many test rounds per frame) as one wrong frame in a few runs of 1 500; the
+    pushes now wait behind a barrier.  30 repetitions, bit for bit against the exhaustive walk each time."""
+    rig = synth.ring_rig(8)
+    blobs, counts, _ = synth.make_blob_stream(rig, 1500, 16, seed=7)
+    ex = searchers["exhaustive"]
+    ex.set_cameras(rig["K"], rig["R"], rig["t"])
+    base = ex.match_triangulate(blobs, counts, K_max=48)
+    valid = np.arange(48)[None, :] < base["n_out"][:, None]
+    tiny = _ctx({"MOCAP_BB_PL": "2"})
+    try:
+        tiny.set_cameras(rig["K"], rig["R"], rig["t"])
+        for rep in range(30):
+            res = tiny.match_triangulate(blobs, counts, K_max=48)
+            assert tiny.last_frame_kernel().startswith("frame_bb_kernel")
+            for key in ("xyz", "err", "corr"):
+                assert np.array_equal(res[key][valid], base[key][valid]), (rep, key)
+    finally:
+        tiny.close()
+
+
 def test_the_reference_seam_reaches_the_search_kernel(core):
     """helpers.find_point_correspondance_and_object_points (the mirror of helpers.py:339, what the live loop calls at
     helpers.py:94) passes no K_max: the default min(C M, 64) and the re-submit capacities must land in the
