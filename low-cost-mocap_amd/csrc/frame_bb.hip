@@ -65,6 +65,9 @@
 #ifndef MOCAP_BB_PROBE
 #define MOCAP_BB_PROBE 0  // seed blocks: one factorisation per candidate, the best one evaluated as the root's probe, the rest tested against it (measured: 5.27 -> 5.9-6.2 ms, see below; kept for the record, compiled out)
 #endif
+#ifndef MOCAP_BB_PREMATCH
+#define MOCAP_BB_PREMATCH 1  // the new roots' pairs matched all at once before the chain, which shrinks to bookkeeping
+#endif
 #ifndef MOCAP_BB_SPEC_COMPACT
 #define MOCAP_BB_SPEC_COMPACT 1  // speculative lines only for blobs the camera-0 roots left unclaimed
 #endif
@@ -470,62 +473,120 @@ struct BBState {
     // pair ~10 per pair.  Pass 1 collects the gated blobs of the pair as a bit mask (M <= 64); pass 2 extracts them in
     // (distance, index) order by repeated minimum -- hit lists are a handful long, distances are simply recomputed
     // (same expression, same bits).  Waves take 64 pairs each: full lanes, as few waves as possible.
+    // Round 5 (MOCAP_BB_PREMATCH): a second stage of the same pass for the PROVISIONAL roots -- the blobs of cameras 1 .. C-1
+    // the camera-0 roots left unclaimed (only they can become roots, helpers.py:402-406): their pairs with the cameras after
+    // them are matched here, all at once on one lane each, into staging rows (the search's dead arrays), and the chain over
+    // the cameras below shrinks to bookkeeping: which provisional roots are real (not claimed by a root created before
+    // them) -- a wave-wide OR of claim masks per camera.  Before, wave 0 matched the new roots camera by camera while the
+    // other waves waited: 2 k dependent instructions of the frame's ~8 k deep critical path.  A frame whose provisional roots
+    // do not fit the staging rows (or one wave) takes the chain as before.
+    auto U_of = [&](int j) {  // provisional blobs of camera j (valid behind stage 0's barrier)
+      const int n = cnt[j];
+      return ~claimw[j] & (n >= 64 ? ~0ull : ((1ull << n) - 1ull));
+    };
+    int n_prov = 0, n_ppairs = 0;
+    bool pre = false;
+    uint8_t* nh_s = nullptr;
+    uint8_t* hits_s = nullptr;
+    unsigned long long* pclaim = (unsigned long long*)scr;
     {
-      const int NP = (MOCAP_BB_DEBUG_SKIP & 4) ? 0 : n0 * (C - 1);
       int Mmax = 0;
       for (int c = 1; c < C; c++) Mmax = cnt[c] > Mmax ? cnt[c] : Mmax;  // wave-uniform
-      for (int base = wave * 64; base < NP; base += W * 64) {
-        const int pi = base + lane;
-        const bool have = pi < NP;
-        int r = 0, i = 1, Mi = 0;
-        Line L = {0, 0, 0, 1, 1};
-        if (have) {
-          r = pi / (C - 1);
-          i = 1 + (pi - r * (C - 1));
-          Mi = cnt[i];
-          L = epiline(r, i);
+#pragma nounroll
+      for (int stage_ = 0; stage_ < 2; stage_++) {
+        const int stage = __builtin_amdgcn_readfirstlane(stage_);  // (opaque: one copy of the pair code)
+        int NP = (MOCAP_BB_DEBUG_SKIP & 4) ? 0 : n0 * (C - 1);
+        if (stage == 1) {
+          __syncthreads();  // the camera-0 roots' claims are complete
+          for (int j = 1; j < C; j++) {
+            const int np = __popcll(U_of(j));
+            n_prov += np;
+            n_ppairs += np * (C - 1 - j);
+          }
+          pre = MOCAP_BB_PREMATCH && !MOCAP_BB_DEBUG_SKIP && n_prov <= 64 && (size_t)n_prov * C * (8 + 1 + (size_t)M) <= scr_bytes;
+          if (!pre) break;
+          nh_s = (uint8_t*)(pclaim + (size_t)n_prov * C);
+          hits_s = nh_s + (size_t)n_prov * C;
+          NP = n_ppairs;
         }
-        const float2* pts = bxy + (size_t)i * M;
-        auto dist = [&](int k) {
-          const float2 pt = pts[k];
-          return div_by(fabs(L.a * (double)pt.x + L.b * (double)pt.y + L.c), L.den, L.rden);  // helpers.py:373
-        };
-        unsigned long long hm = 0ull;
-        for (int k = 0; k < Mmax; k++)
-          if (k < Mi && dist(k) < p.gate_px) hm |= 1ull << k;  // strict <, helpers.py:375,383
-        if (have) nh[(size_t)r * C + i] = (uint8_t)__popcll(hm);
-        // order by (distance, blob index): a stable order where NumPy's default argsort is not (helpers.py:384;
-        // documented deviation); the closest hit's coordinates claim every blob that has them (helpers.py:391)
-        unsigned long long rem = hm, claim = 0ull;
-        uint8_t* hl = hits + ((size_t)r * C + i) * M;
-        int pos = 0;
-        float2 p0 = make_float2(0.f, 0.f);
-        while (__ballot(rem != 0ull)) {
-          if (rem) {
-            double bd = __builtin_huge_val();
-            int bk = 0;
-            for (unsigned long long t = rem; t; t &= t - 1) {  // ascending index, strict <: ties keep the smaller index
-              const int k = __ffsll((long long)t) - 1;
-              const double d = dist(k);
-              if (d < bd) {
-                bd = d;
-                bk = k;
+        for (int base = wave * 64; base < NP; base += W * 64) {
+          const int pi = base + lane;
+          const bool have = pi < NP;
+          int r = 0, i = 1, Mi = 0;   // r: row the pair writes (stage 0: the root; stage 1: the provisional root's staging row)
+          Line L = {0, 0, 0, 1, 1};
+          if (have) {
+            if (stage == 0) {
+              r = pi / (C - 1);
+              i = 1 + (pi - r * (C - 1));
+              L = epiline(r, i);
+            } else {
+              int j = 1, acc = 0, pb = 0, span = C - 2;
+              unsigned long long U = 0ull;
+              for (; j <= C - 2; j++) {
+                span = C - 1 - j;
+                U = U_of(j);
+                const int nj = __popcll(U) * span;
+                if (pi < acc + nj) break;
+                acc += nj;
+                pb += __popcll(U);
               }
+              uint32_t ord, off;
+              divmod_tiny((uint32_t)(pi - acc), (uint32_t)span, ord, off);  // (< 64 x 15, span <= 14)
+              for (uint32_t t = 0; t < ord; t++) U &= U - 1;
+              const int k = __ffsll((long long)U) - 1;
+              i = j + 1 + (int)off;
+              r = pb + (int)ord;
+              L = epiline_of(j, k, i);
             }
-            hl[pos] = (uint8_t)bk;
-            if (pos == 0) {
-              p0 = pts[bk];
-              for (unsigned long long t = hm; t; t &= t - 1) {
+            Mi = cnt[i];
+          }
+          const float2* pts = bxy + (size_t)i * M;
+          auto dist = [&](int k) {
+            const float2 pt = pts[k];
+            return div_by(fabs(L.a * (double)pt.x + L.b * (double)pt.y + L.c), L.den, L.rden);  // helpers.py:373
+          };
+          unsigned long long hm = 0ull;
+          for (int k = 0; k < Mmax; k++)
+            if (k < Mi && dist(k) < p.gate_px) hm |= 1ull << k;  // strict <, helpers.py:375,383
+          uint8_t* nhp = stage == 0 ? nh : nh_s;
+          uint8_t* hl = (stage == 0 ? hits : hits_s) + ((size_t)r * C + i) * M;
+          if (have) nhp[(size_t)r * C + i] = (uint8_t)__popcll(hm);
+          // order by (distance, blob index): a stable order where NumPy's default argsort is not (helpers.py:384;
+          // documented deviation); the closest hit's coordinates claim every blob that has them (helpers.py:391)
+          unsigned long long rem = hm, claim = 0ull;
+          int pos = 0;
+          float2 p0 = make_float2(0.f, 0.f);
+          while (__ballot(rem != 0ull)) {
+            if (rem) {
+              double bd = __builtin_huge_val();
+              int bk = 0;
+              for (unsigned long long t = rem; t; t &= t - 1) {  // ascending index, strict <: ties keep the smaller index
                 const int k = __ffsll((long long)t) - 1;
-                const float2 q = pts[k];
-                if (q.x == p0.x && q.y == p0.y) claim |= 1ull << k;
+                const double d = dist(k);
+                if (d < bd) {
+                  bd = d;
+                  bk = k;
+                }
               }
+              hl[pos] = (uint8_t)bk;
+              if (pos == 0) {
+                p0 = pts[bk];
+                for (unsigned long long t = hm; t; t &= t - 1) {
+                  const int k = __ffsll((long long)t) - 1;
+                  const float2 q = pts[k];
+                  if (q.x == p0.x && q.y == p0.y) claim |= 1ull << k;
+                }
+              }
+              rem &= ~(1ull << bk);
+              pos++;
             }
-            rem &= ~(1ull << bk);
-            pos++;
+          }
+          if (stage == 0) {
+            if (claim) atomicOr(&claimw[i], claim);
+          } else if (have) {
+            pclaim[(size_t)r * C + i] = claim;
           }
         }
-        if (claim) atomicOr(&claimw[i], claim);
       }
     }
     // Speculative lines.  Which blobs of cameras 1 .. C-2 become roots is only known inside the chain below, but their
@@ -544,8 +605,7 @@ struct BBState {
     // (helpers.py:402-406), and on the bench stream the camera-0 roots claim ~14 of every 16.  One more barrier (the claim
     // words are complete behind it), then one lane per (unclaimed blob, later camera) pair: ~40 lines on one wave instead of
     // 336 on all four (two passes).  The table keeps its layout, the chain its reads.
-    __syncthreads();
-    if (spec) {
+    if (spec && !pre) {  // (behind stage 0's barrier: the claim words are complete)
       int tot = 0;
       for (int j = 1; j <= C - 2; j++) {
         const int n = cnt[j];
@@ -593,7 +653,50 @@ struct BBState {
     }
 #endif
     __syncthreads();
-    if (wave == 0) {
+    if (wave == 0 && pre) {
+      // B1, pre-matched: lane p <-> provisional root p = the p-th unclaimed blob of cameras 1 .. C-1 in (camera, blob) order.
+      // A provisional root is real when no root created at an earlier camera claims its blob (helpers.py:391,402-406).
+      int jp = 0, kp = 0;
+      if (lane < n_prov) {
+        int acc = 0;
+        unsigned long long U = 0ull;
+        for (jp = 1; jp < C; jp++) {
+          U = U_of(jp);
+          const int np = __popcll(U);
+          if (lane < acc + np) break;
+          acc += np;
+        }
+        for (int t = 0; t < lane - acc; t++) U &= U - 1;
+        kp = __ffsll((long long)U) - 1;
+      }
+      bool real = false;
+      for (int i = 1; i < C; i++) {
+        unsigned long long m = (lane < n_prov && real && jp < i) ? pclaim[(size_t)lane * C + i] : 0ull;
+        uint32_t mlo = (uint32_t)m, mhi = (uint32_t)(m >> 32);
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+          mlo |= (uint32_t)__shfl_xor((int)mlo, d);
+          mhi |= (uint32_t)__shfl_xor((int)mhi, d);
+        }
+        m = (((unsigned long long)mhi << 32) | mlo) | claimw[i];
+        if (lane < n_prov && jp == i) real = !((m >> kp) & 1ull);
+      }
+      const unsigned long long rm = __ballot(real);
+      const int rank = __popcll(rm & ((1ull << lane) - 1ull));
+      int n_roots = n0 + __popcll(rm);
+      if (real && n0 + rank < R) {
+        root_cam[n0 + rank] = (uint8_t)jp;
+        root_blob[n0 + rank] = (uint8_t)kp;
+        bnl[rank] = (uint8_t)lane;  // (bnl is dead until phase C: the staging row of the rank-th new root)
+      }
+      if (lane == 0) {
+        if (n_roots > R) {
+          misc[MI_STATUS] |= MOCAP_ST_ROOT_OVERFLOW_;
+          n_roots = R;
+        }
+        misc[MI_NROOTS] = n_roots;
+      }
+    } else if (wave == 0) {
       // B1: the chain over the cameras -- only the roots created on the way take part (camera-0 roots are done).
       // State in registers: lane l <-> camera l (blob count, blobs claimed so far), lane l <-> the l-th new root.
       const int cntL = lane < C ? cnt[lane] : 0;
@@ -682,6 +785,22 @@ struct BBState {
       }
     }
     __syncthreads();
+    if (pre) {
+      // the real provisional roots' rows leave the staging area for their final place: one lane per (new root, camera)
+      const int n_new = misc[MI_NROOTS] - n0;
+      for (int idx = tid; idx < n_new * C; idx += T) {
+        const int q = idx / C, c = idx - q * C;
+        const int r = n0 + q, ps = bnl[q];
+        if (c > (int)root_cam[r]) {
+          const int n = nh_s[(size_t)ps * C + c];
+          nh[(size_t)r * C + c] = (uint8_t)n;
+          const uint8_t* src = hits_s + ((size_t)ps * C + c) * M;
+          uint8_t* dst = hits + ((size_t)r * C + c) * M;
+          for (int t = 0; t < n; t++) dst[t] = src[t];
+        }
+      }
+      __syncthreads();  // (the staging rows are the search's arrays: phase C initialises them next)
+    }
 
     // C: candidate counts per root
     const int nroots = misc[MI_NROOTS];
