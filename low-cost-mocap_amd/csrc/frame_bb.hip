@@ -65,6 +65,9 @@
 #ifndef MOCAP_BB_PROBE
 #define MOCAP_BB_PROBE 0  // seed blocks: one factorisation per candidate, the best one evaluated as the root's probe, the rest tested against it (measured: 5.27 -> 5.9-6.2 ms, see below; kept for the record, compiled out)
 #endif
+#ifndef MOCAP_BB_WALK_UNROLL
+#define MOCAP_BB_WALK_UNROLL 4  // (1: 4.79, 4 and 8: 4.70 ms per 100 k frames)
+#endif
 #ifndef MOCAP_BB_PREMATCH
 #define MOCAP_BB_PREMATCH 1  // the new roots' pairs matched all at once before the chain, which shrinks to bookkeeping
 #endif
@@ -497,6 +500,10 @@ struct BBState {
         const int stage = __builtin_amdgcn_readfirstlane(stage_);  // (opaque: one copy of the pair code)
         int NP = (MOCAP_BB_DEBUG_SKIP & 4) ? 0 : n0 * (C - 1);
         if (stage == 1) {
+          // (explicit: the compiler emitted THIS barrier without the s_waitcnt lgkmcnt(0) every other one has -- a wave could
+          // read the claim words while another wave's ds_or of stage 0 was still queued: provisional sets that differed between
+          // waves, one wrong frame in ~10^5)
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           __syncthreads();  // the camera-0 roots' claims are complete
           for (int j = 1; j < C; j++) {
             const int np = __popcll(U_of(j));
@@ -546,7 +553,10 @@ struct BBState {
             return div_by(fabs(L.a * (double)pt.x + L.b * (double)pt.y + L.c), L.den, L.rden);  // helpers.py:373
           };
           unsigned long long hm = 0ull;
-          for (int k = 0; k < Mmax; k++)
+#if MOCAP_BB_WALK_UNROLL > 1
+#pragma unroll MOCAP_BB_WALK_UNROLL
+#endif
+          for (int k = 0; k < Mmax; k++)  // (independent iterations: unrolled, their latencies overlap -- the stage runs on one or two waves)
             if (k < Mi && dist(k) < p.gate_px) hm |= 1ull << k;  // strict <, helpers.py:375,383
           uint8_t* nhp = stage == 0 ? nh : nh_s;
           uint8_t* hl = (stage == 0 ? hits : hits_s) + ((size_t)r * C + i) * M;
