@@ -679,17 +679,20 @@ struct BBState {
         for (int t = 0; t < lane - acc; t++) U &= U - 1;
         kp = __ffsll((long long)U) - 1;
       }
+      // Camera by camera: the provisional roots of camera i look their blob up in the camera's claim word; the real ones add
+      // their own claims to the words of the cameras after them (the claim words end up as the reference's "claimed" sets).
+      // One LDS read and a handful of atomics per camera -- a wave-wide OR by shuffles was 12 dependent cross-lane operations per camera.
       bool real = false;
       for (int i = 1; i < C; i++) {
-        unsigned long long m = (lane < n_prov && real && jp < i) ? pclaim[(size_t)lane * C + i] : 0ull;
-        uint32_t mlo = (uint32_t)m, mhi = (uint32_t)(m >> 32);
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-          mlo |= (uint32_t)__shfl_xor((int)mlo, d);
-          mhi |= (uint32_t)__shfl_xor((int)mhi, d);
+        wave_lds_sync();
+        if (lane < n_prov && jp == i) {
+          real = !((claimw[i] >> kp) & 1ull);
+          if (real)
+            for (int c = i + 1; c < C; c++) {
+              const unsigned long long m = pclaim[(size_t)lane * C + c];
+              if (m) atomicOr(&claimw[c], m);
+            }
         }
-        m = (((unsigned long long)mhi << 32) | mlo) | claimw[i];
-        if (lane < n_prov && jp == i) real = !((m >> kp) & 1ull);
       }
       const unsigned long long rm = __ballot(real);
       const int rank = __popcll(rm & ((1ull << lane) - 1ull));

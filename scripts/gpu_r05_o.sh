@@ -1,7 +1,7 @@
 #!/bin/bash
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
-for lib in "" _u4; do export MOCAP_CORE_LIB=$PWD/low-cost-mocap_amd/lib/libmocap_core$lib.so; echo "== lib $lib"; timeout 600 python - <<'PY' 2>&1 | grep -v amdgpu
+for lib in ""; do export MOCAP_CORE_LIB=$PWD/low-cost-mocap_amd/lib/libmocap_core$lib.so; echo "== lib $lib"; timeout 600 python - <<'PY' 2>&1 | grep -v amdgpu
 import os, sys, numpy as np
 sys.path.insert(0, "low-cost-mocap_amd")
 from mocap_core import capi, synth
@@ -24,7 +24,7 @@ base = ex.match_triangulate(blobs, counts, K_max=K)
 valid = np.arange(K)[None, :] < base["n_out"][:, None]
 c.set_cameras(rig["K"], rig["R"], rig["t"])
 nbad = 0
-for rep in range(60):
+for rep in range(40):
     res = c.match_triangulate(blobs, counts, K_max=K)
     same_n = np.array_equal(res["n_out"], base["n_out"])
     bad = [key for key in ("xyz", "err", "corr") if not np.array_equal(res[key][valid], base[key][valid])]
@@ -35,6 +35,6 @@ for rep in range(60):
             for f in fr:
                 ks = np.nonzero((res["corr"][f] != base["corr"][f]).any(-1) & valid[f])[0]
                 print("rep", rep, "same_n", same_n, "frame", f, "n_out", res["n_out"][f], base["n_out"][f], "cand", base["n_cand"][f], "slots", ks[:6], "got", res["corr"][f, ks[0]], "want", base["corr"][f, ks[0]], "err", res["err"][f, ks[0]], base["err"][f, ks[0]])
-print("bad runs", nbad, "of 60")
+print("bad runs", nbad, "of 40")
 PY
 done
