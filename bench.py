@@ -566,19 +566,8 @@ def ba_bench(core, iters=200, cpu=True):
                             "inside mocap_ba_residuals (marshalling, GPU, copy back); scipy_own_s = the rest: SciPy's own "
                             "per-iteration work on the host (SVD of the m x n Jacobian, Cauchy scaling, the step) which "
                             "bit-identical poses oblige this mode to keep"}
-    # the alternative DESIGN 3.4 weighs against the host subproblem, measured: one wave's time per shift of the secular
-    # iteration on the device (42 x 42 Cholesky + three triangular solves; 2-4 shifts per subproblem)
-    try:
-        dsub = core.tr_device_bench(reps=200)
-        dsub["host_whole_subproblem_us"] = prof["host_tr_us"]
-        dsub["note"] = ("mocap_debug_tr_device_bench (csrc/tr_device_bench.hip): ONE wave, rows in registers, pivots broadcast "
-                        "with v_readlane; a device-resident loop would pay us_per_shift 2-4 times per iteration and save the "
-                        "hand-over (launch_to_result_on_host - gpu_linearisation) but not the host's host_whole_subproblem_us "
-                        "unless 2-4 x us_per_shift is below it")
-    except Exception as e:  # pragma: no cover
-        dsub = {"error": repr(e)}
     return {"metric": "BA iters/sec (8 cams, 1k pts)", "value": info["iterations"] / dt, "measured_mode": "resident",
-            "default_mode": default_mode, "device_subproblem": dsub, "roofline": roofline,
+            "default_mode": default_mode, "roofline": roofline,
             "cpu_baseline": out_cpu, "parity": ba_parity(core),
             "iterations": info["iterations"], "nfev": info["nfev"], "ms_per_iter": 1e3 * dt / max(info["iterations"], 1),
             "runs_ms": [round(1e3 * r[0], 2) for r in runs], "statistic": "median of 5 solves", "warmup_solves": n_warm,

@@ -373,15 +373,6 @@ int mocap_set_ba_progress(mocap_ctx* ctx, void (*cb)(const double* x, int n, voi
 int mocap_ba_profile(mocap_ctx* ctx, const double* x, int64_t N, const double* obs, int f32_residuals,
                      int use_cauchy, int reps, double* out);
 
-/* mocap_debug_tr_device_bench: measurement aid (bench.py's `ba.device_subproblem`), not on the product path.  What ONE
- * wave needs per value of the shift in the trust-region subproblem's secular iteration at the metric's size (42 live
- * parameters): Cholesky of B + a I, then L y = -g, L^T p = y, L w = p (csrc/tr_device_bench.hip) -- the unit a
- * device-resident loop would repeat 2-4 times per iteration, against the host's whole subproblem (mocap_ba_profile
- * out[2]).  `reps` dependent repetitions inside one launch, HIP events on the context's stream.
- * us [3] = {microseconds per factorisation alone, microseconds per shift (factorisation + three solves + norms),
- * max |p - p_host| / max |p_host| of the last shift (plain double loops on the host)}. */
-int mocap_debug_tr_device_bench(mocap_ctx* ctx, int reps, double* us);
-
 /* mocap_ba_solve: resident Levenberg-Marquardt / trust-region loop (the algorithm of
  * scipy.optimize.least_squares(method="trf", loss="cauchy"), helpers.py:287-289, restated
  * on the normal equations).  x [n] in/out.

@@ -585,7 +585,6 @@ static int match_dev_locked(mocap_ctx* ctx, int64_t n_frames, int M_max, const f
   if (wide && lds > 160 * 1024)
     return ctx->fail(MOCAP_E_LIMIT, "frame state needs %zu B of LDS (C=%d, M_max=%d, K_max=%d): lower K_max",
                      lds, ctx->C, M_max, K_max);
-  if (const char* pad = getenv("MOCAP_DEBUG_LDS_PAD")) lds += (size_t)atoi(pad);  // occupancy experiments only
   a.H = hit_cap;
   a.wide = wide ? 1 : 0;
   a.prune = ctx->prune;

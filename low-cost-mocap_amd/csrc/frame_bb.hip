@@ -5,22 +5,16 @@
 // like frame_kernel.hip does (which keeps the general case: per-camera intrinsics, wide frames, tiny frames, and
 // the exhaustive walk every result of this file is tested against, MOCAP_EVAL_BB=0).
 //
-// What is different from frame_kernel.hip, and why (round 3; measurements in DESIGN.md 3.1c):
-//  * its own kernel and LDS layout.  The round-2 search lived inside the all-in-one kernel (match + odometer walk +
-//    search + slice merge in one function: 128 VGPRs with 18 spilled) and borrowed its arrays from the odometer walk,
-//    which capped it at K_max <= 48, C <= 8.  Here: C <= 16 (blob indices of a group in one or two 64-bit words), any
-//    K_max <= 255 that fits LDS -- the reference seam's default K_max = min(C M, 64) and the re-submit's C M included.
-//  * phase B without the per-camera barrier chain.  The reference matches camera after camera (helpers.py:359-406)
-//    because a blob no root claims becomes a new root for the cameras after it.  Only THAT is sequential: the roots of
-//    camera 0 exist from the start, their lines, gates, orders and claims in all C - 1 other cameras are independent
-//    of each other -> one barrier-free pass over (root, camera) pairs.  What remains is a short chain over the cameras
-//    that involves only the roots created on the way (a few per frame): one wave, state in registers, ballots.
-//  * written for instruction issue, which is what binds it (PMC: the SIMDs issue an instruction in ~90-100 % of
-//    their cycles, 40 % of them scalar / branch / LDS): one lane per (root, camera) pair with the camera's blobs walked
-//    serially instead of a lane per (pair, blob); an instantiation with the camera count at compile time (8), and for
-//    8 cameras x 16 blob slots with K_max <= 48 / <= 64 the whole LDS layout at compile time (every array at a constant
-//    address: no base registers, no spills of them, no address arithmetic -- 5.72 -> 5.39 ms per 100 k frames, K_max 64:
-//    7.28 -> 5.47); the blocks' bounds cached between seed and test pass; the camera tables behind one base pointer.
+// What is different from frame_kernel.hip (measurements: DESIGN.md 3.1, docs/HISTORY.md):
+//  * its own kernel and LDS layout: C <= 16 (blob indices of a group in one or two 64-bit words), any K_max <= 255 that fits
+//    LDS -- the reference seam's default K_max = min(C M, 64) and the re-submit's C M included.
+//  * phase B without the per-camera barrier chain.  The reference matches camera after camera (helpers.py:359-406) because a
+//    blob no root claims becomes a new root for the cameras after it.  Only THAT is sequential: the camera-0 roots' lines,
+//    gates, orders and claims in all other cameras are independent -> one barrier-free pass over (root, camera) pairs, then
+//    the same pass for the provisional roots, then a chain over the cameras that is bookkeeping only.
+//  * written for instruction issue, which is what binds it: one lane per (root, camera) pair with the camera's blobs walked
+//    serially; the camera count (8) and, for 8 x 16 with K_max <= 48 / <= 64, the whole LDS layout at compile time; the
+//    blocks' bounds and blob indices cached between seed and test pass; the camera tables behind one base pointer.
 //  * a software pipeline over the frames: frame k + 1 is pulled from the queue and fetched straight into a spare LDS
 //    buffer (global_load_lds, no registers) while frame k is searched.
 //  * one evaluation path: a frame below the search threshold (MOCAP_BB_MIN_G, default 0 = never) queues all its blocks
@@ -44,42 +38,10 @@
 #include "mocap_device.hpp"
 #include "kernels.hpp"
 #include <cstdlib>
-
 #include "frame_common.hpp"
-
-// timing experiments only (results invalid): bit 0 = no search / no output, bit 1 = no chain over the cameras,
-// bit 2 = no camera-0 pairs, bit 3 = no speculative lines (scripts/build_bb_variants.sh)
-#ifndef MOCAP_BB_DEBUG_SKIP
-#define MOCAP_BB_DEBUG_SKIP 0
-#endif
-// round 5 (bit-identical by construction, each switchable for A/B timing): the offset inside a block decoded with the
-// correction-free small division; absent cameras add a record of zeros instead of sitting in an exec-mask region
-// timing experiments only (same results, parts of the candidate evaluation run twice): bit 0 = the table sums, bit 1 = the
-// whole solve, bit 2 = the seed pass's block bounds; -DMOCAP_DEBUG_DOUBLE_REPROJECT: the reprojection pass
-#ifndef MOCAP_BB_DEBUG_DOUBLE
-#define MOCAP_BB_DEBUG_DOUBLE 0
-#endif
-#ifndef MOCAP_BB_GM_ROLLED
-#define MOCAP_BB_GM_ROLLED 0  // group_matrix's camera loop kept rolled (code size: the kernel is 45 KB)
-#endif
-#ifndef MOCAP_BB_PROBE
-#define MOCAP_BB_PROBE 0  // seed blocks: one factorisation per candidate, the best one evaluated as the root's probe, the rest tested against it (measured: 5.27 -> 5.9-6.2 ms, see below; kept for the record, compiled out)
-#endif
-#ifndef MOCAP_BB_WALK_UNROLL
-#define MOCAP_BB_WALK_UNROLL 4  // (1: 4.79, 4 and 8: 4.70 ms per 100 k frames)
-#endif
-#ifndef MOCAP_BB_PREMATCH
-#define MOCAP_BB_PREMATCH 1  // the new roots' pairs matched all at once before the chain, which shrinks to bookkeeping
-#endif
-#ifndef MOCAP_BB_SPEC_COMPACT
-#define MOCAP_BB_SPEC_COMPACT 1  // speculative lines only for blobs the camera-0 roots left unclaimed
-#endif
-#ifndef MOCAP_BB_TINYDIV
-#define MOCAP_BB_TINYDIV 1
-#endif
-#ifndef MOCAP_BB_ZSLOT
-#define MOCAP_BB_ZSLOT 1
-#endif
+// (Round 6: the timing-only switches -- phases compiled out, parts run twice -- and the probe scheme, measured slower in
+// round 5, left this file; they are in the history at 7c94a55 and in docs/HISTORY.md.  What remains switchable is what a
+// test uses: -DMOCAP_DEBUG_EIGCHECK, the self-check build of tests/test_gpu_bb_adversarial.py.)
 
 namespace mocap {
 
@@ -153,9 +115,6 @@ struct BBLayout {
         break;
       }
     }
-#ifdef MOCAP_BB_NO_CACHE
-    ncache = 0;
-#endif
     o += 8 * (size_t)ncache;
     bpk = o;
     o += 8 * (size_t)CW * ncache;
@@ -166,12 +125,10 @@ struct BBLayout {
 // Root slots the launch lays out for a frame shape: the 8-camera, 16-blob shape has instantiations with the whole
 // layout fixed at compile time (48 or 64 slots, 0 = none applies); every other shape is laid out for K_max itself.
 static int bb_fixed_slots(int C, int M, int R) {
-#ifndef MOCAP_BB_NO_CT
   const char* e = getenv("MOCAP_BB_FIXED_LAYOUT");  // 0: the runtime-layout instantiation for every shape (tests, A/B timing)
   if (e && e[0] == '0') return 0;
   if (C == 8 && M == 16 && R <= 48) return 48;
   if (C == 8 && M == 16 && R <= 64) return 64;
-#endif
   return 0;
 }
 static int frame_bb_root_slots(int C, int M, int R) {
@@ -272,9 +229,7 @@ struct BBState {
       const unsigned long long ta = (unsigned long long)(uintptr_t)p_.cv.Pq;
       uint32_t tlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ta);
       uint32_t thi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(ta >> 32));
-#ifndef MOCAP_BB_TABLES_FROM_ARGS  // (timing experiments: the round trip through the kernel arguments back)
       asm volatile("" : "+s"(tlo), "+s"(thi));
-#endif
       cv.base = (const double*)(uintptr_t)(((unsigned long long)thi << 32) | tlo);
       if constexpr (CT == 0) cv.C = C;
     }
@@ -470,19 +425,14 @@ struct BBState {
       if (tid == 0 && cnt[0] > R) misc[MI_STATUS] |= MOCAP_ST_ROOT_OVERFLOW_;
     }
     __syncthreads();
-    // B0: the (camera-0 root, camera) pairs, ONE LANE PER PAIR, the camera's blobs walked serially.  The kernel is
-    // instruction-issue bound (PMC), so what counts is instructions per pair, not latency: a lane per
-    // (pair, blob) spends ~250 wave instructions on every 4 pairs (line broadcast, ballots, rank loop), a lane per
-    // pair ~10 per pair.  Pass 1 collects the gated blobs of the pair as a bit mask (M <= 64); pass 2 extracts them in
-    // (distance, index) order by repeated minimum -- hit lists are a handful long, distances are simply recomputed
-    // (same expression, same bits).  Waves take 64 pairs each: full lanes, as few waves as possible.
-    // Round 5 (MOCAP_BB_PREMATCH): a second stage of the same pass for the PROVISIONAL roots -- the blobs of cameras 1 .. C-1
-    // the camera-0 roots left unclaimed (only they can become roots, helpers.py:402-406): their pairs with the cameras after
-    // them are matched here, all at once on one lane each, into staging rows (the search's dead arrays), and the chain over
-    // the cameras below shrinks to bookkeeping: which provisional roots are real (not claimed by a root created before
-    // them) -- a wave-wide OR of claim masks per camera.  Before, wave 0 matched the new roots camera by camera while the
-    // other waves waited: 2 k dependent instructions of the frame's ~8 k deep critical path.  A frame whose provisional roots
-    // do not fit the staging rows (or one wave) takes the chain as before.
+    // B0: the (camera-0 root, camera) pairs, ONE LANE PER PAIR, the camera's blobs walked serially (the kernel is issue
+    // bound: ~10 wave instructions per pair instead of ~250 per 4 pairs with a lane per (pair, blob)).  Pass 1 collects the
+    // gated blobs of the pair as a bit mask (M <= 64); pass 2 extracts them in (distance, index) order by repeated minimum
+    // (hit lists are a handful long; distances are recomputed: same expression, same bits).
+    // Stage 1 of the same pass: the PROVISIONAL roots -- the blobs of cameras 1 .. C-1 the camera-0 roots left unclaimed
+    // (only they can become roots, helpers.py:402-406) -- against the cameras after them, into staging rows (the search's
+    // dead arrays); the chain over the cameras below then only decides which provisional roots are real.  A frame whose
+    // provisional roots do not fit the staging rows (or one wave) takes the chain with its own matching, as before.
     auto U_of = [&](int j) {  // provisional blobs of camera j (valid behind stage 0's barrier)
       const int n = cnt[j];
       return ~claimw[j] & (n >= 64 ? ~0ull : ((1ull << n) - 1ull));
@@ -498,7 +448,7 @@ struct BBState {
 #pragma nounroll
       for (int stage_ = 0; stage_ < 2; stage_++) {
         const int stage = __builtin_amdgcn_readfirstlane(stage_);  // (opaque: one copy of the pair code)
-        int NP = (MOCAP_BB_DEBUG_SKIP & 4) ? 0 : n0 * (C - 1);
+        int NP = n0 * (C - 1);
         if (stage == 1) {
           // (explicit: the compiler emitted THIS barrier without the s_waitcnt lgkmcnt(0) every other one has -- a wave could
           // read the claim words while another wave's ds_or of stage 0 was still queued: provisional sets that differed between
@@ -510,7 +460,7 @@ struct BBState {
             n_prov += np;
             n_ppairs += np * (C - 1 - j);
           }
-          pre = MOCAP_BB_PREMATCH && !MOCAP_BB_DEBUG_SKIP && n_prov <= 64 && (size_t)n_prov * C * (8 + 1 + (size_t)M) <= scr_bytes;
+          pre = n_prov <= 64 && (size_t)n_prov * C * (8 + 1 + (size_t)M) <= scr_bytes;
           if (!pre) break;
           nh_s = (uint8_t*)(pclaim + (size_t)n_prov * C);
           hits_s = nh_s + (size_t)n_prov * C;
@@ -553,9 +503,7 @@ struct BBState {
             return div_by(fabs(L.a * (double)pt.x + L.b * (double)pt.y + L.c), L.den, L.rden);  // helpers.py:373
           };
           unsigned long long hm = 0ull;
-#if MOCAP_BB_WALK_UNROLL > 1
-#pragma unroll MOCAP_BB_WALK_UNROLL
-#endif
+#pragma unroll 4
           for (int k = 0; k < Mmax; k++)  // (independent iterations: unrolled, their latencies overlap -- the stage runs on one or two waves)
             if (k < Mi && dist(k) < p.gate_px) hm |= 1ull << k;  // strict <, helpers.py:375,383
           uint8_t* nhp = stage == 0 ? nh : nh_s;
@@ -599,22 +547,16 @@ struct BBState {
         }
       }
     }
-    // Speculative lines.  Which blobs of cameras 1 .. C-2 become roots is only known inside the chain below, but their
-    // epipolar lines in the cameras after them depend on nothing: all of them are computed here, by all waves, off the
-    // chain's critical path (a line is ~90 dependent FP64 instructions; the chain would pay them once per camera).
-    // Table = the search's dead arrays: line (j, k) -> i at  sp_base(j) + k (C-1-j) + (i-j-1),  stored as the float32
-    // values they are (F32R: a, b, c are rounded to float32, helpers.py:364) + den in double; without F32R, or when
-    // the table does not fit, the chain computes its lines itself.
+    // Speculative lines (only for frames that take the old chain): the epipolar lines of the blobs that might become roots
+    // depend on nothing, so all waves compute them off the chain's critical path.  Table = the search's dead arrays: line
+    // (j, k) -> i at sp_base(j) + k (C-1-j) + (i-j-1), float32 a, b, c (F32R: that is what they are, helpers.py:364) + den.
     const int NL = M * ((C - 1) * (C - 2) / 2);
-    const bool spec = !(MOCAP_BB_DEBUG_SKIP & 8) && F32R && (size_t)NL * 20 + 8 <= scr_bytes;
+    const bool spec = F32R && (size_t)NL * 20 + 8 <= scr_bytes;
     double* sp_den = (double*)scr;
     float* sp_abc = (float*)(sp_den + NL);
     auto sp_base = [&](int j) { return M * ((j - 1) * (C - 1) - (j - 1) * j / 2); };  // lines of cameras 1 .. j-1
-#if MOCAP_BB_SPEC_COMPACT
-    // (round 5) ... but only of the blobs the camera-0 roots have NOT claimed: a claimed blob never becomes a root
-    // (helpers.py:402-406), and on the bench stream the camera-0 roots claim ~14 of every 16.  One more barrier (the claim
-    // words are complete behind it), then one lane per (unclaimed blob, later camera) pair: ~40 lines on one wave instead of
-    // 336 on all four (two passes).  The table keeps its layout, the chain its reads.
+    // ... of the blobs the camera-0 roots have NOT claimed only (a claimed blob never becomes a root): one lane per
+    // (unclaimed blob, later camera) pair, ~40 lines per frame.
     if (spec && !pre) {  // (behind stage 0's barrier: the claim words are complete)
       int tot = 0;
       for (int j = 1; j <= C - 2; j++) {
@@ -645,23 +587,6 @@ struct BBState {
         sp_abc[3 * ll + 2] = (float)L.c;
       }
     }
-#else
-    if (spec) {
-      for (int l = tid; l < NL; l += T) {
-        int j = 1;
-        while (j < C - 2 && l >= sp_base(j + 1)) j++;
-        const int rel = l - sp_base(j), span = C - 1 - j;
-        const int k = rel / span, i = j + 1 + (rel - k * span);
-        if (k < cnt[j]) {
-          const Line L = epiline_of(j, k, i);
-          sp_den[l] = L.den;
-          sp_abc[3 * l + 0] = (float)L.a;
-          sp_abc[3 * l + 1] = (float)L.b;
-          sp_abc[3 * l + 2] = (float)L.c;
-        }
-      }
-    }
-#endif
     __syncthreads();
     if (wave == 0 && pre) {
       // B1, pre-matched: lane p <-> provisional root p = the p-th unclaimed blob of cameras 1 .. C-1 in (camera, blob) order.
@@ -717,7 +642,7 @@ struct BBState {
       int nr_cam = 0, nr_blob = 0;
       int n_roots = n0;
       bool over = false;
-      for (int i = 1; i < ((MOCAP_BB_DEBUG_SKIP & 2) ? 1 : C); i++) {
+      for (int i = 1; i < C; i++) {
         const int Mi = __builtin_amdgcn_readlane(cntL, i);
         unsigned long long claimed = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)(clmL >> 32), i) << 32) |
                                      (unsigned int)__builtin_amdgcn_readlane((int)clmL, i);
@@ -905,9 +830,6 @@ struct BBState {
 #pragma unroll
       for (int e = 0; e < 10; e++) B[e] = 0.0;
     }
-#if MOCAP_BB_GM_ROLLED
-#pragma nounroll
-#endif
     for (int c = 0; c < C; c++) {
       uint32_t k = 0xFFu;
       if (c == rc) {
@@ -919,9 +841,7 @@ struct BBState {
         } else if (n > 1) {
           if (ka >= skip) {
             uint32_t qd, dgt;
-#if MOCAP_BB_TINYDIV
             if (rem < 8192u) divmod_tiny(rem, n, qd, dgt); else  // (the usual case for every lane of the wave: one path runs)
-#endif
             divmod_small(rem, n, qd, dgt);
             rem = qd;
             k = hr[(size_t)c * M + dgt];
@@ -963,18 +883,13 @@ struct BBState {
       for (int k = 0; k < nl; k++) {  // the block's open digits (rem < pl < 2^13, hit counts <= 64: divmod_tiny is exact)
         const int c = a[k];
         uint32_t qd, dgt;
-#if MOCAP_BB_TINYDIV
         divmod_tiny(rem, nh[(size_t)r * C + c], qd, dgt);
-#else
-        divmod_small(rem, nh[(size_t)r * C + c], qd, dgt);
-#endif
         rem = qd;
         pk.set(c, hits[((size_t)r * C + c) * M + dgt]);
       }
     }
 #pragma unroll
     for (int ee = 0; ee < 10; ee++) B[ee] = 0.0;
-#if MOCAP_BB_ZSLOT
 #pragma unroll CT > 0 ? CT : 1
     for (int c = 0; c < C; c++) {
       const uint32_t k = pk.get(c);
@@ -983,20 +898,6 @@ struct BBState {
       for (int ee = 0; ee < 10; ee++) B[ee] = B[ee] + t[ee];
     }
     return bv[r];
-#else
-    int v = 0;
-#pragma unroll CT > 0 ? CT : 1
-    for (int c = 0; c < C; c++) {
-      const uint32_t k = pk.get(c);
-      if (k != 0xFFu) {
-        const double* t = bt + ((size_t)c * M + k) * 10;
-#pragma unroll
-        for (int ee = 0; ee < 10; ee++) B[ee] = B[ee] + t[ee];
-        v++;
-      }
-    }
-    return v;
-#endif
   }
 
   __device__ void search(bool bound_tests) {
@@ -1032,19 +933,6 @@ struct BBState {
 #pragma unroll
       for (int k = 0; k < CW; k++) rpk[(size_t)slot * CW + k] = pk.w[k];
     };
-#if MOCAP_BB_PROBE
-    // one candidate on its own (bit 31 of the record: gh IS the candidate index, the blob indices are complete)
-    auto push_single = [&](int r, uint32_t gl, const Packed<CW>& pk) {
-      const uint32_t old = (uint32_t)atomicAdd(ctr, (int32_t)((1u << 10) | 1u));
-      const uint32_t slot = old & 0x3FFu;
-      BRec rec;
-      rec.gh = gl;
-      rec.rs = (uint32_t)r | ((old >> 10) << 8) | 0x80000000u;
-      recs[slot] = rec;
-#pragma unroll
-      for (int k = 0; k < CW; k++) rpk[(size_t)slot * CW + k] = pk.w[k];
-    };
-#endif
     auto rec_start = [&](int k) { return (recs[k].rs & 0x7FFFFFFFu) >> 8; };
     // EigCut's first test of a (partial) group of root r against the best error of the root so far
     auto dropped = [&](int r, double s1, double tr) {
@@ -1054,54 +942,6 @@ struct BBState {
       const double limit_adj = fma(1.002, limit, (double)(2 * vf) * ec.o2slack);
       return s1 * fma(2e-12, tr, p.p3max2c * limit_adj) < 1.0;
     };
-#if MOCAP_BB_PROBE
-    // ---- probe scheme (round 5): what a lane keeps of the seed blocks' candidates it looked at (kProbeHold per lane)
-    // across the evaluation of the probes
-    constexpr int kProbeHold = 2;
-    // ... parked in the workgroup's slice of a global workspace (L2-resident, [item][word][lane]: coalesced), not in registers:
-    // held across the probes' evaluation they cost the kernel 70 more spilled VGPRs, reloaded inside the evaluation
-    constexpr int kHoldWords = 4 + 2 * CW;  // candidate index, root (-1: none), s1, trace (floats, rounded up), blob indices
-    uint32_t* hold = (uint32_t*)(p.ws + (size_t)blockIdx.x * p.ws_stride);
-    auto hold_at = [&](int it, int w) -> uint32_t& { return hold[((size_t)it * kHoldWords + w) * T + tid]; };
-#endif
-    int stage = 0;  // 0: the plain loop; 1: the probes are queued (their flush comes first); 2: the second half of the seed tests is pending
-#if MOCAP_BB_PROBE
-    auto seed_test = [&](int it) {
-      const int r = (int)hold_at(it, 1);
-      if (r >= 0) {
-        const uint32_t probe = 0xFFFFFFFFu - (uint32_t)seedkey[r];
-        const uint32_t h_gl_ = hold_at(it, 0);
-        if (h_gl_ != probe) {
-          const bool drop = dropped(r, (double)__uint_as_float(hold_at(it, 2)), (double)__uint_as_float(hold_at(it, 3)));
-          if (!drop) {
-            Packed<CW> hpk;
-#pragma unroll
-            for (int k = 0; k < CW; k++) hpk.w[k] = ((unsigned long long)hold_at(it, 5 + 2 * k) << 32) | hold_at(it, 4 + 2 * k);
-            push_single(r, h_gl_, hpk);
-          }
-#ifdef MOCAP_DEBUG_EIGCHECK  // self-check build: a seed-block candidate dropped on its own bound is evaluated in full against it
-          if (drop) {
-            const double bound = __longlong_as_double((long long)rbound[r]);
-            double B2[10], X2[3], e2 = inf;
-            Packed<CW> pk2;
-            const int v2 = group_matrix<true>(r, h_gl_, 0, B2, pk2);
-            auto obs2 = [&](int c, double& x, double& y) -> bool {
-              const uint32_t k = pk2.get(c);
-              if (k == 0xFFu) return false;
-              const float2 w = bxy[(size_t)c * M + k];
-              x = (double)w.x;
-              y = (double)w.y;
-              return true;
-            };
-            solve_and_score<true, true, F32R>(cv, B2, v2, obs2, X2, e2);
-            atomicAdd(&p.status[p.n_frames + 1], 1);
-            if (e2 <= bound) printf("EIGCHECK seed candidate: root %d candidate %u bound %.17g true %.17g\n", r, h_gl_, bound, e2);
-          }
-#endif
-        }
-      }
-    };
-#endif
     if (bound_tests) {
       // ---- 1. seeds: s1 of every block (cached for the tests); per root the block with the largest s1 (smallest
       // bound) almost always holds the winner
@@ -1124,17 +964,6 @@ struct BBState {
           double s1d = __builtin_huge_val();  // a one-view partial group carries no information: never dropped, any seed
           float s1 = 0.0f;
           if (v >= 2) {
-#if MOCAP_BB_DEBUG_DOUBLE & 4
-            {
-              double B2[10], tr2;
-              Packed<CW> pk2;
-              uint32_t gh2 = gh;
-              asm volatile("" : "+v"(gh2));
-              group_matrix<true>(r, gh2, bnl[r], B2, pk2);
-              const double s2 = eigcut_s1_shifted(B2, c0, tr2);
-              asm volatile("" ::"v"(s2), "v"(tr2));
-            }
-#endif
             s1d = eigcut_s1_shifted(B, c0, tr);
             s1 = (float)fmin(s1d, 3e38);
           }
@@ -1151,19 +980,17 @@ struct BBState {
         }
       }
       __syncthreads();
-#if !MOCAP_BB_PROBE
       if (nblocks <= (uint32_t)T) {
         if (my_r >= 0 && seedkey[my_r] == my_key) {  // (keys are unique inside a root: exactly one lane per root with blocks)
           seedgh[my_r] = my_gh;
           push_block(my_r, my_gh, my_pk);
         }
       } else
-#endif
       for (int r = tid; r < nroots; r += T) {
         if (bnb[r]) {
           const uint32_t gh = 0xFFFFFFFFu - (uint32_t)seedkey[r];
           seedgh[r] = gh;
-          seedkey[r] = 0ull;  // (next: the key of the root's probe)
+          seedkey[r] = 0ull;
           double B[10];
           Packed<CW> pk;
           group_matrix<false>(r, gh, bnl[r], B, pk);
@@ -1171,76 +998,6 @@ struct BBState {
         }
       }
       __syncthreads();
-#if MOCAP_BB_PROBE
-      // ---- 1b. probes (round 5).  Evaluating the seed blocks in full -- 16+ candidates per root with no bound to cut them
-      // short -- was 70 % of a frame's full evaluations.  Instead every candidate of the seed blocks takes only the table sums
-      // and ONE factorisation (s1 of its own matrix, the same bound the blocks are tested with); per root the candidate with
-      // the largest s1 -- the seed block's best in 98 % of the roots of the bench stream (scripts/model_probe.py) -- is
-      // evaluated in full (the probes: one dense round), and the others are tested against its error with the s1 they
-      // already have: the few that survive go to the queue as single candidates.  Nothing is dropped on anything but the
-      // bound every other cut of this file uses, so the results do not change by a bit (tests/test_gpu_bb_adversarial.py;
-      // the self-check build evaluates everything dropped here as well).  Frames with more seed candidates than the lanes
-      // can hold (kProbeHold per lane) keep the old order: their seed blocks are evaluated in full by the loop below.
-      {
-        const uint32_t cvs = (uint32_t)*ctr;
-        const uint32_t ns = cvs & 0x3FFu, ne = cvs >> 10;
-        if (ns && ne <= (uint32_t)(kProbeHold * T)) {  // (uniform)
-#pragma nounroll
-          for (int it = 0; it < kProbeHold; it++) {  // (one copy of the body: the kernel's code has to stay inside the instruction cache)
-            const uint32_t i0 = (uint32_t)(it * T), i = i0 + (uint32_t)tid;
-            const bool have = i < ne;
-            uint32_t lo = 0;
-            if (i0 + (uint32_t)(wave * 64) < ne)  // wave-uniform
-              lo = (uint32_t)coop_last_le(rec_start, (int)ns, i0 + (uint32_t)(wave * 64), have ? i : ne - 1, lane);
-            int r = -1;
-            uint32_t gl = 0;
-            float s1f = 0.f, trf = 0.f;
-            Packed<CW> pk;
-            pk.clear();
-            if (have) {
-              double B[10], tr = 0.0;
-              const int v = fetch_candidate(lo, i, r, gl, pk, B);
-              double s1d = __builtin_huge_val();
-              if (v >= 2) s1d = eigcut_s1_shifted(B, c0, tr);
-              s1f = __double2float_ru(s1d);  // rounded UP: a larger s1 or trace only ever keeps a candidate (safe side)
-              trf = __double2float_ru(tr);
-              atomicMax(&seedkey[r], ((unsigned long long)__float_as_uint((float)fmin(s1d, 3e38)) << 32) | (unsigned long long)(0xFFFFFFFFu - gl));
-            }
-            hold_at(it, 0) = gl;
-            hold_at(it, 1) = (uint32_t)r;
-            hold_at(it, 2) = __float_as_uint(s1f);
-            hold_at(it, 3) = __float_as_uint(trf);
-#pragma unroll
-            for (int k = 0; k < CW; k++) {
-              hold_at(it, 4 + 2 * k) = (uint32_t)pk.w[k];
-              hold_at(it, 5 + 2 * k) = (uint32_t)(pk.w[k] >> 32);
-            }
-          }
-          wait_own_stores();
-          __syncthreads();  // the seed blocks' records are consumed, the probes' keys complete
-          if (tid == 0) *ctr = 0;
-          {
-            int32_t* t = ctr;
-            ctr = ctr_other;
-            ctr_other = t;
-          }
-          // the probes go to the queue as single candidates, each from the lane that holds it
-#pragma nounroll
-          for (int it = 0; it < kProbeHold; it++) {
-            const int hr = (int)hold_at(it, 1);
-            const uint32_t hg = hold_at(it, 0);
-            if (hr >= 0 && hg == 0xFFFFFFFFu - (uint32_t)seedkey[hr]) {
-              Packed<CW> hpk;
-#pragma unroll
-              for (int k = 0; k < CW; k++) hpk.w[k] = ((unsigned long long)hold_at(it, 5 + 2 * k) << 32) | hold_at(it, 4 + 2 * k);
-              push_single(hr, hg, hpk);
-            }
-          }
-          __syncthreads();
-          stage = 1;
-        }
-      }
-#endif
     }
     // ---- 2. the queued records' candidates (spread over all lanes, whatever root they belong to), then the next
     // blocks' tests, until nothing is left
@@ -1250,7 +1007,7 @@ struct BBState {
       const uint32_t ns = cv_ & 0x3FFu, ne = cv_ >> 10;
       const bool blocks_left = b0 < nblocks;
       const bool full = ns > (uint32_t)(kBBRecs - T);
-      if (ns && (stage == 1 || full || (stage == 0 && (!blocks_left || ne >= (uint32_t)p.bb_flush)))) {
+      if (ns && (full || !blocks_left || ne >= (uint32_t)p.bb_flush)) {
         for (uint32_t i0 = 0; i0 < ne; i0 += T) {
           const uint32_t i = i0 + (uint32_t)tid;
           const bool have = i < ne;
@@ -1274,37 +1031,6 @@ struct BBState {
               return true;
             };
             const double bound = __longlong_as_double((long long)rbound[r]);
-#if MOCAP_BB_DEBUG_DOUBLE & 1  // timing experiments only (same results): the table sums of a candidate once more
-            {
-              double B2[10];
-#pragma unroll
-              for (int ee = 0; ee < 10; ee++) B2[ee] = 0.0;
-              uint32_t w0 = (uint32_t)pk.w[0], w1 = (uint32_t)(pk.w[0] >> 32);
-              asm volatile("" : "+v"(w0), "+v"(w1));
-              const unsigned long long ww = ((unsigned long long)w1 << 32) | w0;
-#pragma unroll CT > 0 ? CT : 1
-              for (int c = 0; c < C; c++) {
-                const uint32_t k = (uint32_t)(ww >> (8 * (c & 7))) & 0xFFu;
-                const double* t = bt + (size_t)(k != 0xFFu ? (uint32_t)c * (uint32_t)M + k : (uint32_t)C * (uint32_t)M) * 10;
-#pragma unroll
-                for (int ee = 0; ee < 10; ee++) B2[ee] = B2[ee] + t[ee];
-              }
-#pragma unroll
-              for (int ee = 0; ee < 10; ee++) asm volatile("" ::"v"(B2[ee]));
-            }
-#endif
-#if MOCAP_BB_DEBUG_DOUBLE & 2  // ... the whole solve (factorisations, null vector, reprojection) once more
-            {
-              double B2[10], X2[3], e2 = inf;
-#pragma unroll
-              for (int ee = 0; ee < 10; ee++) {
-                B2[ee] = B[ee];
-                asm volatile("" : "+v"(B2[ee]));
-              }
-              solve_and_score<true, true, F32R, false>(cv, B2, v, obs_p, X2, e2, bound * (double)(2 * v) * (1.0 + 0x1p-40), ec);
-              asm volatile("" ::"v"(e2), "v"(X2[0]), "v"(X2[1]), "v"(X2[2]));
-            }
-#endif
             solve_and_score<true, true, F32R, false>(cv, B, v, obs_p, X, e, bound * (double)(2 * v) * (1.0 + 0x1p-40), ec);
 #ifdef MOCAP_DEBUG_EIGCHECK  // self-check build: a candidate whose evaluation was cut short must not beat the bound it was cut against
             if (!(e < inf)) {
@@ -1358,23 +1084,8 @@ struct BBState {
           ctr = ctr_other;
           ctr_other = t;
         }
-#if MOCAP_BB_PROBE
-        if (stage == 1) {  // the probes have been evaluated: the seed blocks' other candidates against their errors (first half)
-          seed_test(0);
-          stage = 2;
-          __syncthreads();
-        }
-#endif
         continue;
       }
-#if MOCAP_BB_PROBE
-      if (stage == 2) {  // (second half: at most T more records, and the queue holds at most kBBRecs - T)
-        seed_test(1);
-        stage = 0;
-        __syncthreads();
-        continue;
-      }
-#endif
       if (!blocks_left) break;
       const uint32_t b = b0 + (uint32_t)tid;
       const uint32_t bw = b0 + (uint32_t)(wave * 64);
@@ -1485,9 +1196,7 @@ struct BBState {
         if (n) {
           uint32_t qd = rem, dgt = 0;
           if (n > 1) {  // (a single hit is digit 0 of radix 1: nothing to divide)
-#if MOCAP_BB_TINYDIV
             if (rem < 8192u) divmod_tiny(rem, n, qd, dgt); else
-#endif
             divmod_small(rem, n, qd, dgt);
           }
           s = (int16_t)hits[((size_t)r * C + c) * M + dgt];
@@ -1534,7 +1243,7 @@ __global__ __launch_bounds__(kBBThreads, MOCAP_BB_WAVES_PER_EU) void frame_bb_ke
       p.status[frame] = status;
       if (p.n_cand) p.n_cand[frame] = st.misc[MI_G];
     }
-    const uint32_t G = (MOCAP_BB_DEBUG_SKIP & 1) ? 0u : (uint32_t)st.misc[MI_G];
+    const uint32_t G = (uint32_t)st.misc[MI_G];
     if (G) {
       // the bound tests pay their fixed cost (seed pass + a test per block) only on frames with enough candidates;
       // smaller frames queue every block -- same evaluation rounds, same result
@@ -1557,7 +1266,7 @@ __global__ __launch_bounds__(kBBThreads, MOCAP_BB_WAVES_PER_EU) void frame_bb_ke
 }
 
 int frame_bb_wg_per_cu_cap() { return MOCAP_BB_WAVES_PER_EU; }
-size_t frame_bb_ws_bytes(int C) { return MOCAP_BB_PROBE ? (size_t)2 * (4 + 2 * (C <= 8 ? 1 : 2)) * 4 * kBBThreads : 0; }
+size_t frame_bb_ws_bytes(int) { return 0; }  // (no per-workgroup HBM workspace: everything between input and output lives in LDS)
 
 hipError_t launch_frame_bb(const FrameArgs& a, int grid, hipStream_t stream) {
   const size_t lds = frame_bb_lds_bytes(a.cv.C, a.M, a.K_max);
@@ -1573,10 +1282,8 @@ hipError_t launch_frame_bb(const FrameArgs& a, int grid, hipStream_t stream) {
     k = f32 ? frame_bb_kernel<true, 1, 8, 16, 64> : frame_bb_kernel<false, 1, 8, 16, 64>;
   else if (fixed)
     return hipErrorInvalidValue;
-#ifndef MOCAP_BB_NO_CT
   else if (a.cv.C == 8)
     k = f32 ? frame_bb_kernel<true, 1, 8, 0, 0> : frame_bb_kernel<false, 1, 8, 0, 0>;
-#endif
   else if (a.cv.C <= 8)
     k = f32 ? frame_bb_kernel<true, 1, 0, 0, 0> : frame_bb_kernel<false, 1, 0, 0, 0>;
   else

@@ -1474,12 +1474,6 @@ __global__ __launch_bounds__(T, MOCAP_FRAME_WAVES_PER_EU) void frame_kernel(Fram
         sl = item - base;
       }
       if constexpr (WIDE) st.match_wide(frame); else st.match(frame);
-#ifdef MOCAP_DEBUG_DOUBLE_MATCH  // timing experiments only: what phases A-C cost INSIDE the mix: an extra, possibly
-      __syncthreads();             // partial (skip mask = the macro's value) pass before the real one is repeated
-      st.match(frame, MOCAP_DEBUG_DOUBLE_MATCH);
-      __syncthreads();
-      st.match(frame);
-#endif
       const uint32_t G = (uint32_t)st.misc[MI_G];
       if (kind == 1) {
         if (tid == 0) {
@@ -1515,9 +1509,7 @@ __global__ __launch_bounds__(T, MOCAP_FRAME_WAVES_PER_EU) void frame_kernel(Fram
         g_lo = (uint32_t)((uint64_t)G * (uint64_t)sl / S);
         g_hi = (uint32_t)((uint64_t)G * (uint64_t)(sl + 1) / S);
       }
-#ifndef MOCAP_DEBUG_NO_EVAL  // timing experiments only: phases A-C without candidate evaluation
       if (g_hi > g_lo) st.evaluate(g_lo, g_hi);
-#endif
       const int nroots = st.misc[MI_NROOTS];
       bool merge = false;
       for (int r = tid; r < nroots; r += T) {
@@ -1526,9 +1518,7 @@ __global__ __launch_bounds__(T, MOCAP_FRAME_WAVES_PER_EU) void frame_kernel(Fram
         double e = __longlong_as_double(0x7ff0000000000000ll), X[3] = {0, 0, 0};  // +inf: no candidate here
         uint32_t gl = 0;
         bool won = false;
-#ifndef MOCAP_DEBUG_NO_EVAL
         if (g_hi > g_lo) won = st.root_winner(r, g_lo, g_hi, e, gl, X);
-#endif
         if (kind == 1) {
           if (won) st.write_point(frame, r, e, gl, X);
         } else {
@@ -1644,11 +1634,7 @@ __global__ __launch_bounds__(T, MOCAP_FRAME_WAVES_PER_EU) void frame_kernel(Fram
       __syncthreads();
       if (st.misc[MI_DEFER]) continue;  // uniform
       st.write_frame_header(frame);
-#ifdef MOCAP_DEBUG_NO_EVAL  // timing experiments only: phases A-C without candidate evaluation
-      if (false) {
-#else
       if (G) {
-#endif
         st.evaluate(0, G);
         const int nroots = st.misc[MI_NROOTS];
         for (int r = tid; r < nroots; r += T) {

@@ -483,13 +483,6 @@ __device__ __forceinline__ void solve_and_score(const View& cv, double (&B)[10],
       return;
     }
   }
-#ifdef MOCAP_DEBUG_DOUBLE_REPROJECT  // timing experiments only: what the reprojection pass costs inside the mix (run twice, same result)
-  {
-    double e2;
-    score_point<UNIFORM_K, PAIRWISE, F32R, BATCH>(cv, v, obs2, X, e2, limit);
-    asm volatile("" : "+v"(X[0]), "+v"(X[1]), "+v"(X[2]) : "v"(e2));
-  }
-#endif
   score_point<UNIFORM_K, PAIRWISE, F32R, BATCH>(cv, v, obs2, X, err, limit);
 }
 

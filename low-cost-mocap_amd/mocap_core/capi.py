@@ -73,7 +73,6 @@ SIGNATURES = {
     "mocap_reproject": (_i32, [_vp, _i64, _vp, _vp, _vp]),
     "mocap_set_ba_progress": (_i32, [_vp, _vp, _vp]),
     "mocap_ba_profile": (_i32, [_vp, _vp, _i64, _vp, _i32, _i32, _i32, _vp]),
-    "mocap_debug_tr_device_bench": (_i32, [_vp, _i32, _vp]),
     "mocap_ba_solve": (_i32, [_vp, _vp, _i64, _vp, _dbl, _dbl, _dbl, _i32, _i32, _i32, _vp]),
     "mocap_ba_solve_ex": (_i32, [_vp, _vp, _i64, _vp, _dbl, _dbl, _dbl, _i32, _i32, _i32, _vp, _i32]),
 }
@@ -509,12 +508,6 @@ class MocapCore:
                                               int(reps), _p(out)))
         keys = ("gpu_us_per_linearisation", "wall_us_per_linearisation", "host_tr_us", "launches", "m", "NP", "fused", "cost")
         return dict(zip(keys, out.tolist()))
-
-    def tr_device_bench(self, reps=200):
-        """Measurement aid: one wave's cost per shift of the 42 x 42 trust-region subproblem (mocap_debug_tr_device_bench)."""
-        out = np.zeros(3)
-        self._check(self.lib.mocap_debug_tr_device_bench(self._h, int(reps), _p(out)))
-        return {"us_per_factorisation": float(out[0]), "us_per_shift": float(out[1]), "p_max_rel_vs_host": float(out[2])}
 
     def ba_solve(self, x0, obs, ftol=1e-2, xtol=1e-8, gtol=1e-8, max_iter=0, f32_residuals=True,
                  use_cauchy=True):

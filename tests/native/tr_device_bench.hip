@@ -13,14 +13,15 @@
 #include <vector>
 #include <cmath>
 
-#include "ctx.hpp"
-#include "mocap_device.hpp"
-#include "../../include/mocap_core.h"
+#include "../../low-cost-mocap_amd/csrc/mocap_device.hpp"  // rsqrt_pos, recip_refined: the product's own device helpers
 
-#define HIP_TRY(ctx, expr)                                  \
-  do {                                                      \
-    hipError_t e__ = (expr);                                \
-    if (e__ != hipSuccess) return (ctx)->hip_fail(e__, #expr); \
+// Round 6: a TEST-ONLY library of its own (tests/native/Makefile -> tests/native/libmocap_trbench.so), not part of
+// lib/libmocap_core.so and not declared in include/mocap_core.h: the product ABI exports product symbols only.
+
+#define HIP_TRY(ctx, expr)                   \
+  do {                                       \
+    hipError_t e__ = (expr);                 \
+    if (e__ != hipSuccess) return -(int)e__; \
   } while (0)
 
 namespace mocap {
@@ -131,14 +132,14 @@ __global__ __launch_bounds__(64) void tr_wave_kernel(const double* __restrict__ 
 
 }  // namespace mocap
 
-// mocap_debug_tr_device_bench (include/mocap_core.h): times the kernel above on the context's stream with HIP events.
+// trbench_run: times the kernel above on the null stream of `device` with HIP events.
 //   us[0] = microseconds per factorisation alone, us[1] = per shift (factorisation + three triangular solves + norms),
 //   us[2] = max |p_device - p_host| / max |p_host| for the last shift (host: the same system in plain double loops).
-extern "C" int mocap_debug_tr_device_bench(mocap_ctx* ctx, int reps, double* us) {
+extern "C" int trbench_run(int device, int reps, double* us) {
   using namespace mocap;
-  if (!ctx || !us || reps < 1) return MOCAP_E_ARG;
-  std::lock_guard<std::mutex> lk(ctx->mu);
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (!us || reps < 1) return -1;
+  HIP_TRY(ctx, hipSetDevice(device));
+  hipStream_t stream = nullptr;
   const int n = kTrN;
   // a well-conditioned SPD system shaped like J^T J of the metric's problem: B = M^T M + I, g arbitrary
   std::vector<double> M((size_t)n * n), B((size_t)n * n), g(n);
@@ -168,13 +169,13 @@ extern "C" int mocap_debug_tr_device_bench(mocap_ctx* ctx, int reps, double* us)
   float ms[2] = {0, 0};
   for (int which = 0; which < 2; which++) {
     for (int pass = 0; pass < 2; pass++) {  // the first pass warms the code object
-      HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
+      HIP_TRY(ctx, hipEventRecord(e0, stream));
       if (which == 0)
-        hipLaunchKernelGGL(tr_wave_kernel<false>, dim3(1), dim3(64), 0, ctx->stream, dB, dg, a0, reps, dout);
+        hipLaunchKernelGGL(tr_wave_kernel<false>, dim3(1), dim3(64), 0, stream, dB, dg, a0, reps, dout);
       else
-        hipLaunchKernelGGL(tr_wave_kernel<true>, dim3(1), dim3(64), 0, ctx->stream, dB, dg, a0, reps, dout);
+        hipLaunchKernelGGL(tr_wave_kernel<true>, dim3(1), dim3(64), 0, stream, dB, dg, a0, reps, dout);
       HIP_TRY(ctx, hipGetLastError());
-      HIP_TRY(ctx, hipEventRecord(e1, ctx->stream));
+      HIP_TRY(ctx, hipEventRecord(e1, stream));
       HIP_TRY(ctx, hipEventSynchronize(e1));
       HIP_TRY(ctx, hipEventElapsedTime(&ms[which], e0, e1));
     }
@@ -215,5 +216,5 @@ extern "C" int mocap_debug_tr_device_bench(mocap_ctx* ctx, int reps, double* us)
   us[0] = 1e3 * ms[0] / reps;
   us[1] = 1e3 * ms[1] / reps;
   us[2] = dev / mx;
-  return MOCAP_OK;
+  return 0;
 }

@@ -11,6 +11,8 @@ Parity ladder (a13/a14 of SURVEY.md section 8):
   (5) final poses in tight mode (float64 residuals, tolerances 1e-12) vs scipy.least_squares driven
       by the oracle's residuals -- both must reach the same minimum to 1e-5 relative.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -652,8 +654,17 @@ def test_default_mode_batched_jacobian_is_scipys_own(core, name, monkeypatch):
 
 @pytest.mark.gpu
 def test_device_subproblem_microbench_solves_the_system(core):
-    """mocap_debug_tr_device_bench (measurement aid behind bench.py's ba.device_subproblem): the one-wave Cholesky +
-    triangular solves it times must actually solve (B + a I) p = -g -- against plain double loops on the host."""
-    r = core.tr_device_bench(reps=8)
-    assert r["p_max_rel_vs_host"] < 1e-11
-    assert 0.0 < r["us_per_factorisation"] < r["us_per_shift"] < 1e4
+    """tests/native/libmocap_trbench.so (test-only, NOT in the product library: the measurement aid behind DESIGN 3.4's "the
+    subproblem stays on the host", profiles/r05_ba_device_subproblem.txt): the one-wave Cholesky + triangular solves it times
+    must actually solve (B + a I) p = -g -- against plain double loops on the host."""
+    import ctypes
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = os.path.join(root, "tests", "native", "libmocap_trbench.so")
+    assert os.path.exists(path), "build it with `make -C tests/native` (__graft_entry__.build does)"
+    lib = ctypes.CDLL(path)
+    lib.trbench_run.restype = ctypes.c_int
+    lib.trbench_run.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    out = np.zeros(3)
+    assert core is not None and lib.trbench_run(0, 8, out.ctypes.data) == 0
+    assert out[2] < 1e-11                       # max |p - p_host| / max |p_host|
+    assert 0.0 < out[0] < out[1] < 1e4          # us per factorisation < us per shift
