@@ -648,7 +648,7 @@ __global__ __launch_bounds__(kFusedThreads) void ba_fused_kernel(BaFusedArgs a) 
       const int nodes = (units + kFusedFan - 1) / kFusedFan, node = my / kFusedFan;
       const int first = node * kFusedFan, cnt = min(kFusedFan, units - first);
       drain_stores();
-      __syncthreads();
+      block_sync_lds();  // (loop head; the wait written out: tests/isa_barriers.py)
       if (tid == 0) {
         sh_last = __hip_atomic_fetch_add(&a.counters[cnt_base + node], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == cnt - 1;
         if (sh_last) __hip_atomic_store(&a.counters[cnt_base + node], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

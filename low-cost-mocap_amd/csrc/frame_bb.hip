@@ -453,8 +453,7 @@ struct BBState {
           // (explicit: the compiler emitted THIS barrier without the s_waitcnt lgkmcnt(0) every other one has -- a wave could
           // read the claim words while another wave's ds_or of stage 0 was still queued: provisional sets that differed between
           // waves, one wrong frame in ~10^5)
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          __syncthreads();  // the camera-0 roots' claims are complete
+          block_sync_lds();  // the camera-0 roots' claims are complete
           for (int j = 1; j < C; j++) {
             const int np = __popcll(U_of(j));
             n_prov += np;

@@ -72,7 +72,7 @@ __global__ __launch_bounds__(kHvThreads) void heavy_bb_kernel(HeavyArgs a) {
     const int Hs = hd.Hs;
     const float2* fb = (const float2*)(a.blobs + (size_t)hd.frame * C * M * 2);
     const size_t o = (size_t)hd.frame * a.K_big + hd.outslot;
-    __syncthreads();  // (the previous root's shared state is dead)
+    block_sync_lds();  // (the previous root's shared state is dead; reached from every exit of the previous iteration: the wait is written out)
     if (tid < C) s_n[tid] = nc[tid];
     if (tid == 0) {
       int m = 0;

@@ -94,6 +94,16 @@ __host__ __device__ constexpr int sidx(int i, int j) {
 // wave does it).  With sc1 (write-through) stores the acknowledgement means the data has left this XCD's L2.
 __device__ __forceinline__ void wait_own_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
+// A workgroup barrier with its wait WRITTEN OUT.  __syncthreads() normally compiles to s_waitcnt lgkmcnt(0) + s_barrier; round 5
+// found one barrier of frame_bb_kernel emitted without the wait (a wave read claim words while another wave's ds_or was
+// still queued: one wrong frame in 1e5).  Used wherever tests/isa_barriers.py cannot prove the wait from the compiler's own
+// output on every path (a barrier at a loop head that the previous iteration reaches through several exits); free when the
+// compiler has already waited.  tests/test_code_objects_cpu.py checks every barrier of the big kernels in the shipped ISA.
+__device__ __forceinline__ void block_sync_lds() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __syncthreads();
+}
+
 __device__ __forceinline__ double rsqrt_pos(double d) {
   const double y = __builtin_amdgcn_rsq(d);
   const double e = fma(-(d * y), y, 1.0);
