@@ -56,6 +56,12 @@ enum {
   MOCAP_OPT_F32_ROUNDING = 1 /* default ON: reproduce OpenCV's float32 roundings of the
                                 epipolar line (helpers.py:363) and of the projected point /
                                 pixel (helpers.py:231-237).  OFF = all-double arithmetic. */
+  ,
+  MOCAP_OPT_EXHAUSTIVE_WALK = 2 /* default OFF.  ON: every candidate group of the Cartesian product is triangulated and
+                                   reprojected (helpers.py:408-421 as written) -- no eigenvalue bound drops or cuts anything
+                                   (csrc/frame_kernel.hip without its cut-offs instead of csrc/frame_bb.hip).  Same results
+                                   bit for bit, ~3 x the time: the verification mode bench.py's full-batch parity field and
+                                   tests/test_gpu_bench_scale.py compare the shipped selection against. */
 };
 
 /* ---------------------------------------------------------------- lifetime */

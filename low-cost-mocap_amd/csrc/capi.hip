@@ -202,6 +202,7 @@ extern "C" int mocap_set_options(mocap_ctx* ctx, uint32_t flags) {
   std::lock_guard<std::mutex> lk(ctx->mu);
   ctx->flags = flags;
   ctx->cv.f32_rounding = (flags & MOCAP_OPT_F32_ROUNDING) ? 1 : 0;
+  ctx->exhaustive = (flags & MOCAP_OPT_EXHAUSTIVE_WALK) ? 1 : 0;
   return MOCAP_OK;
 }
 
@@ -516,7 +517,7 @@ FramePlan plan_frame(const mocap_ctx* ctx, int M_max, int K_max, int hit_cap_ove
   // (the eigenvalue bounds need K = [[fx,0,cx],[0,fy,cy],[0,0,1]]), <= 16 cameras, <= 64 blobs per camera, <= 255 roots,
   // frames big enough for a 256-lane workgroup (or 256 lanes asked for: MOCAP_FRAME_THREADS / mocap_set_tuning).  Everything
   // else -- and MOCAP_EVAL_BB=0 -- takes the exhaustive walk.  (Decided before narrow / wide: its layout has no odometer columns and fits where the general narrow one does not.)
-  pl.use_bb = ctx->eval_bb && !pl.wide && ctx->cv.uniformK && ctx->prune && ctx->eigcut && ctx->p3max2 > 0.0 && ctx->p3max2c > 0.0 &&
+  pl.use_bb = ctx->eval_bb && !ctx->exhaustive && !pl.wide && ctx->cv.uniformK && ctx->prune && ctx->eigcut && ctx->p3max2 > 0.0 && ctx->p3max2c > 0.0 &&
               (ctx->frame_threads == 256 || (ctx->frame_threads == 0 && ctx->C * M_max > 32)) && ctx->frame_launches != 3 &&
               frame_bb_fits(ctx->C, M_max, K_max);
   if (pl.use_bb) {
@@ -587,8 +588,8 @@ static int match_dev_locked(mocap_ctx* ctx, int64_t n_frames, int M_max, const f
                      lds, ctx->C, M_max, K_max);
   a.H = hit_cap;
   a.wide = wide ? 1 : 0;
-  a.prune = ctx->prune;
-  a.p3max2 = ctx->prune && ctx->eigcut ? ctx->p3max2 : 0.0;
+  a.prune = ctx->prune && !ctx->exhaustive;
+  a.p3max2 = a.prune && ctx->eigcut ? ctx->p3max2 : 0.0;
   if (!wide && ctx->frame_threads == 0 && T == 64) a.p3max2 = 0.0;  // tiny frames (a handful of candidates): the cut-offs cost more than they save
   a.eval_bb = use_bb ? 1 : 0;
   a.bb_pl = ctx->bb_pl;
@@ -801,7 +802,7 @@ static int resubmit_dev_locked(mocap_ctx* ctx, int64_t n_frames, int M_max, cons
   // form EigCut needs: the pass enumerates up to MOCAP_RESUBMIT_G_CAP groups per root (default 4096) and exports the
   // roots above it; elsewhere it enumerates up to 2^24 per root and flags what is larger, as before.
   const FramePlan pl2 = plan_frame(ctx, M_max, K_big, M_max);
-  const bool heavy_ok = pl2.wide && ctx->cv.uniformK && ctx->prune && ctx->eigcut && ctx->p3max2 > 0.0 && !getenv("MOCAP_NO_HEAVY_BB");
+  const bool heavy_ok = pl2.wide && ctx->cv.uniformK && ctx->prune && ctx->eigcut && ctx->p3max2 > 0.0 && !ctx->exhaustive && !getenv("MOCAP_NO_HEAVY_BB");
   int64_t G2 = (int64_t)1 << 24;
   HeavyHook hk{nullptr, nullptr, 0};
   int ncap = 4096;  // (swept on the stress stream: 16 384 and 65 536 solve 1-3 more of ~30 hard roots per 12 500 frames and double the step)

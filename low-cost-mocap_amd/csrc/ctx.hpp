@@ -29,6 +29,7 @@ struct mocap_ctx {
   bool frame_q_clean = false;  // the queue counters were left at zero by the one-launch schedule
   int frame_launches = 1;   // 1: one persistent launch per batch (MODE_ALL); 3: main / slice / merge launches
   int prune = 1;            // stop a candidate group's reprojection once it cannot beat its root's best (exact)
+  int exhaustive = 0;       // MOCAP_OPT_EXHAUSTIVE_WALK: no branch and bound, no cut-offs (verification mode)
   int eval_bb = 1;          // branch-and-bound selection (csrc/frame_bb.hip) wherever it applies; 0: always the exhaustive walk
   int bb_pl = 16;           // ... candidates per block (at least)
   int bb_min_g = 0;         // ... frames with fewer candidates queue every block untested (swept: 0-512 equal, 2048 +13 %)

@@ -26,6 +26,7 @@ ST_ROUNDED = 8          # informational (mocap_match_triangulate_f64): a coordin
 BLOB_ST_POINT_OVERFLOW = 1
 BLOB_ST_CAP_OVERFLOW = 2
 OPT_F32_ROUNDING = 1
+OPT_EXHAUSTIVE_WALK = 2
 
 _vp, _i32, _i64, _dbl, _u32 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_double, ctypes.c_uint32
 
@@ -152,8 +153,10 @@ class MocapCore:
         self._check(self.lib.mocap_set_cameras(self._h, C, _p(K), _p(R), _p(t)))
         self.C = C
 
-    def set_options(self, f32_rounding=True):
-        self._check(self.lib.mocap_set_options(self._h, OPT_F32_ROUNDING if f32_rounding else 0))
+    def set_options(self, f32_rounding=True, exhaustive_walk=False):
+        """exhaustive_walk: MOCAP_OPT_EXHAUSTIVE_WALK, the verification mode (every candidate group evaluated in full)."""
+        self._check(self.lib.mocap_set_options(self._h, (OPT_F32_ROUNDING if f32_rounding else 0) |
+                                               (OPT_EXHAUSTIVE_WALK if exhaustive_walk else 0)))
         self.f32_rounding = bool(f32_rounding)
 
     def set_tuning(self, frame_threads=0, heavy_threshold=-1, slice_size=0):
