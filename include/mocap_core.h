@@ -47,9 +47,18 @@ enum {
   MOCAP_ST_CAND_OVERFLOW = 2, /* a root has more than G_cap candidate groups: invalid */
   MOCAP_ST_HIT_OVERFLOW = 4,  /* wide frames only: a (root, camera) pair has more gated hits
                                  than hit_cap (mocap_set_frame_limits): invalid          */
-  MOCAP_ST_ROUNDED = 8        /* mocap_match_triangulate_f64 only, INFORMATIONAL (outputs valid): a coordinate of the
+  MOCAP_ST_ROUNDED = 8,       /* mocap_match_triangulate_f64 only, INFORMATIONAL (outputs valid): a coordinate of the
                                  frame was not representable in float32 and was rounded to the nearest float32 */
+  MOCAP_ST_INTRACTABLE = 16,  /* set WITH MOCAP_ST_CAND_OVERFLOW by the re-submit pass: a root of the frame has more than 2^24
+                                 candidate groups and the exact search over its multi-hit cameras (csrc/heavy_bb.hip) could not
+                                 bound it -- no enumeration reaches it, the reference's own (helpers.py:394-400) included;
+                                 bits 20..28 of the status word then hold ceil(log2(groups)) of the largest such root */
+  MOCAP_ST_FINAL = 32         /* set by the re-submit pass on a frame it leaves flagged: larger caps do not exist, a repeated
+                                 re-submit skips the frame (frames WITHOUT this bit that are still flagged were not reached:
+                                 scratch batch full -- mocap_resubmit_dev continues with them) */
 };
+#define MOCAP_ST_LOG2_GROUPS_SHIFT 20
+#define MOCAP_ST_LOG2_GROUPS_MASK 0x1FF
 
 /* flags for mocap_set_options */
 enum {
@@ -149,6 +158,14 @@ int mocap_match_triangulate_dev(mocap_ctx* ctx, int64_t n_frames, int M_max, con
                                 double* d_xyz, double* d_err, int16_t* d_corr, int32_t* d_n_out,
                                 int32_t* d_status, int32_t* d_n_cand);
 
+/* mocap_resubmit_dev: the re-submit stage of mocap_match_triangulate_dev_auto on its own -- for a batch whose first pass has
+ * run (same arguments, same buffers): every frame that is flagged and not MOCAP_ST_FINAL is re-run with the largest caps.
+ * A caller that reads d_resubmitted[0] > d_resubmitted[1] after its own synchronisation calls this until the two agree;
+ * every call repairs or finalises at least one frame. */
+int mocap_resubmit_dev(mocap_ctx* ctx, int64_t n_frames, int M_max, const float* d_blobs, const int32_t* d_counts,
+                       double gate_px, int K_max, double* d_xyz, double* d_err, int16_t* d_corr, int32_t* d_n_out,
+                       int32_t* d_status, int32_t* d_n_cand, int32_t* d_resubmitted);
+
 /* mocap_match_triangulate_dev_auto: mocap_match_triangulate_dev, then -- queued behind it on the context's stream, without
  * the host ever waiting -- every frame whose status is non-zero is re-run ON THE DEVICE with the largest caps the core has
  * (root capacity C * M_max as far as a kernel's LDS holds it, G_cap = 2^24 groups per root, every gated hit of a (root,
@@ -157,8 +174,10 @@ int mocap_match_triangulate_dev(mocap_ctx* ctx, int64_t n_frames, int M_max, con
  * fit the caller's K_max slots are scattered back in place.  Status after the call has run: as
  * mocap_match_triangulate_auto (MOCAP_ST_ROOT_OVERFLOW = the frame needs n_out[f] > K_max slots and nothing was written
  * for it; consumers treat n_out > K_max as "no valid slot").  d_resubmitted (may be NULL): [2] device-accessible int32,
- * {frames flagged by the first pass, frames re-run}; the two differ only when the scratch batch (one slot per frame up to
- * MOCAP_RESUBMIT_SCRATCH_MB, default 8192) could not hold every flagged frame -- those keep their status: call again. */
+ * {frames flagged by the first pass, frames re-run}; the two differ only when the scratch batch could not hold every flagged
+ * frame (it is sized for one frame in eight, at least 1 024 frames, within MOCAP_RESUBMIT_SCRATCH_MB, default 8192; halved
+ * until the allocation succeeds) -- those keep their status WITHOUT MOCAP_ST_FINAL: mocap_resubmit_dev continues with them
+ * (the host-buffer entry points loop until none is left). */
 int mocap_match_triangulate_dev_auto(mocap_ctx* ctx, int64_t n_frames, int M_max, const float* d_blobs,
                                      const int32_t* d_counts, double gate_px, int K_max, int64_t G_cap,
                                      double* d_xyz, double* d_err, int16_t* d_corr, int32_t* d_n_out,

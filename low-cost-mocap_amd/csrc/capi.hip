@@ -125,6 +125,7 @@ extern "C" void mocap_destroy(mocap_ctx* ctx) {
   ctx->resub_ctr.release();
   ctx->heavy_recs.release();
   ctx->heavy_ws.release();
+  ctx->heavy_enum.release();
   if (ctx->live_pin) (void)hipHostFree(ctx->live_pin);
   if (ctx->live_event) (void)hipEventDestroy(ctx->live_event);
   ctx->img_map.release();
@@ -752,14 +753,26 @@ static int resubmit_dev_locked(mocap_ctx* ctx, int64_t n_frames, int M_max, cons
   // (default 8192); beyond it, flagged frames keep their status (d_info[0] > d_info[1] says so: call again)
   size_t budget = (size_t)8192 << 20;
   if (const char* e = getenv("MOCAP_RESUBMIT_SCRATCH_MB")) budget = (size_t)(atol(e) > 0 ? atol(e) : 1) << 20;
-  int64_t cap = n_frames;
+  // The scratch batch is sized for the flagged share one expects, not for the whole batch (round-5 advice: a full copy of a
+  // 100 k-frame batch was reserved up front although no frame might be flagged): one frame in eight, at least 1 024.  More
+  // flagged frames than that keep their status without MOCAP_ST_FINAL and d_info says so; mocap_resubmit_dev (and the
+  // host-buffer entry points, in a loop) continue with them.  An allocation that fails is retried at half the size down to
+  // one frame: the first pass has succeeded by now, a missing scratch must not fail the call.
+  int64_t cap = n_frames / 8 < 1024 ? 1024 : n_frames / 8;
+  if (const char* e = getenv("MOCAP_RESUBMIT_SCRATCH_FRAMES")) cap = atol(e) > 0 ? atol(e) : 1;  // (tests: a scratch smaller than the flagged set)
+  if (cap > n_frames) cap = n_frames;
   if ((size_t)cap * per_frame > budget) cap = (int64_t)(budget / per_frame);
   if (cap < 1) cap = 1;
-  const size_t F2 = (size_t)cap;
-  const size_t b_list = al(4 * F2), b_b2 = al(sizeof(float) * F2 * C * M_max * 2), b_c2 = al(4 * F2 * C),
-               b_x2 = al(8 * F2 * K_big * 3), b_e2 = al(8 * F2 * K_big), b_r2 = al(2 * F2 * K_big * C), b_i = al(4 * (F2 + 2));
-  if (ctx->resub.reserve(b_list + b_b2 + b_c2 + b_x2 + b_e2 + b_r2 + 3 * b_i))
-    return ctx->fail(MOCAP_E_HIP, "hipMalloc(re-submit scratch, %zu B) failed", b_list + b_b2 + b_c2 + b_x2 + b_e2 + b_r2 + 3 * b_i);
+  size_t F2, b_list, b_b2, b_c2, b_x2, b_e2, b_r2, b_i;
+  for (;;) {
+    F2 = (size_t)cap;
+    b_list = al(4 * F2), b_b2 = al(sizeof(float) * F2 * C * M_max * 2), b_c2 = al(4 * F2 * C);
+    b_x2 = al(8 * F2 * K_big * 3), b_e2 = al(8 * F2 * K_big), b_r2 = al(2 * F2 * K_big * C), b_i = al(4 * (F2 + 2));
+    if (!ctx->resub.reserve(b_list + b_b2 + b_c2 + b_x2 + b_e2 + b_r2 + 3 * b_i)) break;
+    (void)hipGetLastError();  // (the failed hipMalloc's sticky error)
+    if (cap == 1) return ctx->fail(MOCAP_E_HIP, "hipMalloc(re-submit scratch, %zu B for ONE frame) failed", b_list + b_b2 + b_c2 + b_x2 + b_e2 + b_r2 + 3 * b_i);
+    cap = (cap + 1) / 2;
+  }
   if (!ctx->resub_ctr.ptr) {
     if (ctx->resub_ctr.reserve(256)) return ctx->fail(MOCAP_E_HIP, "hipMalloc(re-submit counters) failed");
     HIP_TRY(ctx, hipMemsetAsync(ctx->resub_ctr.ptr, 0, 256, ctx->stream));
@@ -776,8 +789,10 @@ static int resubmit_dev_locked(mocap_ctx* ctx, int64_t n_frames, int M_max, cons
   ra.blobs = d_blobs;
   ra.counts = d_counts;
   // two counters, 128 bytes apart, alternate between calls: this call's is zero (the previous call's gather cleared it)
+  // (the parity advances only once the gather -- which zeroes the OTHER counter for the next call -- is known to be queued:
+  // a failure before that leaves this call's counter untouched and still zero)
   int32_t* ctr = (int32_t*)ctx->resub_ctr.ptr;
-  const uint32_t par = ctx->resub_calls++ & 1u;
+  const uint32_t par = ctx->resub_calls & 1u;
   ra.count = ctr + 32 * par;
   ra.count_next = ctr + 32 * (par ^ 1u);
   ra.list = (int32_t*)w;   w += b_list;
@@ -807,20 +822,25 @@ static int resubmit_dev_locked(mocap_ctx* ctx, int64_t n_frames, int M_max, cons
   HeavyHook hk{nullptr, nullptr, 0};
   int ncap = 4096;  // (swept on the stress stream: 16 384 and 65 536 solve 1-3 more of ~30 hard roots per 12 500 frames and double the step)
   const int hv_grid = 64;
+  const int enum_grid = ctx->num_cus * 2;  // heavy_enum_kernel: 256-lane workgroups, the whole GPU on one root at a time
   if (const char* e = getenv("MOCAP_HEAVY_NCAP")) ncap = atoi(e) >= 64 ? atoi(e) : 64;
   if (heavy_ok) {
     G2 = 4096;
     if (const char* e = getenv("MOCAP_RESUBMIT_G_CAP")) G2 = atol(e) > 0 ? atol(e) : 1;
     hk.cap = 2048;
-    if (ctx->heavy_recs.reserve((size_t)hk.cap * heavy_rec_bytes(C, M_max)) || ctx->heavy_ws.reserve((size_t)hv_grid * heavy_bb_ws_bytes(ncap)))
+    if (ctx->heavy_recs.reserve((size_t)hk.cap * heavy_rec_bytes(C, M_max)) || ctx->heavy_ws.reserve((size_t)hv_grid * heavy_bb_ws_bytes(ncap)) ||
+        ctx->heavy_enum.reserve(heavy_enum_ws_bytes(kHeavyEnumMax, enum_grid)))
       return ctx->fail(MOCAP_E_HIP, "hipMalloc(heavy-root search buffers) failed");
     hk.recs = (unsigned char*)ctx->heavy_recs.ptr;
     hk.count = ctr + 16;  // (its own word of the counter block; the gather kernel zeroes it)
     ra.heavy_count = hk.count;
+    ra.enum_count = ctr + 17;
   } else {
     ra.heavy_count = nullptr;
+    ra.enum_count = nullptr;
   }
   HIP_TRY(ctx, launch_resubmit_gather(ra, ctx->stream));
+  ctx->resub_calls++;
   const int rc = match_dev_locked(ctx, cap, M_max, ra.b2, ra.c2, gate_px, K_big, G2, x2, e2, r2, n2, s2, g2,
                                   /*hit_cap_override=*/M_max, /*n_frames_dev=*/ra.count, heavy_ok ? &hk : nullptr);
   if (rc) return rc;
@@ -849,7 +869,22 @@ static int resubmit_dev_locked(mocap_ctx* ctx, int64_t n_frames, int M_max, cons
     ha.enum_cap = (int64_t)1 << 16;  // (2^20 in place costs tens of ms on one CU: the first pass, which slices such roots over 64 workgroups, is the place for them)
     if (const char* e = getenv("MOCAP_HEAVY_ENUM_CAP")) ha.enum_cap = atol(e) >= 0 ? atol(e) : 0;
     ha.debug = getenv("MOCAP_HEAVY_DEBUG") ? 1 : 0;
+    {
+      // roots the search gives up on with at most 2^24 groups are enumerated by the whole GPU behind it (heavy_enum_kernel):
+      // the pass stays exact up to 2^24 groups per root, like the enumeration it replaces (round-5 advice)
+      char* e = (char*)ctx->heavy_enum.ptr;
+      ha.enum_max = getenv("MOCAP_NO_HEAVY_ENUM") ? 0 : kHeavyEnumMax;
+      ha.enum_grid = enum_grid;
+      ha.enum_count = ctr + 17;
+      ha.enum_list = (int32_t*)e;    e += 4 * (size_t)kHeavyEnumMax;
+      ha.enum_slice = (int32_t*)e;   e += 4 * (size_t)kHeavyEnumMax;
+      ha.enum_done = (int32_t*)e;    e += 4 * (size_t)kHeavyEnumMax;
+      e = (char*)(((uintptr_t)e + 63) / 64 * 64);
+      ha.enum_bound = (unsigned long long*)e;  e += 8 * (size_t)kHeavyEnumMax;
+      ha.enum_part = (unsigned char*)e;
+    }
     HIP_TRY(ctx, launch_heavy_bb(ha, hv_grid, ctx->stream));
+    HIP_TRY(ctx, launch_heavy_enum(ha, ctx->stream));
   }
   HIP_TRY(ctx, launch_resubmit_scatter(ra, ctx->stream));
   return MOCAP_OK;
@@ -864,6 +899,21 @@ extern "C" int mocap_match_triangulate_dev(mocap_ctx* ctx, int64_t n_frames, int
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   const int rc = match_dev_locked(ctx, n_frames, M_max, d_blobs, d_counts, gate_px, K_max, G_cap, d_xyz, d_err, d_corr,
                                   d_n_out, d_status, d_n_cand);
+  return rc ? rc : ctx->mark_enqueued();
+}
+
+extern "C" int mocap_resubmit_dev(mocap_ctx* ctx, int64_t n_frames, int M_max, const float* d_blobs, const int32_t* d_counts,
+                                  double gate_px, int K_max, double* d_xyz, double* d_err, int16_t* d_corr, int32_t* d_n_out,
+                                  int32_t* d_status, int32_t* d_n_cand, int32_t* d_resubmitted) {
+  if (!ctx) return MOCAP_E_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (!ctx->C) return ctx->fail(MOCAP_E_NOCAMS, "mocap_set_cameras has not been called");
+  if (n_frames < 0 || M_max < 1 || K_max < 1) return ctx->fail(MOCAP_E_ARG, "mocap_resubmit_dev: bad size argument");
+  if (n_frames > 0 && (!d_blobs || !d_counts || !d_xyz || !d_err || !d_corr || !d_n_out || !d_status))
+    return ctx->fail(MOCAP_E_ARG, "mocap_resubmit_dev: null buffer");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const int rc = resubmit_dev_locked(ctx, n_frames, M_max, d_blobs, d_counts, gate_px, K_max, d_xyz, d_err, d_corr, d_n_out, d_status,
+                                     d_n_cand, d_resubmitted);
   return rc ? rc : ctx->mark_enqueued();
 }
 
@@ -944,11 +994,16 @@ static int match_host_locked(mocap_ctx* ctx, int64_t n_frames, int M_max, const 
     bool flagged = false;
     for (size_t f = 0; f < F && resubmit; f++) flagged |= h_status[f] != 0;
     if (flagged) {  // rare: the second pass is queued only when the first one, already back, asks for it
-      rc = resubmit_dev_locked(ctx, n_frames, M_max, h_blobs, h_counts, gate_px, K_max, h_xyz, h_err, h_corr, h_n_out, h_status,
-                               h_n_cand, h_info);
-      if (rc) return rc;
-      HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-      if (n_resubmitted) *n_resubmitted = h_info[1];
+      int total = 0;
+      for (;;) {  // (more than one round only when the scratch batch was smaller than the flagged set)
+        rc = resubmit_dev_locked(ctx, n_frames, M_max, h_blobs, h_counts, gate_px, K_max, h_xyz, h_err, h_corr, h_n_out, h_status,
+                                 h_n_cand, h_info);
+        if (rc) return rc;
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        total += h_info[1];
+        if (h_info[0] <= h_info[1] || h_info[1] <= 0) break;
+      }
+      if (n_resubmitted) *n_resubmitted = total;
     }
     memcpy(n_out, h_n_out, b_i);
     memcpy(status, h_status, b_i);
@@ -981,10 +1036,17 @@ static int match_host_locked(mocap_ctx* ctx, int64_t n_frames, int M_max, const 
   if (rc) return rc;
   int32_t h_info[2] = {0, 0};
   if (resubmit) {
-    rc = resubmit_dev_locked(ctx, n_frames, M_max, d_blobs, d_counts, gate_px, K_max, d_xyz, d_err, d_corr, d_n_out, d_status,
-                             d_n_cand, d_info);
-    if (rc) return rc;
-    HIP_TRY(ctx, hipMemcpyAsync(h_info, d_info, sizeof h_info, hipMemcpyDeviceToHost, ctx->stream));
+    int total = 0;
+    for (;;) {  // (more than one round only when the scratch batch was smaller than the flagged set)
+      rc = resubmit_dev_locked(ctx, n_frames, M_max, d_blobs, d_counts, gate_px, K_max, d_xyz, d_err, d_corr, d_n_out, d_status,
+                               d_n_cand, d_info);
+      if (rc) return rc;
+      HIP_TRY(ctx, hipMemcpyAsync(h_info, d_info, sizeof h_info, hipMemcpyDeviceToHost, ctx->stream));
+      HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+      total += h_info[1];
+      if (h_info[0] <= h_info[1] || h_info[1] <= 0) break;
+    }
+    h_info[1] = total;
   }
   HIP_TRY(ctx, hipMemcpyAsync(xyz, d_xyz, b_xyz, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(err, d_err, b_err, hipMemcpyDeviceToHost, ctx->stream));

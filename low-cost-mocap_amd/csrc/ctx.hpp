@@ -82,6 +82,7 @@ struct mocap_ctx {
   DevBuf resub_ctr;         // ... its two alternating counters (never re-allocated while a call is in flight)
   DevBuf heavy_recs;        // ... heavy roots exported by the second pass (csrc/heavy_bb.hip)
   DevBuf heavy_ws;          // ... the search's frontier workspace
+  DevBuf heavy_enum;        // ... queue + per-workgroup winners of the roots enumerated over the whole GPU (heavy_enum_kernel)
   uint32_t resub_calls = 0; // ... parity selects the counter of the current call
   DevBuf scratch[4];        // [0] host-API staging, [1..3] bundle adjustment workspace
 

@@ -34,6 +34,9 @@ namespace mocap {
 
 constexpr int kHvThreads = 1024;  // (one workgroup per CU: the frontier of a hard root is tens of thousands of nodes per level)
 constexpr int kHvEnumDigits = 20;  // multi-hit cameras of a root the fall-back enumerates (product <= 2^20, two hits at least each)
+constexpr int kHvGlobalEnumDigits = 24;  // ... of a root heavy_enum_kernel enumerates over the whole GPU (product <= 2^24)
+constexpr int kHvEnumThreads = 256;
+constexpr int kHvEnumSlice = 16 * kHvEnumThreads;  // groups per slice
 constexpr int kHvDigits = 64;  // digit slots of a node (>= multi-hit cameras of a root: < kMaxCameras)
 
 size_t heavy_bb_ws_bytes(int ncap) { return (size_t)2 * ncap * (sizeof(double) * 10 + kHvDigits); }
@@ -208,8 +211,43 @@ __global__ __launch_bounds__(kHvThreads) void heavy_bb_kernel(HeavyArgs a) {
       for (int j = 0; j < m; j++) prod *= (double)s_n[s_dcam[j]];
       if (!(prod <= (double)a.enum_cap) || !(prod <= 1048576.0) || m > kHvEnumDigits) {
         if (tid == 0) {
-          a.status[hd.frame] |= MOCAP_ST_CAND_OVERFLOW_;
-          a.n_out[hd.frame] = 0;
+          // at most 2^24 groups: the whole GPU enumerates the root behind this kernel (heavy_enum_kernel) -- the re-submit
+          // pass is exact up to there, as the frame kernels' own enumeration is.  Above: no enumeration reaches it (the
+          // reference's own included) and the bound has just failed: the frame says so.
+          int slot = -1;
+          if (prod <= 16777216.0 && m <= kHvGlobalEnumDigits && a.enum_count) {
+            slot = atomicAdd(a.enum_count, 1);
+            if (slot < a.enum_max) {
+              a.enum_list[slot] = h;
+              a.enum_slice[slot] = 0;
+              a.enum_done[slot] = 0;
+              a.enum_bound[slot] = 0x7ff0000000000000ull;
+            } else {
+              slot = -2;
+            }
+          }
+          if (slot < 0) {
+            int flags = MOCAP_ST_CAND_OVERFLOW_;
+            if (slot == -1 && !(prod <= 16777216.0)) {
+              double l2 = 0.0;
+              for (int j = 0; j < m; j++) l2 += log2((double)s_n[s_dcam[j]]);
+              int lg = (int)ceil(l2 - 1e-9);
+              lg = lg < 25 ? 25 : (lg > 511 ? 511 : lg);
+              flags |= MOCAP_ST_INTRACTABLE_;
+              // the largest root's log2(groups) in bits 20..28 (several roots of a frame may arrive from different workgroups)
+              int old = __hip_atomic_load(&a.status[hd.frame], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              while (true) {
+                const int of = (old >> MOCAP_ST_LOG2_GROUPS_SHIFT_) & 0x1FF;
+                const int want = ((old | flags) & ~(0x1FF << MOCAP_ST_LOG2_GROUPS_SHIFT_)) | ((of > lg ? of : lg) << MOCAP_ST_LOG2_GROUPS_SHIFT_);
+                const int seen = atomicCAS(&a.status[hd.frame], old, want);
+                if (seen == old) break;
+                old = seen;
+              }
+            } else {
+              atomicOr(&a.status[hd.frame], flags);
+            }
+            a.n_out[hd.frame] = 0;
+          }
         }
         continue;
       }
@@ -357,6 +395,201 @@ __global__ __launch_bounds__(kHvThreads) void heavy_bb_kernel(HeavyArgs a) {
       a.corr[o * C + tid] = s;
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// heavy_enum_kernel: the roots the search gave up on with at most 2^24 groups, ENUMERATED -- every group of the Cartesian
+// product triangulated and scored by the path's own device function (helpers.py:394-421 as written), the whole GPU on one
+// root at a time.  All workgroups walk the queued roots in the same order and pull slices of the root's group range from a
+// counter; a lane keeps the first minimum of its ascending run, the smallest error seen anywhere (a global word) is everybody's
+// cut-off (a cut-off only ever skips work: mocap_device.hpp); per workgroup the lexicographic minimum of (error bits, group
+// index) goes to a partial record, and the last workgroup to report merges the records the same way and writes the root's
+// slot -- the first minimum in candidate order (np.argmin, helpers.py:418), whatever ran where.
+struct HvPart {
+  unsigned long long ebits;
+  uint32_t g, pad;
+  double X[3];
+};
+static_assert(sizeof(HvPart) == kHeavyEnumPartBytes, "partial record layout");
+
+template <bool F32R>
+__global__ __launch_bounds__(kHvEnumThreads) void heavy_enum_kernel(HeavyArgs a) {
+  __shared__ uint16_t s_n[kMaxCameras];
+  __shared__ uint8_t s_lvl[kMaxCameras];
+  __shared__ uint8_t s_dcam[kMaxCameras];
+  __shared__ int s_m, s_slice, s_last;
+  __shared__ uint32_t s_G;
+  __shared__ unsigned long long s_best, s_gbest;
+  __shared__ uint8_t s_dg[kHvGlobalEnumDigits][kHvEnumThreads];
+  const int tid = threadIdx.x;
+  const int C = a.cv.C, M = a.M;
+  int n_roots = *a.enum_count;
+  if (n_roots > a.enum_max) n_roots = a.enum_max;
+  const double inf = __builtin_huge_val();
+  for (int s = 0; s < n_roots; s++) {
+    const int h = a.enum_list[s];
+    const unsigned char* rec = a.recs + (size_t)h * a.stride;
+    const HeavyRecHdr hd = *reinterpret_cast<const HeavyRecHdr*>(rec);
+    const uint16_t* nc = reinterpret_cast<const uint16_t*>(rec + heavy_rec_counts_off());
+    const uint8_t* hl = rec + heavy_rec_hits_off(C);
+    const int Hs = hd.Hs;
+    const float2* fb = (const float2*)(a.blobs + (size_t)hd.frame * C * M * 2);
+    const size_t o = (size_t)hd.frame * a.K_big + hd.outslot;
+    block_sync_lds();  // (the previous root's shared state is dead)
+    if (tid < C) s_n[tid] = nc[tid];
+    if (tid == 0) {
+      int m = 0;
+      unsigned long long G = 1;
+      for (int c = 0; c < C; c++) {
+        s_lvl[c] = 0xFF;
+        if (nc[c] > 1) {
+          s_lvl[c] = (uint8_t)m;
+          s_dcam[m++] = (uint8_t)c;
+          G *= nc[c];
+        }
+      }
+      s_m = m;
+      s_G = (uint32_t)G;  // (<= 2^24: heavy_bb_kernel queued it)
+      s_best = 0x7ff0000000000000ull;
+      s_gbest = ~0ull;
+    }
+    __syncthreads();
+    const int m = s_m;
+    const uint32_t G = s_G;
+    const uint32_t n_slices = (G + kHvEnumSlice - 1) / kHvEnumSlice;
+    EigCut ec;
+    {
+      const double om = (double)__int_as_float(hd.omax_bits);
+      ec.p3max2 = a.p3max2;
+      ec.o2slack = (1100.0 * 0x1p-46) * (om * om);
+    }
+    double be = inf, bX[3] = {0, 0, 0};
+    uint32_t bg = 0;
+    while (true) {
+      if (tid == 0) s_slice = atomicAdd(&a.enum_slice[s], 1);
+      __syncthreads();
+      const uint32_t sl = (uint32_t)s_slice;
+      __syncthreads();
+      if (sl >= n_slices) break;  // (uniform)
+      const uint32_t g1 = (sl + 1) * (uint32_t)kHvEnumSlice < G ? (sl + 1) * (uint32_t)kHvEnumSlice : G;
+      for (uint32_t g = sl * (uint32_t)kHvEnumSlice + (uint32_t)tid; g < g1; g += kHvEnumThreads) {
+        // digits of g: the first multi-hit camera is the fastest one (helpers.py:394-400 order, as in frame_kernel.hip)
+        uint32_t rem = g;
+        for (int j = 0; j < m; j++) {
+          uint32_t qd, d;
+          divmod_small(rem, (uint32_t)s_n[s_dcam[j]], qd, d);
+          rem = qd;
+          s_dg[j][tid] = (uint8_t)d;
+        }
+        auto obs = [&](int c, double& x, double& y) -> bool {
+          const int n = s_n[c];
+          if (!n) return false;
+          const int d = n > 1 ? s_dg[s_lvl[c]][tid] : 0;
+          const float2 w = fb[(size_t)c * M + hl[(size_t)c * Hs + d]];
+          x = (double)w.x;
+          y = (double)w.y;
+          return true;
+        };
+        double X[3], e = inf;
+        const double bound = __longlong_as_double((long long)__hip_atomic_load(&a.enum_bound[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        triangulate_and_score<true, true, F32R, 1, false>(a.cv, obs, obs, X, e, bound, ec);
+        if (e < be) {  // strict <: the first minimum of this lane's ascending run
+          be = e;
+          bg = g;
+          bX[0] = X[0]; bX[1] = X[1]; bX[2] = X[2];
+          atomicMin(&a.enum_bound[s], (unsigned long long)__double_as_longlong(e));
+        }
+      }
+    }
+    // the workgroup's winner: smallest error bits, then smallest group index among its holders
+    if (be < inf) atomicMin(&s_best, (unsigned long long)__double_as_longlong(be));
+    __syncthreads();
+    const unsigned long long wb = s_best;
+    if (be < inf && (unsigned long long)__double_as_longlong(be) == wb) atomicMin(&s_gbest, (unsigned long long)bg);
+    __syncthreads();
+    HvPart* part = reinterpret_cast<HvPart*>(a.enum_part) + (size_t)s * a.enum_grid;
+    if (wb == 0x7ff0000000000000ull) {
+      if (tid == 0) {
+        q_st(&part[blockIdx.x].ebits, wb);  // (agent-scope stores: the merging workgroup may sit on another XCD)
+        q_st(&part[blockIdx.x].g, 0xFFFFFFFFu);
+      }
+    } else if (be < inf && (unsigned long long)__double_as_longlong(be) == wb && (unsigned long long)bg == s_gbest) {  // (one lane)
+      q_st(&part[blockIdx.x].ebits, wb);
+      q_st(&part[blockIdx.x].g, bg);
+      q_st(&part[blockIdx.x].X[0], bX[0]);
+      q_st(&part[blockIdx.x].X[1], bX[1]);
+      q_st(&part[blockIdx.x].X[2], bX[2]);
+    }
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) s_last = atomicAdd(&a.enum_done[s], 1) == (int)gridDim.x - 1;
+    __syncthreads();
+    if (!s_last) continue;  // (uniform)
+    // ---- the last workgroup to report merges (its loads see the others' records: each was fenced before its count)
+    __threadfence();
+    if (tid == 0) {
+      s_best = 0x7ff0000000000000ull;
+      s_gbest = ~0ull;
+    }
+    __syncthreads();
+    for (int w = tid; w < (int)gridDim.x; w += kHvEnumThreads) {
+      const unsigned long long eb = __hip_atomic_load(&part[w].ebits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (eb != 0x7ff0000000000000ull) atomicMin(&s_best, eb);
+    }
+    __syncthreads();
+    const unsigned long long fb_ = s_best;
+    if (fb_ == 0x7ff0000000000000ull) continue;  // no group with a finite error: the frame kernel's group 0 stands
+    for (int w = tid; w < (int)gridDim.x; w += kHvEnumThreads)
+      if (__hip_atomic_load(&part[w].ebits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == fb_)
+        atomicMin(&s_gbest, (unsigned long long)__hip_atomic_load(&part[w].g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    __syncthreads();
+    const uint32_t gw = (uint32_t)s_gbest;
+    for (int w = tid; w < (int)gridDim.x; w += kHvEnumThreads) {
+      if (__hip_atomic_load(&part[w].ebits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == fb_ &&
+          __hip_atomic_load(&part[w].g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gw) {  // (one record: a group lives in one slice)
+        const double X[3] = {__hip_atomic_load(&part[w].X[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                             __hip_atomic_load(&part[w].X[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                             __hip_atomic_load(&part[w].X[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)};
+        FrameArgs fa;  // (store_point only looks at xyz and world)
+        fa.xyz = a.xyz;
+        fa.world = a.world;
+        store_point(fa, o, X);
+        a.err[o] = __longlong_as_double((long long)fb_);
+        uint32_t rem = gw;
+        uint8_t dg[kHvGlobalEnumDigits];
+        for (int j = 0; j < m; j++) {
+          uint32_t qd, d;
+          divmod_small(rem, (uint32_t)s_n[s_dcam[j]], qd, d);
+          rem = qd;
+          dg[j] = (uint8_t)d;
+        }
+        for (int c = 0; c < C; c++) {
+          const int n = s_n[c];
+          int16_t sidx = -1;
+          if (n) {
+            int d = 0;
+            if (n > 1)
+              for (int j = 0; j < m; j++)
+                if (s_dcam[j] == c) d = dg[j];
+            sidx = (int16_t)hl[(size_t)c * Hs + d];
+          }
+          a.corr[o * C + c] = sidx;
+        }
+      }
+    }
+  }
+}
+
+size_t heavy_enum_ws_bytes(int enum_max, int grid) {
+  return (size_t)enum_max * (4 + 4 + 4 + 8) + 64 + (size_t)enum_max * grid * kHeavyEnumPartBytes;
+}
+
+hipError_t launch_heavy_enum(const HeavyArgs& a, hipStream_t stream) {
+  if (a.cv.f32_rounding)
+    hipLaunchKernelGGL(heavy_enum_kernel<true>, dim3(a.enum_grid), dim3(kHvEnumThreads), 0, stream, a);
+  else
+    hipLaunchKernelGGL(heavy_enum_kernel<false>, dim3(a.enum_grid), dim3(kHvEnumThreads), 0, stream, a);
+  return hipGetLastError();
 }
 
 hipError_t launch_heavy_bb(const HeavyArgs& a, int grid, hipStream_t stream) {

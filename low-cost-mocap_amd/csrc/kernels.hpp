@@ -11,6 +11,9 @@ namespace mocap {
 constexpr int MOCAP_ST_ROOT_OVERFLOW_ = 1;
 constexpr int MOCAP_ST_CAND_OVERFLOW_ = 2;
 constexpr int MOCAP_ST_HIT_OVERFLOW_ = 4;
+constexpr int MOCAP_ST_INTRACTABLE_ = 16;
+constexpr int MOCAP_ST_FINAL_ = 32;
+constexpr int MOCAP_ST_LOG2_GROUPS_SHIFT_ = 20;
 
 // device-side work queues of the frame path (see the scheduling note in frame_kernel.hip)
 constexpr int MODE_MAIN = 0, MODE_SLICE = 1, MODE_MERGE = 2, MODE_ALL = 3;
@@ -104,7 +107,20 @@ struct HeavyArgs {
   int ncap;                    // nodes per frontier buffer
   int64_t enum_cap;            // a root the search gives up on is enumerated in place when its product is at most this
   int debug;                   // MOCAP_HEAVY_DEBUG: one printf per root
+  // roots the search gives up on whose product is above enum_cap and at most 2^24: queued for heavy_enum_kernel, which
+  // enumerates them over the whole GPU (the contract of the re-submit pass: exact up to 2^24 groups per root)
+  int32_t* enum_count;         // [1] queued roots (zeroed by the gather kernel)
+  int32_t* enum_list;          // [enum_max] their record numbers
+  int32_t* enum_slice;         // [enum_max] next slice of the root's group range
+  int32_t* enum_done;          // [enum_max] workgroups that have reported
+  unsigned long long* enum_bound;  // [enum_max] smallest error seen so far (bit pattern): every workgroup's cut-off
+  unsigned char* enum_part;    // [enum_max][enum_grid][kHeavyEnumPartBytes] per-workgroup winners
+  int enum_max, enum_grid;
 };
+constexpr int kHeavyEnumPartBytes = 40;  // {error bits u64, group u32, pad u32, X[3]}
+constexpr int kHeavyEnumMax = 256;  // roots per re-submit call (beyond: the frame keeps its candidate-overflow flag)
+size_t heavy_enum_ws_bytes(int enum_max, int grid);
+hipError_t launch_heavy_enum(const HeavyArgs& a, hipStream_t stream);
 size_t heavy_bb_ws_bytes(int ncap);
 hipError_t launch_heavy_bb(const HeavyArgs& a, int grid, hipStream_t stream);
 
@@ -205,6 +221,7 @@ struct ResubmitArgs {
   int32_t* n_cand;           // or null
   int32_t* info;             // null, or [2] out: {frames flagged, frames re-run}
   int32_t* heavy_count;      // null, or the heavy-root export counter of the second pass: zeroed by the gather kernel
+  int32_t* enum_count;       // null, or the counter of roots queued for heavy_enum_kernel: zeroed by the gather kernel
 };
 hipError_t launch_resubmit_gather(const ResubmitArgs& a, hipStream_t stream);
 hipError_t launch_resubmit_scatter(const ResubmitArgs& a, hipStream_t stream);

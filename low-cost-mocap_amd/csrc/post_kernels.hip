@@ -347,11 +347,12 @@ __global__ __launch_bounds__(256) void resubmit_gather_kernel(ResubmitArgs a) {
   if (wave == 0 && lane == 0) {
     *a.count_next = 0;
     if (a.heavy_count) *a.heavy_count = 0;
+    if (a.enum_count) *a.enum_count = 0;
   }
   const int64_t f0 = wave * 64;
   if (f0 >= a.n_frames) return;
   const int64_t f = f0 + lane;
-  const bool flagged = f < a.n_frames && a.status[f] != 0;
+  const bool flagged = f < a.n_frames && a.status[f] != 0 && !(a.status[f] & MOCAP_ST_FINAL_);  // (FINAL: an earlier re-submit has seen it)
   unsigned long long m = __ballot(flagged);
   if (!m) return;
   int base = 0;
@@ -381,9 +382,12 @@ __global__ __launch_bounds__(256) void resubmit_scatter_kernel(ResubmitArgs a) {
     const int64_t f = a.list[j];
     const int n = a.n2[j], s = a.s2[j];
     if (threadIdx.x == 0) {
-      a.n_out[f] = n;  // > K_max: the caller's arrays are too small for this frame -- status says so, n_out how many it needs
+      // > K_max: the caller's arrays are too small for this frame -- status says so, n_out how many it needs.  A frame the second
+      // pass leaves flagged (s != 0) reports NO valid slot: its xyz / err / corr slots still hold the first pass's data, and the
+      // device-side consumers (locate_objects, track export, compaction) gate on n_out alone
+      a.n_out[f] = s != 0 ? 0 : n;
       if (a.n_cand) a.n_cand[f] = a.g2[j];
-      a.status_out[f] = (s == 0 && n > a.K_max) ? MOCAP_ST_ROOT_OVERFLOW_ : s;
+      a.status_out[f] = (s == 0 && n > a.K_max) ? MOCAP_ST_ROOT_OVERFLOW_ : (s ? (s | MOCAP_ST_FINAL_) : 0);
     }
     if (s != 0 || n > a.K_max) continue;  // (uniform)
     const size_t so = (size_t)j * a.K_big, dd = (size_t)f * a.K_max;

@@ -22,6 +22,9 @@ MOCAP_E_NOCONV = -5
 ST_ROOT_OVERFLOW = 1
 ST_CAND_OVERFLOW = 2
 ST_HIT_OVERFLOW = 4
+ST_INTRACTABLE = 16      # with ST_CAND_OVERFLOW: a root of more than 2^24 groups the exact search could not bound
+ST_FINAL = 32            # the re-submit pass has seen the frame: its status is final
+ST_LOG2_GROUPS_SHIFT, ST_LOG2_GROUPS_MASK = 20, 0x1FF
 ST_ROUNDED = 8          # informational (mocap_match_triangulate_f64): a coordinate was rounded to float32
 BLOB_ST_POINT_OVERFLOW = 1
 BLOB_ST_CAP_OVERFLOW = 2
@@ -50,6 +53,7 @@ SIGNATURES = {
     "mocap_match_triangulate": (_i32, [_vp, _i64, _i32, _vp, _vp, _dbl, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mocap_match_triangulate_dev": (_i32, [_vp, _i64, _i32, _vp, _vp, _dbl, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mocap_match_triangulate_dev_auto": (_i32, [_vp, _i64, _i32, _vp, _vp, _dbl, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mocap_resubmit_dev": (_i32, [_vp, _i64, _i32, _vp, _vp, _dbl, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mocap_match_triangulate_auto": (_i32, [_vp, _i64, _i32, _vp, _vp, _dbl, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mocap_match_triangulate_f64": (_i32, [_vp, _i64, _i32, _vp, _vp, _dbl, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mocap_track_frame": (_i32, [_vp, _i64, _i32, _vp, _vp, _dbl, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
@@ -416,6 +420,14 @@ class MocapCore:
             self._h, int(n_frames), int(M_max), _vp(d_blobs), _vp(d_counts), float(gate_px), int(K_max),
             int(G_cap), _vp(d_xyz), _vp(d_err), _vp(d_corr), _vp(d_n_out), _vp(d_status), _vp(d_n_cand or 0),
             _vp(d_resubmitted or 0)))
+
+    def resubmit_dev(self, n_frames, M_max, d_blobs, d_counts, gate_px, K_max, d_xyz, d_err, d_corr, d_n_out, d_status,
+                     d_n_cand=0, d_resubmitted=0):
+        """mocap_resubmit_dev: the re-submit stage alone, for a batch whose first pass has run (continues where a scratch batch
+        smaller than the flagged set stopped: d_resubmitted[0] > d_resubmitted[1])."""
+        self._check(self.lib.mocap_resubmit_dev(
+            self._h, int(n_frames), int(M_max), _vp(d_blobs), _vp(d_counts), float(gate_px), int(K_max), _vp(d_xyz), _vp(d_err),
+            _vp(d_corr), _vp(d_n_out), _vp(d_status), _vp(d_n_cand or 0), _vp(d_resubmitted or 0)))
 
     def compact_tracks_dev(self, n_frames, K_max, d_n_out, d_xyz, d_err, d_corr, d_offsets, d_records, capacity, d_total=0):
         """Valid points of a frame batch -> fixed-stride records + exclusive prefix of n_out (device pointers)."""

@@ -1,7 +1,7 @@
 """Device-side verification helpers: a frame batch's outputs as torch tensors, and bit-for-bit comparison of two
 result sets without leaving HBM.  Used by bench.py (`parity.full_batch_vs_exhaustive_bit_exact`: the whole timed batch
 against the exhaustive walk, MOCAP_OPT_EXHAUSTIVE_WALK) and by tests/test_gpu_bench_scale.py (the bench stream x 20
-repetitions; run-to-run equality at 64 x 256 and 4 x 4).  No oracle here: both sides are the core itself -- what is checked is
+repetitions; run-to-run equality at 64 x 256 and 4 x 4).  Both sides of a comparison are the core itself -- what is checked is
 that the shipped selection (exact branch and bound, csrc/frame_bb.hip) and its synchronisation return, at the scale the
 metric is quoted on, every bit the walk over all candidate groups returns (helpers.py:408-421)."""
 import torch

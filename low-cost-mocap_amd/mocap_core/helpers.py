@@ -241,8 +241,7 @@ def find_point_correspondance_and_object_points(image_points, camera_poses, fram
         # still over a cap after the worst-case re-submit (> 2^24 candidate groups for one root, > 2^32 per
         # frame, C*M > 1024 roots): the reference would enumerate the full product; an empty answer would be
         # silently wrong
-        raise capi.MocapError(f"frame exceeds the core's limits (status {int(res['status'][0])}): "
-                              "candidate groups / roots over the caps of include/mocap_core.h")
+        raise capi.MocapError(_status_message(int(res["status"][0])))
     k = int(res["n_out"][0])
     if k == 0:
         return np.array([]), np.array([]), frames
@@ -339,8 +338,7 @@ def track_frame(image_points, camera_poses, is_locating_objects=True, O_max=8):
         blobs, counts, _ = pack_frame(image_points)
         res = core.track_frame(blobs, counts, gate_px=5.0, O_max=O_max if is_locating_objects else 0)
     if int(res["status"][0]) != 0:
-        raise capi.MocapError(f"frame exceeds the core's limits (status {int(res['status'][0])}): "
-                              "candidate groups / roots over the caps of include/mocap_core.h")
+        raise capi.MocapError(_status_message(int(res["status"][0])))
     k = int(res["n_pts"][0])
     if k == 0:
         return np.array([]), np.array([]), []
@@ -397,6 +395,15 @@ def object_points_payload(errors, object_points, objects, filtered_objects=()):
         "objects": [{k: (v.tolist() if isinstance(v, np.ndarray) else v) for (k, v) in obj.items()} for obj in objects],
         "filtered_objects": list(filtered_objects),
     }
+
+
+def _status_message(st):
+    """What a frame's status word says once the core's worst-case re-submit has run (include/mocap_core.h MOCAP_ST_*)."""
+    if st & capi.ST_INTRACTABLE:
+        lg = (st >> capi.ST_LOG2_GROUPS_SHIFT) & capi.ST_LOG2_GROUPS_MASK
+        return (f"frame has a root with about 2^{lg} candidate groups (status {st}): the reference would enumerate all of them "
+                "(helpers.py:394-400) and never return; no enumeration reaches it and the exact search could not bound it")
+    return (f"frame exceeds the core's limits (status {st}): candidate groups / roots over the caps of include/mocap_core.h")
 
 
 # ----------------------------------------------------------------------------- initial poses (caller of BA)
@@ -490,7 +497,20 @@ def bundle_adjustment(image_points, camera_poses, socketio, return_info=False):
                 core.set_ba_progress(None)
         else:
             from scipy import optimize
-            from scipy.optimize._numdiff import _compute_absolute_step
+            # SciPy's own step rule for jac='2-point' (a PRIVATE helper: its 4-argument form exists in SciPy 1.5 .. 1.15; checked
+            # here, not assumed).  Anything else -- import error, another signature, a step that is not what approx_derivative
+            # would take -- falls back to jac='2-point' (the reference's call verbatim: n + 1 separate residual evaluations)
+            _compute_absolute_step = None
+            try:
+                import inspect
+                from scipy.optimize._numdiff import _compute_absolute_step as _cas
+                if list(inspect.signature(_cas).parameters)[:4] == ["rel_step", "x0", "f0", "method"]:
+                    probe = _cas(None, np.array([1.0, -2.0, 0.0]), np.zeros(2, dtype=np.float32), "2-point")
+                    eps32 = float(np.finfo(np.float32).eps) ** 0.5
+                    if np.allclose(probe, [eps32, -2.0 * eps32, eps32], rtol=1e-12, atol=0.0):
+                        _compute_absolute_step = _cas
+            except Exception:
+                _compute_absolute_step = None
 
             last = {"x": None, "r": None}
             spent = {"core_s": 0.0}                             # wall time inside the core's calls (the rest is SciPy's own)
@@ -539,7 +559,7 @@ def bundle_adjustment(image_points, camera_poses, socketio, return_info=False):
                     J_T[i] = df / dx[i]
                 return J_T.T
 
-            use_batched = os.environ.get("MOCAP_BA_BATCHED_JAC", "1") != "0"
+            use_batched = os.environ.get("MOCAP_BA_BATCHED_JAC", "1") != "0" and _compute_absolute_step is not None
             res = optimize.least_squares(residual_function, x0, jac=jacobian if use_batched else "2-point", verbose=0,
                                          loss="cauchy", ftol=1e-2)
             x, info = res.x, {"iterations": res.njev, "njev": res.njev, "nfev": res.nfev, "status": res.status,

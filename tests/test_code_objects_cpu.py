@@ -77,7 +77,9 @@ def test_wide_kernel_budget(kernels):
     heavy = _find(kernels, "frame_kernelILi1024ELb1ELb1ELb1ELi3ELb1E")
     assert heavy["vgpr_count"] <= 128 and k["vgpr_spill_count"] < heavy["vgpr_spill_count"] + 40, heavy
     hv = _find(kernels, "heavy_bb_kernelILb1E")
-    assert hv["vgpr_count"] <= 128 and hv["vgpr_spill_count"] <= 40, hv     # (1 024 lanes: one workgroup per CU)
+    assert hv["vgpr_count"] <= 128 and hv["vgpr_spill_count"] <= 60, hv     # (1 024 lanes: one workgroup per CU; round 6: + the intractable-root bookkeeping, 55)
+    en = _find(kernels, "heavy_enum_kernelILb1E")
+    assert en["vgpr_count"] <= 128 and en["vgpr_spill_count"] == 0, en      # the enumeration over the whole GPU (round 6)
 
 
 # ---------------------------------------------------------------- synchronisation of the shipped ISA (tests/isa_barriers.py)

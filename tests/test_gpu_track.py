@@ -382,3 +382,45 @@ def test_track_frame_dev_resubmits_before_the_object_search(core):
     assert not a["st"].any() and not b["st"].any() and np.array_equal(a["n"], b["n"]) and np.array_equal(a["nobj"], b["nobj"])
     valid = np.arange(K)[None, :] < a["n"][:, None]
     assert np.array_equal(a["xyz"][valid], b["xyz"][valid]) and np.array_equal(a["corr"][valid], b["corr"][valid])
+
+
+def test_resubmit_continues_where_a_small_scratch_stopped(core, monkeypatch):
+    """Round-5 advice: the re-submit's scratch batch is sized for the flagged share one expects (one frame in eight), and a
+    batch with more flagged frames must still be repaired.  With a scratch of 7 frames (MOCAP_RESUBMIT_SCRATCH_FRAMES): the
+    device entry repairs 7 and says so; mocap_resubmit_dev continues with the rest -- every call makes progress, repaired
+    frames are not picked again -- until the batch equals, bit for bit, a run whose caps never bound.  The host-buffer entry
+    loops by itself."""
+    import torch
+    from mocap_core import devcheck, synth
+    rig = synth.ring_rig(8)
+    blobs, counts, _ = synth.make_blob_stream(rig, 3000, 16, seed=3)
+    core.set_cameras(rig["K"], rig["R"], rig["t"])
+    dev = torch.device("cuda", 0)
+    d_b, d_c = torch.from_numpy(blobs).to(dev), torch.from_numpy(counts).to(dev)
+    want = devcheck.FrameOutputs(3000, 64, 8, dev)
+    want.run(core, 16, d_b, d_c, 5.0, 1 << 24)
+    core.synchronize()
+    assert not want.status.any().item()
+    monkeypatch.setenv("MOCAP_RESUBMIT_SCRATCH_FRAMES", "7")
+    got = devcheck.FrameOutputs(3000, 64, 8, dev)
+    got.run(core, 16, d_b, d_c, 5.0, 64)
+    core.synchronize()
+    flagged, rerun = got.info.cpu().tolist()
+    assert flagged > 20 and rerun == 7
+    assert int((got.status != 0).sum().item()) == flagged - 7 and not got.n_out[got.status != 0].any().item()
+    rounds, left = 0, flagged - 7
+    while left > 0:
+        core.resubmit_dev(3000, 16, d_b.data_ptr(), d_c.data_ptr(), 5.0, 64, got.xyz.data_ptr(), got.err.data_ptr(), got.corr.data_ptr(),
+                          got.n_out.data_ptr(), got.status.data_ptr(), got.n_cand.data_ptr(), got.info.data_ptr())
+        core.synchronize()
+        f2, r2 = got.info.cpu().tolist()
+        assert f2 == left and r2 == min(left, 7)           # only the frames still flagged are picked; each round takes 7
+        left -= r2
+        rounds += 1
+    assert rounds == -(-(flagged - 7) // 7)
+    cmp = devcheck.compare_bitwise(got, want)
+    assert cmp["frames_differing"] == 0, cmp
+    host = core.match_triangulate_auto(blobs, counts, K_max=64, G_cap=64)
+    assert host["resubmitted"] == flagged and not host["status"].any()
+    valid = np.arange(64)[None, :] < host["n_out"][:, None]
+    assert np.array_equal(host["n_out"], want.n_out.cpu().numpy()) and np.array_equal(host["xyz"][valid], want.xyz.cpu().numpy()[valid])

@@ -221,16 +221,21 @@ def test_heavy_root_search_equals_the_enumeration(core):
     assert ok.sum() >= 20
     valid = (np.arange(384)[None, :] < plain["n_out"][:, None]) & ok[:, None]
     # second leg: a frontier of 64 nodes -- the search gives up on most of these roots and its fall-back enumerates them in
-    # place (products up to 2^20): the same bits again
-    for ncap in (None, "64"):
+    # place (products up to 2^16): the same bits again.  Third leg (round 6): no in-place fall-back either
+    # (MOCAP_HEAVY_ENUM_CAP=0) -- every root the search gives up on goes to heavy_enum_kernel, the enumeration over the whole
+    # GPU that keeps the re-submit exact up to 2^24 groups per root: the same bits once more.
+    for ncap, ecap in ((None, None), ("64", None), ("64", "0")):
         os.environ["MOCAP_RESUBMIT_G_CAP"] = "8"
         if ncap:
             os.environ["MOCAP_HEAVY_NCAP"] = ncap
+        if ecap:
+            os.environ["MOCAP_HEAVY_ENUM_CAP"] = ecap
         try:
             auto = core.match_triangulate_auto(blobs, counts, gate_px=synth.STRESS_GATE_PX, K_max=384, G_cap=1)
         finally:
             del os.environ["MOCAP_RESUBMIT_G_CAP"]
             os.environ.pop("MOCAP_HEAVY_NCAP", None)
+            os.environ.pop("MOCAP_HEAVY_ENUM_CAP", None)
         assert auto["resubmitted"] >= 20 and not auto["status"][ok].any(), ncap
         assert np.array_equal(auto["n_out"][ok], plain["n_out"][ok])
         assert np.array_equal(auto["corr"][valid], plain["corr"][valid]), ncap
@@ -261,6 +266,18 @@ def test_two_markers_behind_each_other_as_seen_from_camera_0(core):
     assert (plain["status"] & capi.ST_CAND_OVERFLOW).all()
     auto = core.match_triangulate_auto(blobs, counts, gate_px=synth.STRESS_GATE_PX, K_max=384, G_cap=1 << 20)
     assert auto["resubmitted"] == 4 and not auto["status"].any()
+    # the same frames with a search that cannot bound anything (a 64-node frontier): 2^60 groups are beyond every enumeration,
+    # the reference's own included -- the frame says so: candidate overflow + INTRACTABLE + FINAL, log2(groups) in bits 20..28
+    import os
+    os.environ["MOCAP_HEAVY_NCAP"] = "64"
+    try:
+        lost = core.match_triangulate_auto(blobs, counts, gate_px=synth.STRESS_GATE_PX, K_max=384, G_cap=1 << 20)
+    finally:
+        del os.environ["MOCAP_HEAVY_NCAP"]
+    want_bits = capi.ST_CAND_OVERFLOW | capi.ST_INTRACTABLE | capi.ST_FINAL
+    assert ((lost["status"] & want_bits) == want_bits).all() and not lost["n_out"].any()
+    lg = (lost["status"] >> capi.ST_LOG2_GROUPS_SHIFT) & capi.ST_LOG2_GROUPS_MASK
+    assert (lg >= 50).all() and (lg <= 63).all(), lg
     X0 = truth["points_cam0"]
     for f in range(4):
         n = int(auto["n_out"][f])
