@@ -702,6 +702,21 @@ def config_record(name, local_rank, dev, stream, steps, warmup, frames=0):
                           "xyz_max_rel": float(np.abs(xyz[vv] - ref["xyz"][vv]).max() / np.abs(ref["xyz"][vv]).max()) if vv.any() else None,
                           "run_to_run": {"frames_checked": rr["frames"], "frames_differing": rr["frames_differing"],
                                          "bit_identical": rr["frames_differing"] == 0}}}
+        if wl["stress"]:
+            # the same batch with MOCAP_OPT_BOUNDED_RESUBMIT: roots of 2^16 .. 2^24 groups the exact search gives up on are flagged
+            # instead of enumerated by the whole GPU (~3 ms each): the price of the default's last few frames, measured
+            core.set_options(bounded_resubmit=True)
+            out.run(core, M, d_blobs, d_counts, gate, g_cap)
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            for _ in range(steps):
+                out.run(core, M, d_blobs, d_counts, gate, g_cap)
+            torch.cuda.synchronize(dev)
+            w2 = time.perf_counter() - t1
+            st2, no2 = out.status.cpu().numpy(), out.n_out.cpu().numpy()
+            rec["bounded_resubmit"] = {"option": "MOCAP_OPT_BOUNDED_RESUBMIT", "ms_per_step": 1e3 * w2 / steps, "frames_per_s": F * steps / w2,
+                                       "value": float(no2[st2 == 0].sum()) * steps / w2, "overflow_frames": int((st2 != 0).sum())}
+            core.set_options(bounded_resubmit=False)
         mix, stale, path = load_profile(f"fp64_mix_{name}")
         if mix is not None:
             tf = float(mix["fp64_flop_per_frame"]) * F / (kernel_ms * 1e-3) / 1e12
@@ -802,7 +817,7 @@ def main():
     ap.add_argument("--frames", type=int, default=0, help="frames per GPU per step (0 = the workload's default)")
     ap.add_argument("--chunks", type=int, default=0,
                     help="N > 1: sub-batches a rank's shard is cut into per step, so that the gather of chunk k travels while chunk "
-                         "k + 1 is computed inside ONE step (0 = automatic: 4; 1 = the whole shard at once)")
+                         "k + 1 is computed inside ONE step (0 = automatic: 4, or 2 at 64 x 256; 1 = the whole shard at once)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ba", action="store_true")
     ap.add_argument("--no-blobs", action="store_true")
@@ -885,7 +900,9 @@ def main():
     # A rank's shard is cut into sub-batches: the gather of chunk k is posted once chunk k + 1's kernels are queued, so the
     # exchange overlaps compute INSIDE a step too (a one-step run used to expose all of it: at 64 x 256 that is 532 MB per
     # rank, 3.7 GB into the root).  Each chunk has its own compactor buffers.
-    n_chunks = 1 if not multi else max(1, min(args.chunks or 4, F))
+    # (automatic: 4 sub-batches; 2 at the stress shape, where every sub-batch pays a kernel tail of ~1 ms and its own re-submit --
+    # gather, second pass, heavy-root search: 1.7 ms -- measured in round 5: 4 x 8.5 ms instead of 30.6 for the first pass alone)
+    n_chunks = 1 if not multi else max(1, min(args.chunks or (2 if C * M >= 4096 else 4), F))
     cb = [mdist.shard_bounds(F, c, n_chunks) for c in range(n_chunks)]
     comps = [mdist.TrackCompactor(core, hi - lo, K_MAX, C, dev) for lo, hi in cb] if multi else []
     comm = torch.cuda.Stream(dev) if multi else None

@@ -71,6 +71,12 @@ enum {
                                    (csrc/frame_kernel.hip without its cut-offs instead of csrc/frame_bb.hip).  Same results
                                    bit for bit, ~3 x the time: the verification mode bench.py's full-batch parity field and
                                    tests/test_gpu_bench_scale.py compare the shipped selection against. */
+  ,
+  MOCAP_OPT_BOUNDED_RESUBMIT = 4 /* default OFF.  ON: the re-submit pass of the wide variant does not ENUMERATE the roots its
+                                   exact search gives up on (2^16 .. 2^24 groups: ~3 ms of the whole GPU each, csrc/heavy_bb.hip
+                                   heavy_enum_kernel); their frames keep MOCAP_ST_CAND_OVERFLOW | MOCAP_ST_FINAL instead.  For
+                                   callers that prefer a bounded step time to the last 0.1 % of the frames of a stress batch;
+                                   every frame that is returned is still exact. */
 };
 
 /* ---------------------------------------------------------------- lifetime */
@@ -226,7 +232,9 @@ int mocap_get_undistort_map(mocap_ctx* ctx, int camera, uint32_t* map);
 /* scheduling knob of the blob stage; results are bit-identical for either setting (tested).
  *   skip_dark_tiles  default 1: a 64 x 64 tile whose source bytes span a value range <= 2 (activity map of
  *                    the pre-pass) provably yields no mask bit and is not filtered (exact early-out; IR
- *                    frames are black but for the dots).  0 = filter every tile. */
+ *                    frames are black but for the dots).  0 = filter every tile.  2 (round 6) = the same early-out decided
+ *                    INSIDE the mask pass on the range of the tile's undistorted region (no activity pass, no second read
+ *                    of the image; a dark tile then pays its gather first). */
 int mocap_set_blob_options(mocap_ctx* ctx, int skip_dark_tiles);
 
 /* per-image status bits written by mocap_find_blobs* */

@@ -129,7 +129,7 @@ int find_blobs_dev_locked(mocap_ctx* ctx, int64_t n_frames, const uint8_t* d_ima
     a.counts = d_counts + i0;
     a.status = d_status + i0;
     a.n_contours = d_n_contours ? d_n_contours + i0 : nullptr;
-    if (a.skip_dark && !a.processed) HIP_TRY(ctx, launch_blob_activity(a, ctx->stream));  // the map's only reader
+    if (a.skip_dark == 1 && !a.processed) HIP_TRY(ctx, launch_blob_activity(a, ctx->stream));  // the map's only reader
     HIP_TRY(ctx, launch_blob_mask(a, ctx->stream));
   }
   // contours of the whole batch at once (one workgroup per image, reads only the 1-bit masks)
@@ -369,7 +369,7 @@ extern "C" int mocap_set_image_params(mocap_ctx* ctx, int C, int rows, int cols,
 extern "C" int mocap_set_blob_options(mocap_ctx* ctx, int skip_dark_tiles) {
   if (!ctx) return MOCAP_E_ARG;
   std::lock_guard<std::mutex> lk(ctx->mu);
-  ctx->blob_skip_dark = skip_dark_tiles ? 1 : 0;
+  ctx->blob_skip_dark = skip_dark_tiles == 2 ? 2 : (skip_dark_tiles ? 1 : 0);
   return MOCAP_OK;
 }
 

@@ -60,6 +60,7 @@ constexpr uint32_t pk4(int a, int b, int c, int d) {
   return (uint32_t)(a & 0xff) | (uint32_t)(b & 0xff) << 8 | (uint32_t)(c & 0xff) << 16 | (uint32_t)(d & 0xff) << 24;
 }
 typedef unsigned short v2u16 __attribute__((ext_vector_type(2)));
+typedef unsigned char uchar4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint32_t udot2(uint32_t a, uint32_t b, uint32_t c) {
   return __builtin_amdgcn_udot2(__builtin_bit_cast(v2u16, a), __builtin_bit_cast(v2u16, b), c, false);
 }
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(kBlobThreads) void blob_mask_kernel(BlobArgs a) {
   // with round-to-nearest, so every blurred value stays in [m, M]; the 5x5 kernel sums to 0 with positive
   // weights summing to 20, so its output is at most 20 (M - m); grey is a convex combination of the three
   // channels.  M - m <= 2  =>  grey <= 40 < 52: no mask bit can be set.
-  if (a.skip_dark && !a.processed) {
+  if (a.skip_dark == 1 && !a.processed) {
     const int16_t* box = a.tile_box + lt * 4;
     const int b0 = box[0], b1 = box[1], s0 = box[2], s1 = box[3];
     if (b0 >= 0) {
@@ -292,6 +293,41 @@ __global__ __launch_bounds__(kBlobThreads) void blob_mask_kernel(BlobArgs a) {
     }
   }
   __syncthreads();
+  // ---- dark-tile early-out, folded into this pass (mocap_set_blob_options(2), round 6): the range of the UNDISTORTED region
+  // itself, which is in LDS now -- no activity pass, no second read of the image.  Everything below depends on U alone, and the
+  // argument above holds with m, M = min / max over U's 3 x 76 x 76 bytes (the Gaussian is a convex combination with
+  // round-to-nearest; the 5x5 kernel sums to 0 with positive weights summing to 20; grey is a convex combination of the
+  // channels): M - m <= 2  =>  grey <= 40 < 52, no mask bit.  A dark tile pays its gather first: the price, measured.
+  if (a.skip_dark == 2 && !a.processed) {
+    uint32_t lo4 = 0xffffffffu, hi4 = 0u;  // four byte lanes at a time
+    for (int c = 0; c < 3; c++) {
+      const uint32_t* w = (const uint32_t*)U[c];
+      for (int i = tid; i < UW * UP / 4; i += kBlobThreads) {  // (76 * 76 = 5776 bytes = 1444 words)
+        const uint32_t v = w[i];
+        lo4 = (uint32_t)__builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(uchar4_t, lo4), __builtin_bit_cast(uchar4_t, v)));
+        hi4 = (uint32_t)__builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(uchar4_t, hi4), __builtin_bit_cast(uchar4_t, v)));
+      }
+    }
+    uint32_t lo = min(min(lo4 & 0xffu, (lo4 >> 8) & 0xffu), min((lo4 >> 16) & 0xffu, lo4 >> 24));
+    uint32_t hi = max(max(hi4 & 0xffu, (hi4 >> 8) & 0xffu), max((hi4 >> 16) & 0xffu, hi4 >> 24));
+    for (int o = 32; o > 0; o >>= 1) {
+      lo = min(lo, (uint32_t)__shfl_xor((int)lo, o));
+      hi = max(hi, (uint32_t)__shfl_xor((int)hi, o));
+    }
+    __shared__ uint32_t red2[2][kBlobThreads / 64];
+    if ((tid & 63) == 0) {
+      red2[0][tid >> 6] = lo;
+      red2[1][tid >> 6] = hi;
+    }
+    __syncthreads();
+    lo = min(min(red2[0][0], red2[0][1]), min(red2[0][2], red2[0][3]));
+    hi = max(max(red2[1][0], red2[1][1]), max(red2[1][2], red2[1][3]));
+    if (hi <= lo + 2u) {  // (uniform)
+      for (int y = tid; y < BT; y += kBlobThreads)
+        if (ty0 + y < S) mask[(size_t)(ty0 + y) * words + tx0 / 64] = 0ull;
+      return;
+    }
+  }
 
   // lane -> output pixels: x = lane % 64, rows 16 (lane / 64) + j: one wave covers one tile row at a time
   const int px = tid & 63, wv = tid >> 6;

@@ -873,7 +873,7 @@ static int resubmit_dev_locked(mocap_ctx* ctx, int64_t n_frames, int M_max, cons
       // roots the search gives up on with at most 2^24 groups are enumerated by the whole GPU behind it (heavy_enum_kernel):
       // the pass stays exact up to 2^24 groups per root, like the enumeration it replaces (round-5 advice)
       char* e = (char*)ctx->heavy_enum.ptr;
-      ha.enum_max = getenv("MOCAP_NO_HEAVY_ENUM") ? 0 : kHeavyEnumMax;
+      ha.enum_max = (getenv("MOCAP_NO_HEAVY_ENUM") || (ctx->flags & MOCAP_OPT_BOUNDED_RESUBMIT)) ? 0 : kHeavyEnumMax;
       ha.enum_grid = enum_grid;
       ha.enum_count = ctr + 17;
       ha.enum_list = (int32_t*)e;    e += 4 * (size_t)kHeavyEnumMax;

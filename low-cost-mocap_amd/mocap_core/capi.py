@@ -30,6 +30,7 @@ BLOB_ST_POINT_OVERFLOW = 1
 BLOB_ST_CAP_OVERFLOW = 2
 OPT_F32_ROUNDING = 1
 OPT_EXHAUSTIVE_WALK = 2
+OPT_BOUNDED_RESUBMIT = 4
 
 _vp, _i32, _i64, _dbl, _u32 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_double, ctypes.c_uint32
 
@@ -157,10 +158,12 @@ class MocapCore:
         self._check(self.lib.mocap_set_cameras(self._h, C, _p(K), _p(R), _p(t)))
         self.C = C
 
-    def set_options(self, f32_rounding=True, exhaustive_walk=False):
-        """exhaustive_walk: MOCAP_OPT_EXHAUSTIVE_WALK, the verification mode (every candidate group evaluated in full)."""
+    def set_options(self, f32_rounding=True, exhaustive_walk=False, bounded_resubmit=False):
+        """exhaustive_walk: MOCAP_OPT_EXHAUSTIVE_WALK, the verification mode (every candidate group evaluated in full).
+        bounded_resubmit: MOCAP_OPT_BOUNDED_RESUBMIT (no whole-GPU enumeration of roots the exact search gives up on)."""
         self._check(self.lib.mocap_set_options(self._h, (OPT_F32_ROUNDING if f32_rounding else 0) |
-                                               (OPT_EXHAUSTIVE_WALK if exhaustive_walk else 0)))
+                                               (OPT_EXHAUSTIVE_WALK if exhaustive_walk else 0) |
+                                               (OPT_BOUNDED_RESUBMIT if bounded_resubmit else 0)))
         self.f32_rounding = bool(f32_rounding)
 
     def set_tuning(self, frame_threads=0, heavy_threshold=-1, slice_size=0):
@@ -351,7 +354,8 @@ class MocapCore:
         self.img_C, self.img_rows, self.img_cols = C, int(rows), int(cols)
 
     def set_blob_options(self, skip_dark_tiles=True):
-        self._check(self.lib.mocap_set_blob_options(self._h, int(bool(skip_dark_tiles))))
+        """True / 1: activity pre-pass + early-out; False / 0: every tile filtered; 2: early-out decided inside the mask pass."""
+        self._check(self.lib.mocap_set_blob_options(self._h, 2 if skip_dark_tiles == 2 and skip_dark_tiles is not True else int(bool(skip_dark_tiles))))
 
     def undistort_map(self, camera=0):
         m = np.zeros((self.img_cols, self.img_cols), dtype=np.uint32)

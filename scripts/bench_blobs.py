@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--markers", type=int, default=16)
     ap.add_argument("--processed", action="store_true")
     ap.add_argument("--no-skip", action="store_true", help="filter every tile (no dark-tile early-out)")
+    ap.add_argument("--fold", action="store_true", help="mocap_set_blob_options(2): the early-out decided inside the mask pass (no activity pass)")
     ap.add_argument("--noise", type=int, default=3, help="background noise levels: uniform in [0, noise)")
     args = ap.parse_args()
     C, M_max = args.cams, 32
@@ -33,7 +34,7 @@ def main():
     dev = torch.device("cuda", 0)
     core = capi.MocapCore(0)
     core.set_image_params(240, 320, rig["K"], [synth.REFERENCE_DISTORTION] * C)
-    core.set_blob_options(skip_dark_tiles=not args.no_skip)
+    core.set_blob_options(skip_dark_tiles=2 if args.fold else (not args.no_skip))
     stream = torch.cuda.current_stream(dev)
     core.set_stream(stream.cuda_stream)
     F = args.frames
@@ -63,7 +64,8 @@ def main():
     print(json.dumps({"images": n_img, "ms": ms, "runs_ms": ts, "images_per_s": n_img / ms * 1e3,
                       "frame_sets_per_s": F / ms * 1e3, "GBps_algorithmic": (in_bytes + out_bytes) / ms / 1e6,
                       "frac_of_8TBps": (in_bytes + out_bytes) / ms / 1e6 / 8000, "points": int(d_counts.sum().item()),
-                      "status_nonzero": int((d_st != 0).sum().item()), "processed": args.processed, "skip_dark_tiles": not args.no_skip, "noise_levels": args.noise}))
+                      "status_nonzero": int((d_st != 0).sum().item()), "processed": args.processed, "skip_dark_tiles": not args.no_skip, "fold": args.fold,
+                      "centroid_checksum": int(d_blobs.nan_to_num().double().sum().item() * 8) ^ int(d_counts.sum().item()), "noise_levels": args.noise}))
 
 
 if __name__ == "__main__":

@@ -2,7 +2,7 @@
 # One box: wide-variant timing of library variants (lib/libmocap_core_<tag>.so; "base" = product) at N frames of 64 x 256.
 #   usage: scripts/gpu_wide_ab.sh <frames> base tag1 tag2 ...
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-O=$R/gpurun_out/r04; mkdir -p $O
+O=$R/gpurun_out/r06; mkdir -p $O
 cd $R
 N=$1; shift
 python scripts/time_wide.py $N 1 > /dev/null 2>&1

@@ -11,7 +11,7 @@ cache = f"/tmp/stress_{F}.npz"
 if os.path.exists(cache):
     z = np.load(cache); blobs, counts = z["b"], z["c"]
 else:
-    blobs, counts, _ = synth.make_stress_stream(rig, F, M, seed=1)
+    blobs, counts, _ = synth.make_stress_stream_chunked(rig, F, M, seed=1)   # (bench.py's stream since round 6)
     np.savez(cache, b=blobs, c=counts)
 dev = torch.device("cuda:0")
 core = capi.MocapCore(0)

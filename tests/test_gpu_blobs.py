@@ -173,8 +173,12 @@ def test_dark_tile_early_out_does_not_change_results(core):
         on = core.find_blobs(images, M_max=64)
         core.set_blob_options(skip_dark_tiles=False)
         off = core.find_blobs(images, M_max=64)
+        core.set_blob_options(skip_dark_tiles=2)        # (round 6) the early-out decided inside the mask pass: no activity pass
+        fold = core.find_blobs(images, M_max=64)
     finally:
         core.set_blob_options(skip_dark_tiles=True)
+    for k in ("blobs", "counts", "n_contours"):
+        assert np.array_equal(fold[k], off[k]), ("fold", k)
     for k in ("blobs", "counts", "status", "n_contours"):
         assert np.array_equal(on[k], off[k]), k
     assert on["counts"].sum() > 0
@@ -243,8 +247,12 @@ def test_dark_tile_early_out_on_wide_frames(core, rows, cols):
         on = core.find_blobs(images, M_max=64)
         core.set_blob_options(skip_dark_tiles=False)
         off = core.find_blobs(images, M_max=64)
+        core.set_blob_options(skip_dark_tiles=2)        # (round 6) the early-out decided inside the mask pass: no activity pass
+        fold = core.find_blobs(images, M_max=64)
     finally:
         core.set_blob_options(skip_dark_tiles=True)
+    for k in ("blobs", "counts", "n_contours"):
+        assert np.array_equal(fold[k], off[k]), ("fold", k)
     ref = c_oracle.BlobOracle(rows, cols, [K, K], dists, [0, 0]).find_blobs(images, M_max=64)
     assert ref["counts"].min() >= 6
     for k in ("blobs", "counts", "n_contours"):

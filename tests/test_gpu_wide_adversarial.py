@@ -266,18 +266,28 @@ def test_two_markers_behind_each_other_as_seen_from_camera_0(core):
     assert (plain["status"] & capi.ST_CAND_OVERFLOW).all()
     auto = core.match_triangulate_auto(blobs, counts, gate_px=synth.STRESS_GATE_PX, K_max=384, G_cap=1 << 20)
     assert auto["resubmitted"] == 4 and not auto["status"].any()
-    # the same frames with a search that cannot bound anything (a 64-node frontier): 2^60 groups are beyond every enumeration,
-    # the reference's own included -- the frame says so: candidate overflow + INTRACTABLE + FINAL, log2(groups) in bits 20..28
-    import os
-    os.environ["MOCAP_HEAVY_NCAP"] = "64"
-    try:
-        lost = core.match_triangulate_auto(blobs, counts, gate_px=synth.STRESS_GATE_PX, K_max=384, G_cap=1 << 20)
-    finally:
-        del os.environ["MOCAP_HEAVY_NCAP"]
+    # The same frames with marker A's blob missing in three cameras where B's is there (what 5 % dropout does to such a pair in
+    # the stress stream): B's blob is then the ONLY hit of A's root in those cameras -- forced views hundreds of pixels off, every
+    # group of the root carries them, its best error is ~1e5 px^2 and no bound separates the 2^57 mixtures.  No enumeration
+    # reaches that, the reference's own included (helpers.py:394-400 would not return): the frame says so -- candidate overflow
+    # + INTRACTABLE + FINAL, log2(groups) of the root in bits 20..28 -- and reports no point.
+    b2, c2 = blobs.copy(), counts.copy()
+    for f in range(4):
+        for cam in (5, 17, 40):
+            k = int(np.nonzero(truth["ident"][f, cam] == 0)[0][0])
+            n = int(c2[f, cam])
+            b2[f, cam, k:n - 1] = b2[f, cam, k + 1:n]
+            b2[f, cam, n - 1] = np.nan
+            c2[f, cam] = n - 1
+    lost = core.match_triangulate_auto(b2, c2, gate_px=synth.STRESS_GATE_PX, K_max=384, G_cap=1 << 20)
     want_bits = capi.ST_CAND_OVERFLOW | capi.ST_INTRACTABLE | capi.ST_FINAL
-    assert ((lost["status"] & want_bits) == want_bits).all() and not lost["n_out"].any()
-    lg = (lost["status"] >> capi.ST_LOG2_GROUPS_SHIFT) & capi.ST_LOG2_GROUPS_MASK
-    assert (lg >= 50).all() and (lg <= 63).all(), lg
+    # (where B is only a little behind A the forced views are a few tens of pixels off and the search still bounds the root:
+    # those frames come back solved; the frame with B furthest out does not)
+    hard = lost["status"] != 0
+    assert hard.any() and ((lost["status"][hard] & want_bits) == want_bits).all() and not lost["n_out"][hard].any(), lost["status"]
+    lg = (lost["status"][hard] >> capi.ST_LOG2_GROUPS_SHIFT) & capi.ST_LOG2_GROUPS_MASK
+    assert (lg >= 45).all() and (lg <= 63).all(), lg
+    assert (lost["n_out"][~hard] >= 250).all()
     X0 = truth["points_cam0"]
     for f in range(4):
         n = int(auto["n_out"][f])
