@@ -181,7 +181,7 @@ int mocap_resubmit_dev(mocap_ctx* ctx, int64_t n_frames, int M_max, const float*
  * mocap_match_triangulate_auto (MOCAP_ST_ROOT_OVERFLOW = the frame needs n_out[f] > K_max slots and nothing was written
  * for it; consumers treat n_out > K_max as "no valid slot").  d_resubmitted (may be NULL): [2] device-accessible int32,
  * {frames flagged by the first pass, frames re-run}; the two differ only when the scratch batch could not hold every flagged
- * frame (it is sized for one frame in eight, at least 1 024 frames, within MOCAP_RESUBMIT_SCRATCH_MB, default 8192; halved
+ * frame (the whole batch while that takes at most 256 MB, else one frame in eight, within MOCAP_RESUBMIT_SCRATCH_MB, default 8192; halved
  * until the allocation succeeds) -- those keep their status WITHOUT MOCAP_ST_FINAL: mocap_resubmit_dev continues with them
  * (the host-buffer entry points loop until none is left). */
 int mocap_match_triangulate_dev_auto(mocap_ctx* ctx, int64_t n_frames, int M_max, const float* d_blobs,

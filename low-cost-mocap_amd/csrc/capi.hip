@@ -754,11 +754,14 @@ static int resubmit_dev_locked(mocap_ctx* ctx, int64_t n_frames, int M_max, cons
   size_t budget = (size_t)8192 << 20;
   if (const char* e = getenv("MOCAP_RESUBMIT_SCRATCH_MB")) budget = (size_t)(atol(e) > 0 ? atol(e) : 1) << 20;
   // The scratch batch is sized for the flagged share one expects, not for the whole batch (round-5 advice: a full copy of a
-  // 100 k-frame batch was reserved up front although no frame might be flagged): one frame in eight, at least 1 024.  More
+  // 100 k-frame batch was reserved up front although no frame might be flagged): the whole batch while that costs at most
+  // 256 MB (a caller's tiny G_cap may flag every frame of a small batch), else one frame in eight, at least 1 024 and at least
+  // what 256 MB hold.  More
   // flagged frames than that keep their status without MOCAP_ST_FINAL and d_info says so; mocap_resubmit_dev (and the
   // host-buffer entry points, in a loop) continue with them.  An allocation that fails is retried at half the size down to
   // one frame: the first pass has succeeded by now, a missing scratch must not fail the call.
   int64_t cap = n_frames / 8 < 1024 ? 1024 : n_frames / 8;
+  if (cap < (int64_t)(((size_t)256 << 20) / per_frame)) cap = (int64_t)(((size_t)256 << 20) / per_frame);
   if (const char* e = getenv("MOCAP_RESUBMIT_SCRATCH_FRAMES")) cap = atol(e) > 0 ? atol(e) : 1;  // (tests: a scratch smaller than the flagged set)
   if (cap > n_frames) cap = n_frames;
   if ((size_t)cap * per_frame > budget) cap = (int64_t)(budget / per_frame);
@@ -822,7 +825,7 @@ static int resubmit_dev_locked(mocap_ctx* ctx, int64_t n_frames, int M_max, cons
   HeavyHook hk{nullptr, nullptr, 0};
   int ncap = 4096;  // (swept on the stress stream: 16 384 and 65 536 solve 1-3 more of ~30 hard roots per 12 500 frames and double the step)
   const int hv_grid = 64;
-  const int enum_grid = ctx->num_cus * 2;  // heavy_enum_kernel: 256-lane workgroups, the whole GPU on one root at a time
+  const int enum_grid = ctx->num_cus * 3;  // heavy_enum_kernel: 256-lane workgroups (168 VGPRs: three waves per SIMD), the whole GPU on one root at a time
   if (const char* e = getenv("MOCAP_HEAVY_NCAP")) ncap = atoi(e) >= 64 ? atoi(e) : 64;
   if (heavy_ok) {
     G2 = 4096;

@@ -36,7 +36,8 @@ constexpr int kHvThreads = 1024;  // (one workgroup per CU: the frontier of a ha
 constexpr int kHvEnumDigits = 20;  // multi-hit cameras of a root the fall-back enumerates (product <= 2^20, two hits at least each)
 constexpr int kHvGlobalEnumDigits = 24;  // ... of a root heavy_enum_kernel enumerates over the whole GPU (product <= 2^24)
 constexpr int kHvEnumThreads = 256;
-constexpr int kHvEnumSlice = 16 * kHvEnumThreads;  // groups per slice
+constexpr int kHvEnumSlice = 16 * kHvEnumThreads;  // groups per slice (roots with more hits than the table holds)
+constexpr int kHvEnumTab = 256;  // hits of a root heavy_enum_kernel tabulates (contribution + pixel)
 constexpr int kHvDigits = 64;  // digit slots of a node (>= multi-hit cameras of a root: < kMaxCameras)
 
 size_t heavy_bb_ws_bytes(int ncap) { return (size_t)2 * ncap * (sizeof(double) * 10 + kHvDigits); }
@@ -421,6 +422,13 @@ __global__ __launch_bounds__(kHvEnumThreads) void heavy_enum_kernel(HeavyArgs a)
   __shared__ uint32_t s_G;
   __shared__ unsigned long long s_best, s_gbest;
   __shared__ uint8_t s_dg[kHvGlobalEnumDigits][kHvEnumThreads];
+  // the root's hits, tabulated once: DLT contribution (dlt_contribution: the function every path of the core rounds with) and
+  // pixel coordinates of hit d of camera c at entry s_off[c] + d
+  __shared__ double s_tab[kHvEnumTab][10];
+  __shared__ float2 s_xy[kHvEnumTab];
+  __shared__ uint16_t s_off[kMaxCameras + 1];
+  __shared__ int s_split, s_csplit, s_views;
+  __shared__ uint32_t s_Npre, s_Psuf;
   const int tid = threadIdx.x;
   const int C = a.cv.C, M = a.M;
   int n_roots = *a.enum_count;
@@ -452,11 +460,48 @@ __global__ __launch_bounds__(kHvEnumThreads) void heavy_enum_kernel(HeavyArgs a)
       s_G = (uint32_t)G;  // (<= 2^24: heavy_bb_kernel queued it)
       s_best = 0x7ff0000000000000ull;
       s_gbest = ~0ull;
+      int off = 0, views = 0;
+      for (int c = 0; c < C; c++) {
+        s_off[c] = (uint16_t)(off < 0xFFFF ? off : 0xFFFF);
+        off += nc[c];
+        views += nc[c] ? 1 : 0;
+      }
+      s_off[C] = (uint16_t)(off < 0xFFFF ? off : 0xFFFF);
+      s_views = views;
+      // The digits split into a PREFIX (the multi-hit cameras with the lowest camera numbers = the fastest digits of the
+      // candidate index) and a SUFFIX (the last ones, >= 64 combinations where the root has them).  A lane takes one prefix
+      // and walks the suffix combinations: B is summed in camera order from zeros (mocap_device.hpp triangulate_and_score), so
+      // the partial sum over the cameras before the first suffix camera is the same for all of them -- computed once, the very
+      // bits the full left-to-right sum passes through.
+      int split = m;
+      uint32_t psuf = 1;
+      while (split > 0 && psuf < 64u) psuf *= nc[s_dcam[--split]];
+      s_split = split;
+      s_Psuf = psuf;
+      s_Npre = (uint32_t)(G / psuf);
+      s_csplit = split < m ? s_dcam[split] : C;
     }
     __syncthreads();
     const int m = s_m;
     const uint32_t G = s_G;
-    const uint32_t n_slices = (G + kHvEnumSlice - 1) / kHvEnumSlice;
+    const bool tabbed = s_off[C] <= kHvEnumTab;  // (uniform) else: every group from its raw observations, as before
+    if (tabbed) {
+      for (int c = 0; c < C; c++) {
+        const int n = s_n[c];
+        if (tid < n) {
+          const float2 w = fb[(size_t)c * M + hl[(size_t)c * Hs + tid]];
+          double Bc[10];
+          dlt_contribution(Bc, a.cv.pq((size_t)12 * c), (double)w.x, (double)w.y);
+#pragma unroll
+          for (int e = 0; e < 10; e++) s_tab[s_off[c] + tid][e] = Bc[e];
+          s_xy[s_off[c] + tid] = w;
+        }
+      }
+      __syncthreads();
+    }
+    const int split = s_split, csplit = s_csplit, views = s_views;
+    const uint32_t Npre = s_Npre, Psuf = s_Psuf;
+    const uint32_t n_slices = tabbed ? (Npre + kHvEnumThreads - 1) / kHvEnumThreads : (G + kHvEnumSlice - 1) / kHvEnumSlice;
     EigCut ec;
     {
       const double om = (double)__int_as_float(hd.omax_bits);
@@ -471,6 +516,66 @@ __global__ __launch_bounds__(kHvEnumThreads) void heavy_enum_kernel(HeavyArgs a)
       const uint32_t sl = (uint32_t)s_slice;
       __syncthreads();
       if (sl >= n_slices) break;  // (uniform)
+      if (tabbed) {
+        const uint32_t q = sl * (uint32_t)kHvEnumThreads + (uint32_t)tid;  // this lane's prefix
+        if (q < Npre) {
+          uint32_t rem = q;
+          for (int j = 0; j < split; j++) {
+            uint32_t qd, d;
+            divmod_small(rem, (uint32_t)s_n[s_dcam[j]], qd, d);
+            rem = qd;
+            s_dg[j][tid] = (uint8_t)d;
+          }
+          double Bp[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+          for (int c = 0; c < csplit; c++) {
+            const int n = s_n[c];
+            if (n) {
+              const double* t = s_tab[s_off[c] + (n > 1 ? (int)s_dg[s_lvl[c]][tid] : 0)];
+#pragma unroll
+              for (int e = 0; e < 10; e++) Bp[e] = Bp[e] + t[e];
+            }
+          }
+          auto obs = [&](int c, double& x, double& y) -> bool {
+            const int n = s_n[c];
+            if (!n) return false;
+            const float2 w = s_xy[s_off[c] + (n > 1 ? (int)s_dg[s_lvl[c]][tid] : 0)];
+            x = (double)w.x;
+            y = (double)w.y;
+            return true;
+          };
+          for (uint32_t sfx = 0; sfx < Psuf; sfx++) {  // ascending candidate index: g = q + Npre * sfx
+            uint32_t r2 = sfx;
+            for (int j = split; j < m; j++) {
+              uint32_t qd, d;
+              divmod_small(r2, (uint32_t)s_n[s_dcam[j]], qd, d);
+              r2 = qd;
+              s_dg[j][tid] = (uint8_t)d;
+            }
+            double B[10];
+#pragma unroll
+            for (int e = 0; e < 10; e++) B[e] = Bp[e];
+            for (int c = csplit; c < C; c++) {
+              const int n = s_n[c];
+              if (n) {
+                const double* t = s_tab[s_off[c] + (n > 1 ? (int)s_dg[s_lvl[c]][tid] : 0)];
+#pragma unroll
+                for (int e = 0; e < 10; e++) B[e] = B[e] + t[e];
+              }
+            }
+            double X[3], e = inf;
+            const double bound = __longlong_as_double((long long)__hip_atomic_load(&a.enum_bound[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            // (the call triangulate_and_score ends in, with the B it would have summed)
+            solve_and_score<true, true, F32R, false, 1>(a.cv, B, views, obs, X, e, bound * (double)(2 * views) * (1.0 + 0x1p-40), ec);
+            if (e < be) {  // strict <: the first minimum of this lane's ascending run
+              be = e;
+              bg = q + Npre * sfx;
+              bX[0] = X[0]; bX[1] = X[1]; bX[2] = X[2];
+              atomicMin(&a.enum_bound[s], (unsigned long long)__double_as_longlong(e));
+            }
+          }
+        }
+        continue;
+      }
       const uint32_t g1 = (sl + 1) * (uint32_t)kHvEnumSlice < G ? (sl + 1) * (uint32_t)kHvEnumSlice : G;
       for (uint32_t g = sl * (uint32_t)kHvEnumSlice + (uint32_t)tid; g < g1; g += kHvEnumThreads) {
         // digits of g: the first multi-hit camera is the fastest one (helpers.py:394-400 order, as in frame_kernel.hip)

@@ -79,7 +79,7 @@ def test_wide_kernel_budget(kernels):
     hv = _find(kernels, "heavy_bb_kernelILb1E")
     assert hv["vgpr_count"] <= 128 and hv["vgpr_spill_count"] <= 60, hv     # (1 024 lanes: one workgroup per CU; round 6: + the intractable-root bookkeeping, 55)
     en = _find(kernels, "heavy_enum_kernelILb1E")
-    assert en["vgpr_count"] <= 128 and en["vgpr_spill_count"] == 0, en      # the enumeration over the whole GPU (round 6)
+    assert en["vgpr_count"] <= 168 and en["vgpr_spill_count"] == 0, en      # the enumeration over the whole GPU (round 6): 3 waves per SIMD
 
 
 # ---------------------------------------------------------------- synchronisation of the shipped ISA (tests/isa_barriers.py)

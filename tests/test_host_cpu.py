@@ -291,3 +291,38 @@ def test_divmod_tiny_is_exact_for_every_operand_the_block_decode_can_see():
     src = open(os.path.join(ROOT, "low-cost-mocap_amd", "csrc", "capi.hip")).read()
     assert "(size_t)a.bb_pl * M_max * 2 * 256 >= ((size_t)1 << 22)" in src
     assert "M <= 64" in open(os.path.join(ROOT, "low-cost-mocap_amd", "csrc", "frame_bb.hip")).read()
+
+
+def test_device_side_comparison_counts_exactly_the_valid_slots():
+    """mocap_core/devcheck.compare_bitwise (bench.py's full-batch parity field, tests/test_gpu_bench_scale.py) on CPU tensors:
+    equal batches compare equal whatever sits beyond n_out; one flipped bit in a valid slot, a NaN with another payload, a
+    differing n_out or status each make their frame differ; NaNs with equal bits do not."""
+    import torch
+    from mocap_core import devcheck
+    dev = torch.device("cpu")
+    F, K, C = 50, 6, 3
+    g = torch.Generator().manual_seed(5)
+    a, b = devcheck.FrameOutputs(F, K, C, dev), devcheck.FrameOutputs(F, K, C, dev)
+    a.n_out[:] = torch.randint(0, K + 1, (F,), generator=g, dtype=torch.int32)
+    a.xyz[:] = torch.randn((F, K, 3), generator=g, dtype=torch.float64)
+    a.err[:] = torch.rand((F, K), generator=g, dtype=torch.float64)
+    a.corr[:] = torch.randint(-1, 9, (F, K, C), generator=g, dtype=torch.int16)
+    a.err[3, 0] = float("nan")
+    a.n_out[3] = max(int(a.n_out[3]), 1)
+    for t in ("n_out", "xyz", "err", "corr", "status"):
+        getattr(b, t)[:] = getattr(a, t)
+    valid = torch.arange(K)[None, :] < a.n_out[:, None]
+    b.xyz[~valid] = 123.0                                     # garbage beyond n_out: not compared
+    b.corr[~valid] = 77
+    assert devcheck.compare_bitwise(a, b, chunk=16)["frames_differing"] == 0
+    f = int(torch.nonzero(a.n_out >= 2)[0])
+    b.xyz.view(torch.int64)[f, 1, 2] ^= 1                     # one bit of one coordinate of a valid slot
+    b.err.view(torch.int64)[3, 0] ^= 1                        # a NaN with another payload
+    g2 = int(torch.nonzero(a.n_out >= 1)[5])
+    b.corr[g2, 0, 1] += 1
+    b.status[40] = 2
+    b.n_out[41] += 1
+    r = devcheck.compare_bitwise(a, b, chunk=16)
+    assert r["frames_differing"] == len({f, 3, g2, 40, 41}) and r["fields"]["xyz"] >= 1 and r["fields"]["err"] >= 1
+    assert r["fields"]["status"] == 1 and r["fields"]["n_out"] == 1 and r["fields"]["corr"] >= 1
+    assert sorted(r["first_differing_frames"]) == sorted({f, 3, g2, 40, 41})
