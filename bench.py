@@ -40,10 +40,10 @@ WORKLOADS = {
     "4x4": dict(C=4, M=4, frames=1_000_000, K_max=16, gate=5.0, stress=False, oracle_frames=300,
                 desc="4 cams x 4 markers, synthetic ring rig f=320 c=160, int-truncated blobs, sigma=0.3px, "
                      "5% dropout (BASELINE.json configs[1])"),
-    "64x256": dict(C=64, M=256, frames=4_096, K_max=384, gate=None, stress=True, oracle_frames=16,
+    "64x256": dict(C=64, M=256, frames=12_500, K_max=384, gate=None, stress=True, oracle_frames=16,
                    desc="stress: 64 virtual cams x 256 markers, 16k x 16k px virtual sensor, float centroids, "
-                        "sigma=0.02px, gate 0.5px (bounded ambiguity), 5% dropout (BASELINE.json configs[4]; 4 096 frames "
-                        "per GPU by default -- 12.5k with --frames 12500 -- generated in chunks of 256 on the host's cores)"),
+                        "sigma=0.02px, gate 0.5px (bounded ambiguity), 5% dropout (BASELINE.json configs[4]: 100 k frames over 8 GPUs "
+                        "= 12 500 frames per GPU, generated in chunks of 256 on the host's cores)"),
 }
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: 8 TB/s spec
 FP64_VALU_PEAK_TF = 78.6      # MI355X FP64 vector peak
@@ -563,11 +563,32 @@ def ba_bench(core, iters=200, cpu=True):
             _, dinfo = helpers.bundle_adjustment(ref_obs, [dict(p) for p in poses0], None, return_info=True)
             d_runs.append((time.perf_counter() - t0, float(dinfo.get("core_s", 0.0))))
     d_dt, d_core = sorted(d_runs)[1]
+    # The same solve with the host's BLAS pinned to ONE thread for its duration.  SciPy's share of this mode is an SVD of the
+    # m x n Jacobian per iteration; on a many-core host whose cores are shared (the bench boxes: 256 threads, load average 30-50)
+    # OpenBLAS's 64 spinning threads make that SVD slower, starve the HIP runtime's own threads (inside_core_calls_s grows from
+    # ~0.01 s of GPU work to 0.4-0.8 s) and change the result's last bits with the thread count.  Measured, not imposed: the mirror
+    # leaves the process's BLAS settings alone, as the reference does.
+    one_thread = None
+    try:
+        from threadpoolctl import threadpool_limits
+        o_runs = []
+        with threadpool_limits(limits=1), helpers.bundle_adjustment_mode("scipy"):
+            for _ in range(3):
+                t0 = time.perf_counter()
+                _, oinfo = helpers.bundle_adjustment(ref_obs, [dict(p) for p in poses0], None, return_info=True)
+                o_runs.append((time.perf_counter() - t0, float(oinfo.get("core_s", 0.0))))
+        o_dt, o_core = sorted(o_runs)[1]
+        one_thread = {"wall_s": o_dt, "iterations_per_s": oinfo["njev"] / o_dt, "inside_core_calls_s": o_core, "scipy_own_s": o_dt - o_core,
+                      "njev": int(oinfo["njev"]), "nfev": int(oinfo["nfev"]), "runs_s": [round(r[0], 4) for r in o_runs],
+                      "how": "threadpoolctl.threadpool_limits(limits=1) around helpers.bundle_adjustment"}
+    except Exception as e:  # pragma: no cover
+        one_thread = {"error": repr(e)}
     default_mode = {"mode": helpers.DEFAULT_BA_MODE, "measured_mode": "scipy", "wall_s": d_dt, "njev": int(dinfo["njev"]),
                     "nfev": int(dinfo["nfev"]), "iterations_per_s": dinfo["njev"] / d_dt,
                     "residual_evaluations_per_s": (dinfo["nfev"] + dinfo["njev"] * x0.size) / d_dt,
                     "runs_s": [round(r[0], 4) for r in d_runs], "statistic": "median of 3 solves after one untimed",
-                    "inside_core_calls_s": d_core, "scipy_own_s": d_dt - d_core,
+                    "inside_core_calls_s": d_core, "scipy_own_s": d_dt - d_core, "one_blas_thread": one_thread,
+                    "host_load_average": (os.getloadavg()[0] if hasattr(os, "getloadavg") else None),
                     "note": "the seam's default: scipy.optimize.least_squares drives; a trial point is one mocap_ba_residuals "
                             "call, a Jacobian is ONE call too (jac= callable: the n perturbed parameter vectors of scipy's "
                             "2-point rule as a batch, J formed with scipy's own float32-difference / float64-quotient "
@@ -991,7 +1012,8 @@ def main():
     local = torch.tensor([float(n_out.sum()), elapsed, float(status.astype(bool).sum()), float((status & 1).astype(bool).sum()),
                           float((status & 2).astype(bool).sum()), float((status & 4).astype(bool).sum()),
                           float(exposed["ms"] or 0.0), float(resub[:, 0].sum()), float(resub[:, 1].sum()),
-                          float(full_par["frames_checked"] if full_par else 0), float(full_par["frames_differing"] if full_par else 0)],
+                          float(full_par["frames_checked"] if full_par else 0), float(full_par["frames_differing"] if full_par else 0),
+                          float((status & 16).astype(bool).sum())],
                          dtype=torch.float64, device=dev)
     if world > 1:
         allv = [torch.zeros_like(local) for _ in range(world)]
@@ -1035,17 +1057,18 @@ def main():
                        "resubmitted_frames": int(allv[:, 8].sum()), "flagged_by_first_pass": int(allv[:, 7].sum()),
                        "overflow_by_cap": {"roots_K_max": int(allv[:, 3].sum()), "candidates_G_cap": int(allv[:, 4].sum()),
                                            "hits_per_root_and_camera": int(allv[:, 5].sum()),
+                                           "intractable_roots_over_2^24_groups": int(allv[:, 11].sum()),
                                            "note": "AFTER the device-side re-submit (mocap_match_triangulate_dev_auto, inside the timed "
                                                    f"region): frames the first pass flagged (G_cap = {g_cap} groups per root, K_max "
                                                    "roots, hit cap) are re-run per step with C x M roots and every hit; a root of more "
                                                    "than 4096 groups goes to the heavy-root search (csrc/heavy_bb.hip: exact branch "
                                                    "and bound over its multi-hit cameras, whatever the size of the product -- 2^60 for "
-                                                   "two markers behind each other; a root the search gives up on is enumerated in "
-                                                   "place when its product is at most 2^16).  What is still counted here: larger roots whose "
-                                                   "search frontier outgrew 4096 nodes -- a marker dropped out of some cameras where ANOTHER "
-                                                   "marker's blob is the root's only hit, so every group carries views hundreds of "
-                                                   "pixels off and no bound separates the mixtures (the reference's own answer for "
-                                                   "such a root is a point with an error of 1e4-1e6 px^2, after 2^20+ evaluations)"},
+                                                   "two markers behind each other); a root the search gives up on is enumerated -- in "
+                                                   "place up to 2^16 groups, by the whole GPU (heavy_enum_kernel) up to 2^24.  What is still "
+                                                   "counted here: frames with a root of MORE than 2^24 groups the search could not bound "
+                                                   "(MOCAP_ST_INTRACTABLE: a marker dropped out of cameras where ANOTHER marker's blob is the "
+                                                   "root's only hit, every group carries views hundreds of pixels off, no bound separates "
+                                                   "the mixtures; the reference would enumerate 2^25 .. 2^55 groups and not return)"},
                        "exchange": ({"format": "compact records (32 + 2C bytes per valid point) + n_out per frame, count-first "
                                                "point-to-point gather on rank 0",
                                      "bytes_per_rank_per_step": exchanged["bytes"] / max(args.steps, 1),

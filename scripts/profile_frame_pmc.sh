@@ -3,7 +3,7 @@
 # command, then one counter set per run (FP64 instruction mix; issue mix; FETCH_SIZE; WRITE_SIZE), and the two JSON
 # summaries bench.py reads (stamped with git HEAD + source hash).  usage: profile_frame_pmc.sh <git head> [tag]
 set -u
-HEAD=${1:-unknown}; TAG=${2:-r04}
+HEAD=${1:-unknown}; TAG=${2:-r06}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$TAG/prof; rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
@@ -13,8 +13,8 @@ summ() {  # <dir> <tag>
   python $R/scripts/rocpd_summary.py pmc $DB | grep -v "rocclr\|at::native\|rocprim" > $O/$2_pmc.csv
   find $1 -name "*.db" -delete
 }
-CMD5="python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-ba --no-blobs --no-latency"
-CMD="python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-ba --no-blobs --no-latency"
+CMD5="python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-ba --no-blobs --no-latency --no-configs --no-full-parity"
+CMD="python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-ba --no-blobs --no-latency --no-configs --no-full-parity"
 timeout 120 rocprofv3 --kernel-trace --stats -d $O/stats -o p -- $CMD5 > $O/stats.log 2>&1; summ $O/stats bench
 grep '^{"metric"' $O/stats.log | tail -1 > $O/bench_line.json
 timeout 120 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES -d $O/mix -o p -- $CMD > $O/mix.log 2>&1; summ $O/mix frame_mix

@@ -49,3 +49,7 @@ def test_bench_gpus2_starts_its_own_ranks_on_the_gpu():
     ex = line["config"]["exchange"]
     assert ex["bytes_per_rank_per_step"] > 2000 * 20 * 48            # ~23 points x 48 bytes per frame
     assert 20 < line["config"]["markers_per_frame"] < 26
+    # round 6: who took part (two ranks, ONE device here: the identities gathered over the process group say so -- a driver-side
+    # scaling run proves N distinct GPUs by N distinct entries), and every rank's whole timed shard against the exhaustive walk
+    assert line["world_size"] == 2 and line["backend"] == "gloo" and len(line["devices"]) == 2 and line["distinct_devices"] == 1
+    assert line["parity"]["frames_checked"] == 4000 and line["parity"]["full_batch_vs_exhaustive_bit_exact"] is True

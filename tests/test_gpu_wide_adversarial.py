@@ -242,6 +242,22 @@ def test_heavy_root_search_equals_the_enumeration(core):
         assert np.array_equal(auto["xyz"][valid], plain["xyz"][valid]) and np.array_equal(auto["err"][valid], plain["err"][valid]), ncap
         # the search did run: roots with a choice count one candidate each now
         assert (auto["n_cand"][ok] < plain["n_cand"][ok]).any()
+    # MOCAP_OPT_BOUNDED_RESUBMIT: the same forced give-ups are NOT enumerated -- their frames stay flagged (candidate overflow +
+    # FINAL, not INTRACTABLE: the roots have fewer than 2^24 groups) and report no point; every frame that is returned is exact
+    os.environ.update({"MOCAP_RESUBMIT_G_CAP": "8", "MOCAP_HEAVY_NCAP": "64", "MOCAP_HEAVY_ENUM_CAP": "0"})
+    try:
+        core.set_options(bounded_resubmit=True)
+        bounded = core.match_triangulate_auto(blobs, counts, gate_px=synth.STRESS_GATE_PX, K_max=384, G_cap=1)
+    finally:
+        core.set_options(bounded_resubmit=False)
+        for k in ("MOCAP_RESUBMIT_G_CAP", "MOCAP_HEAVY_NCAP", "MOCAP_HEAVY_ENUM_CAP"):
+            del os.environ[k]
+    left = bounded["status"] != 0
+    assert left.any() and (bounded["status"][left] & (capi.ST_CAND_OVERFLOW | capi.ST_FINAL | capi.ST_INTRACTABLE) == (capi.ST_CAND_OVERFLOW | capi.ST_FINAL)).all()
+    assert not bounded["n_out"][left].any()
+    done = ok & ~left
+    v3 = (np.arange(384)[None, :] < plain["n_out"][:, None]) & done[:, None]
+    assert np.array_equal(bounded["n_out"][done], plain["n_out"][done]) and np.array_equal(bounded["xyz"][v3], plain["xyz"][v3])
 
 
 def test_two_markers_behind_each_other_as_seen_from_camera_0(core):
