@@ -535,6 +535,16 @@ FramePlan plan_frame(const mocap_ctx* ctx, int M_max, int K_max, int hit_cap_ove
   if (pl.wide) {
     pl.T = kWideThreads;
     pl.lds = frame_lds_bytes(ctx->C, M_max, K_max, pl.T, pl.hit_cap, true, false);
+    // Round 6: 512 lanes per frame and TWO frames per CU wherever the LDS holds two frame states (64 cameras x 256 blobs:
+    // up to ~400 roots).  The same 16 waves per CU and 128 VGPRs, no arithmetic changed -- but two independent frames in
+    // different phases (the matching's scalar-heavy pre-test loop, the geometry's FP64) share the SIMDs' issue slots, and
+    // every barrier waits for 8 waves instead of 16: 33.3 -> 28.9 ms per 12 500 stress frames.  MOCAP_WIDE_THREADS=1024 = the old plan.
+    const char* wt = getenv("MOCAP_WIDE_THREADS");
+    const size_t l2 = frame_lds_bytes(ctx->C, M_max, K_max, 512, pl.hit_cap, true, false);
+    if (!(wt && atoi(wt) == 1024) && 2 * l2 <= (size_t)160 * 1024 && ctx->frame_launches != 3) {
+      pl.T = 512;
+      pl.lds = l2;
+    }
   }
   return pl;
 }
@@ -694,7 +704,7 @@ static int match_dev_locked(mocap_ctx* ctx, int64_t n_frames, int M_max, const f
     ctx->frame_q_clean = true;
     return MOCAP_OK;
   }
-  ctx->last_frame_kernel = wide ? "frame_kernel<1024, wide>" : (T == 64 ? "frame_kernel<64>" : (T == 128 ? "frame_kernel<128>" : "frame_kernel<256>"));
+  ctx->last_frame_kernel = wide ? (T == 512 ? "frame_kernel<512, wide>" : "frame_kernel<1024, wide>") : (T == 64 ? "frame_kernel<64>" : (T == 128 ? "frame_kernel<128>" : "frame_kernel<256>"));
   if (one_launch) {
     // one launch: frames, then slices of the heavy frames, merged by the workgroup that finishes a frame's last slice.
     // Few frames (live calls): still enough workgroups for a heavy frame's slices to run side by side.
@@ -826,7 +836,7 @@ static int resubmit_dev_locked(mocap_ctx* ctx, int64_t n_frames, int M_max, cons
   int ncap = 4096;  // (swept on the stress stream: 16 384 and 65 536 solve 1-3 more of ~30 hard roots per 12 500 frames and double the step)
   const int hv_grid = 64;
   const int enum_grid = ctx->num_cus * 3;  // heavy_enum_kernel: 256-lane workgroups (168 VGPRs: three waves per SIMD), the whole GPU on one root at a time
-  if (const char* e = getenv("MOCAP_HEAVY_NCAP")) ncap = atoi(e) >= 64 ? atoi(e) : 64;
+  if (const char* e = getenv("MOCAP_HEAVY_NCAP")) ncap = atoi(e) >= 1 ? atoi(e) : 1;  // (tests: 1 = the search gives up at the first level that keeps two nodes)
   if (heavy_ok) {
     G2 = 4096;
     if (const char* e = getenv("MOCAP_RESUBMIT_G_CAP")) G2 = atol(e) > 0 ? atol(e) : 1;

@@ -115,8 +115,12 @@ struct FrameLayout {
     // of gated hits (saturating at 255).  Almost every pair of a wide frame has exactly one hit (the marker's own
     // blob), so these two bytes are all a candidate group is ever decoded from; the full hit lists of the rare
     // multi-hit pairs (and their exact counts) sit in the HBM workspace and are touched only for those pairs.
+    // (round 6: the count as two BITS per (root, camera) -- "has a hit", "has several: the exact count is in the workspace" --
+    // kept as two 64-bit camera masks per root, [R][2]: 6 KB instead of 24.5 KB of bytes at 384 roots x 64 cameras, which
+    // is what lets TWO frames share a CU's LDS; a group's decode loads its root's two masks once and tests a bit per camera)
     h0 = o;        o += wide ? (size_t)R * C : 0;
-    nhc = o;       o += wide ? (size_t)R * C : 0;
+    o = align(o, 8);
+    nhc = o;       o += wide ? 16 * (size_t)R : 0;
     o = align(o, 16);
     // wide: one camera's blobs per wave, staged for match_roots_wide (read back as broadcasts): matching scratch, dead before the
     // segment arrays of phase D / E come alive -- it lies over them (seg_e + seg_x = 32 (T + R) bytes >= 32 KB at T = 1024)
@@ -163,7 +167,7 @@ struct FrameState {
   uint8_t *root_cam, *claimed, *act, *nact;  // act [R][C]: cameras of root r with >= 2 hits
   unsigned long long* claimw;  // wide: [C][ceil(M / 64)] blobs claimed so far (match_wide)
   uint8_t* h0;                 // wide: [R][C] blob index of the closest gated hit (the root's own blob at its camera)   (LDS)
-  uint8_t* nhc;                // wide: [R][C] number of gated hits, saturating at 255 (1 at the root's camera, 0 before it) (LDS)
+  unsigned long long* nhc;     // wide: [R][2] camera masks of root r: bit c of [0] = a gated hit in camera c (the root's own camera included), of [1] = several (LDS)
   float2* wbl;                 // wide: [T / 64][kMaxBlobs] a wave's copy of the camera it is matching against               (LDS)
 
   __device__ FrameState(const FrameArgs& p_, unsigned char* smem)
@@ -197,18 +201,26 @@ struct FrameState {
     act = (uint8_t*)(big + L.act);
     claimw = (unsigned long long*)(smem + L.claimw);
     h0 = smem + L.h0;
-    nhc = smem + L.nhc;
+    nhc = (unsigned long long*)(smem + L.nhc);
     wbl = (float2*)(smem + L.wbl);
   }
 
   // gated hits of root r in camera c (wide: the LDS byte, or the exact count from the workspace when it saturated)
   __device__ __forceinline__ uint32_t nhits(int r, int c) const {
     if constexpr (WIDE) {
-      const uint32_t n = nhc[(size_t)r * C + c];
-      return n < 255u ? n : (uint32_t)nh[(size_t)r * C + c];
+      if (!((nhc[2 * (size_t)r] >> c) & 1ull)) return 0u;
+      return ((nhc[2 * (size_t)r + 1] >> c) & 1ull) ? (uint32_t)nh[(size_t)r * C + c] : 1u;  // (several: resolve_pair left the exact count in the workspace)
     } else {
       return nh[(size_t)r * C + c];
     }
+  }
+  // wide: record that root r has one or several gated hits in camera c.  The masks start at zero for every frame (match_wide)
+  // and every (root, camera) pair is decided once -- by the wave that owns camera c, other cameras' waves set other bits of
+  // the same word at the same time: LDS atomics.
+  __device__ __forceinline__ void set_hit_code(int r, int c, int n_hits) {
+    if (n_hits <= 0) return;
+    atomicOr(&nhc[2 * (size_t)r], 1ull << c);
+    if (n_hits >= 2) atomicOr(&nhc[2 * (size_t)r + 1], 1ull << c);
   }
   // blob index of root r's d-th closest hit in camera c (d < nhits(r, c))
   __device__ __forceinline__ uint32_t hit_at(int r, int c, uint32_t d) const {
@@ -703,7 +715,7 @@ struct FrameState {
           }
           if (have) {
             h0[(size_t)r * C + i] = (uint8_t)my_k0;
-            nhc[(size_t)r * C + i] = (uint8_t)(my_nh < 255 ? my_nh : 255);
+            set_hit_code(r, i, my_nh);
           }
         }
       }
@@ -867,7 +879,7 @@ struct FrameState {
         }
         if (have) {
           h0[(size_t)r * C + i] = (uint8_t)my_k0;
-          nhc[(size_t)r * C + i] = (uint8_t)(my_nh < 255 ? my_nh : 255);
+          set_hit_code(r, i, my_nh);
         }
       }
     }
@@ -882,6 +894,7 @@ struct FrameState {
         cnt[tid] = n < 0 ? 0 : (n > M ? M : n);
       }
       for (int i = tid; i < C * MW; i += T) claimw[i] = 0ull;
+      for (int i = tid; i < 2 * R; i += T) nhc[i] = 0ull;  // every (root, camera) pair: no hit yet
       if (tid == 0) {
         misc[MI_STATUS] = 0;
         misc[MI_OMAX] = 0;
@@ -911,7 +924,7 @@ struct FrameState {
       const int ncam0 = (MOCAP_WIDE_DEBUG_SKIP & 1) ? C : 1;
       for (int idx = tid; idx < n0 * ncam0; idx += T) {
         const int r = idx / ncam0, c = idx - r * ncam0;
-        nhc[(size_t)r * C + c] = c == 0 ? 1 : 0;
+        if (c == 0) set_hit_code(r, 0, 1);
         h0[(size_t)r * C + c] = (uint8_t)r;
       }
       if (tid == 0) {
@@ -961,7 +974,7 @@ struct FrameState {
         const int ncam = (MOCAP_WIDE_DEBUG_SKIP & 2) ? C : j + 1;
         for (int idx = tid; idx < (now - n_roots) * ncam; idx += T) {
           const int r = n_roots + idx / ncam, c = idx % ncam;
-          nhc[(size_t)r * C + c] = c == j ? 1 : 0;
+          if (c == j) set_hit_code(r, j, 1);
           h0[(size_t)r * C + c] = (uint8_t)root_blob[r];
         }
         if (j + 1 < C && !(MOCAP_WIDE_DEBUG_SKIP & 2)) {
@@ -1191,8 +1204,8 @@ struct FrameState {
       // real one and the values are discarded (`c0 + u < C`).  A pass that needs anything else must decode statelessly.
       struct WideObs {
         const uint8_t* h0r;     // LDS [C]: closest hit per camera of the current root
-        const uint8_t* nhr;     // LDS [C]: hit count (saturating)
-        const uint16_t* nh16r;  // workspace [C]: exact counts (read only where the byte saturated)
+        unsigned long long present, several;  // the current root's camera masks (FrameState::nhc)
+        const uint16_t* nh16r;  // workspace [C]: exact counts (read only where the mask says "several")
         const uint8_t* hitsr;   // workspace [C][Hs]: full hit lists of the multi-hit pairs
         const float2* blobs;    // the frame's blobs [C][M]
         int M, Hs;
@@ -1200,12 +1213,11 @@ struct FrameState {
         uint32_t rem;
         __device__ __forceinline__ unsigned long long raw(int c) {
           if (c == 0) rem = gl;
-          uint32_t n = nhr[c];
           unsigned long long w = 0x7fc000007fc00000ull;  // NaN, NaN: camera not in the group
-          if (n) {
+          if ((present >> c) & 1ull) {
             uint32_t k = h0r[c];
-            if (n > 1) {
-              if (n == 255u) n = nh16r[c];
+            if ((several >> c) & 1ull) {
+              const uint32_t n = nh16r[c];
               uint32_t qd, dg;
               divmod_small(rem, n, qd, dg);
               rem = qd;
@@ -1224,7 +1236,7 @@ struct FrameState {
         }
         __device__ __forceinline__ bool operator()(int c, double& x, double& y) { return decode(raw(c), x, y); }
       };
-      WideObs wobs{h0 + (size_t)r * C, nhc + (size_t)r * C, nh + (size_t)r * C, hits + (size_t)r * C * Hs, bxy, M, Hs, g - r_beg, 0u};
+      WideObs wobs{h0 + (size_t)r * C, nhc[2 * (size_t)r], nhc[2 * (size_t)r + 1], nh + (size_t)r * C, hits + (size_t)r * C * Hs, bxy, M, Hs, g - r_beg, 0u};
       // table mode: the column holds blob indices; 0xFF marks "camera not in the group"
       auto contrib = [&](int c, double (&B)[10]) -> bool {
         const uint32_t k = cix[(size_t)c * T];
@@ -1314,7 +1326,8 @@ struct FrameState {
           r_end = goff[r + 1];
           if constexpr (WIDE) {
             wobs.h0r = h0 + (size_t)r * C;
-            wobs.nhr = nhc + (size_t)r * C;
+            wobs.present = nhc[2 * (size_t)r];
+            wobs.several = nhc[2 * (size_t)r + 1];
             wobs.nh16r = nh + (size_t)r * C;
             wobs.hitsr = hits + (size_t)r * C * Hs;
             wobs.gl = 0;
@@ -1734,7 +1747,11 @@ static hipError_t launch_T(const FrameArgs& a, int mode, int grid, size_t lds, h
 
 hipError_t launch_frame_kernel(const FrameArgs& a, int mode, int threads, int grid, hipStream_t stream) {
   const size_t lds = frame_lds_bytes(a.cv.C, a.M, a.K_max, threads, a.H, a.wide != 0, a.cv.uniformK != 0);
-  if (a.wide) return threads == kWideThreads ? launch_T<kWideThreads, true>(a, mode, grid, lds, stream) : hipErrorInvalidValue;
+  if (a.wide) {
+    if (threads == kWideThreads) return launch_T<kWideThreads, true>(a, mode, grid, lds, stream);
+    if (threads == 512 && mode == MODE_ALL) return launch_TM<512, true, MODE_ALL>(a, grid, lds, stream);  // two frames per CU (capi.hip plan_frame)
+    return hipErrorInvalidValue;
+  }
   switch (threads) {
     case 64: return launch_T<64, false>(a, mode, grid, lds, stream);
     case 128: return launch_T<128, false>(a, mode, grid, lds, stream);

@@ -5,7 +5,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "low-cost-mocap_
 from mocap_core import capi, synth
 F = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-C, M, K = 64, 256, 384
+C, M, K = 64, 256, int(os.environ.get("TW_K", "384"))
 rig = synth.stress_rig(C)
 cache = f"/tmp/stress_{F}.npz"
 if os.path.exists(cache):

@@ -112,7 +112,7 @@ def test_stress_frames_run_to_run_bit_identical_through_wide_and_heavy_kernels(g
     first = devcheck.FrameOutputs(F, K_MAX, C, dev)
     first.run(core, M, d_blobs, d_counts, synth.STRESS_GATE_PX, 1 << 20)
     torch.cuda.synchronize(dev)
-    assert core.last_frame_kernel() == "frame_kernel<1024, wide>"
+    assert core.last_frame_kernel() in ("frame_kernel<512, wide>", "frame_kernel<1024, wide>")
     flagged, rerun = first.info.cpu().numpy()
     assert flagged >= 1 and rerun == flagged           # the stream holds frames over the first pass's cap: the repair path runs
     ok = (first.status == 0)

@@ -337,7 +337,7 @@ def test_device_side_resubmit_at_the_stress_shape_and_scratch_budget(core, monke
     auto = core.match_triangulate_auto(blobs, counts, gate_px=gate, K_max=384, G_cap=2)
     assert auto["resubmitted"] == 10
     got = _dev_call(core, core.match_triangulate_dev_auto, blobs, counts, gate, 384, 2)
-    assert core.last_frame_kernel() == "frame_kernel<1024, wide>"
+    assert core.last_frame_kernel() in ("frame_kernel<512, wide>", "frame_kernel<1024, wide>")
     assert got["info"].tolist() == [10, 10] and np.array_equal(got["status"], auto["status"]) and np.array_equal(got["n_out"], auto["n_out"])
     ok = auto["status"] == 0
     assert ok.sum() >= 8
