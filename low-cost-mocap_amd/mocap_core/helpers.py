@@ -43,6 +43,7 @@ _state = {
     "cam_key": None,         # bytes of (K, R, t) currently uploaded
     "lock": threading.Lock(),
     "ba_mode": DEFAULT_BA_MODE,   # "scipy" (reference optimizer, GPU residuals) | "resident" (LM loop in the core)
+    "ba_blas_threads": None,      # None: the process's BLAS settings are left alone (as the reference does); n: pinned for the solve
     "img_key": None,         # (rows, cols, K, dist, rot) of the lens model currently uploaded
     "to_world": None,        # last Cameras.to_world_coords_matrix handed to set_to_world_coords_matrix
 }
@@ -80,6 +81,15 @@ def set_camera_params(camera_params):
     _state["camera_params"] = [dict(p) for p in camera_params]
     _state["cam_key"] = None
     _state["img_key"] = None
+
+
+def set_bundle_adjustment_blas_threads(n):
+    """Mode "scipy" spends its host time in SciPy's SVD of the m x n Jacobian.  On a many-core host OpenBLAS's default thread
+    count makes that SVD slower, not faster (1 000 points x 50 parameters: 1.1 s per calibration with 64 spinning threads on a
+    shared 256-thread box, 0.23 s with one -- bench.py ba.default_mode.one_blas_thread), and its last bits depend on the thread
+    count either way.  n = 1 pins the BLAS for the duration of a solve (threadpoolctl); None (default) leaves the process's
+    settings alone, like the reference."""
+    _state["ba_blas_threads"] = None if n is None else int(n)
 
 
 def set_bundle_adjustment_mode(mode):
@@ -560,8 +570,17 @@ def bundle_adjustment(image_points, camera_poses, socketio, return_info=False):
                 return J_T.T
 
             use_batched = os.environ.get("MOCAP_BA_BATCHED_JAC", "1") != "0" and _compute_absolute_step is not None
-            res = optimize.least_squares(residual_function, x0, jac=jacobian if use_batched else "2-point", verbose=0,
-                                         loss="cauchy", ftol=1e-2)
+            import contextlib
+            blas = contextlib.nullcontext()
+            if _state["ba_blas_threads"] is not None:
+                try:
+                    from threadpoolctl import threadpool_limits
+                    blas = threadpool_limits(limits=_state["ba_blas_threads"])
+                except Exception:
+                    pass
+            with blas:
+                res = optimize.least_squares(residual_function, x0, jac=jacobian if use_batched else "2-point", verbose=0,
+                                             loss="cauchy", ftol=1e-2)
             x, info = res.x, {"iterations": res.njev, "njev": res.njev, "nfev": res.nfev, "status": res.status,
                        "cost": res.cost, "optimality": res.optimality, "core_s": spent["core_s"]}
     poses = _params_to_camera_poses(x)
