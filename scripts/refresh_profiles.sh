@@ -28,5 +28,5 @@ cp $G/final/blob_kernel_stats_skip.csv $P/${TAG}_blob_kernel_stats_prepass.csv
 cp $G/final/blob_kernel_stats_fold.csv $P/${TAG}_blob_kernel_stats_folded.csv
 cp $G/final/blob_pmc_traffic_skip.csv $P/${TAG}_blob_pmc_traffic_prepass.csv
 cp $G/final/blob_pmc_traffic_fold.csv $P/${TAG}_blob_pmc_traffic_folded.csv
-tail -4 $G/final/gpu_suite.txt > $P/${TAG}_gpu_suite_final.txt
+grep "passed\|failed" $G/final/gpu_suite.txt | tail -2 > $P/${TAG}_gpu_suite_final.txt
 ls $P/${TAG}_*
