@@ -599,6 +599,10 @@ static int match_dev_locked(mocap_ctx* ctx, int64_t n_frames, int M_max, const f
                      lds, ctx->C, M_max, K_max);
   a.H = hit_cap;
   a.wide = wide ? 1 : 0;
+  if (wide) {  // A/B and tests: MOCAP_WIDE_SPEC=0 = the chain over the cameras strictly camera by camera (frame_kernel.hip spec_begin)
+    const char* sp = getenv("MOCAP_WIDE_SPEC");
+    if (sp && atoi(sp) == 0) a.wide = 2;
+  }
   a.prune = ctx->prune && !ctx->exhaustive;
   a.p3max2 = a.prune && ctx->eigcut ? ctx->p3max2 : 0.0;
   if (!wide && ctx->frame_threads == 0 && T == 64) a.p3max2 = 0.0;  // tiny frames (a handful of candidates): the cut-offs cost more than they save

@@ -72,6 +72,8 @@ enum { MI_NROOTS = 0, MI_STATUS = 1, MI_NOUT = 2, MI_G = 3, MI_ITEM = 4, MI_DEFE
        MI_BBCTR = 8 /* frame_bb.hip: queued blocks | their candidates << 10 */, MI_NEXT = 9 /* frame_bb.hip: the next frame */,
        MI_BBCTR2 = 10 /* frame_bb.hip: MI_BBCTR's partner (the two take turns) */,
        MI_HEAVY_N = 11 /* wide frames: heavy roots of this frame (FrameArgs::heavy_bb) */, MI_HEAVY_SLOT = 12,
+       MI_SPEC_N = 13 /* wide frames, speculative chain: provisional roots (-1: too many), then 1 = a claim beyond the closest hit */,
+       MI_SPEC_OVER = 14 /* ... provisional roots with a hit list over the cap, two words */,
        MI_HEAVY_R0 = 16 /* ... their root numbers, kMaxHeavyPerFrame entries */ };
 constexpr int kMaxHeavyPerFrame = 48;
 

@@ -50,6 +50,22 @@
 
 namespace mocap {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// median of three unsigned words (with a <= b: the second smallest of {a, b, c})
+__device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) {
+  uint32_t r;
+  asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+// the key mask of the wide pre-test in a VECTOR register the compiler cannot see through: (t & m) | k with a wave-uniform k is then
+// selected as one v_and_or_b32 (one constant-bus operand per instruction; a literal mask would make it v_and + v_or).  Written in
+// C so that the compiler sees the v_pk_fma_f32 -> VALU dependency and keeps the wait state gfx950 wants behind a packed result.
+__device__ __forceinline__ uint32_t opaque_vgpr(uint32_t v) {
+  uint32_t r;
+  asm("v_mov_b32 %0, %1" : "=v"(r) : "s"(v));
+  return r;
+}
+
 // register budget: 4 waves per SIMD (<= 128 VGPRs); the LDS footprint at 8 x 16 allows 4 workgroups
 // of 256 lanes per CU, so both limits meet at 16 waves per CU
 // timing experiments only (results invalid): wide frames without the camera-0 pairs (1) / the chain's pairs (2) / the geometry of the candidate evaluation (4: groups are still loaded, walked and merged)
@@ -57,13 +73,19 @@ namespace mocap {
 #define MOCAP_WIDE_DEBUG_SKIP 0
 #endif
 #ifndef MOCAP_WIDE_ACC
-#define MOCAP_WIDE_ACC 1  // (1: 32.4 -> 30.5 ms per 12 500 stress frames)
+#define MOCAP_WIDE_ACC 1  // (1: 32.4 -> 30.5 ms per 12 500 stress frames; 3: keys + two smallest per position, no compare / branch)
 #endif
 #ifndef MOCAP_WIDE_DEPTH_CUT
 #define MOCAP_WIDE_DEPTH_CUT 0
 #endif
 #ifndef MOCAP_WIDE_CHAIN_T
 #define MOCAP_WIDE_CHAIN_T 24  // wide frames: a chain step with fewer new roots than this keeps the blobs in registers and broadcasts the roots (swept: 8 +2 %, 0 +34 %, never = 24)
+#endif
+#ifndef MOCAP_WIDE_SPEC
+#define MOCAP_WIDE_SPEC 1  // wide frames: the rest of the chain over the cameras matched speculatively in one pass once few blobs are left unclaimed (0: camera by camera)
+#endif
+#ifndef MOCAP_WIDE_SPEC_T
+#define MOCAP_WIDE_SPEC_T 32  // ... at most this many (every provisional root costs one broadcast round per camera: a marker no earlier camera saw -- some 60 unclaimed blobs -- is cheaper as one sequential step)
 #endif
 #ifndef MOCAP_FRAME_WAVES_PER_EU
 #define MOCAP_FRAME_WAVES_PER_EU 4
@@ -77,7 +99,7 @@ namespace mocap {
 struct FrameLayout {
   // byte offsets, computed identically on host (sizes) and device (carving)
   size_t line, dist, seg_e, seg_x, seg_g, goff, gcnt, outslot, root_blob, root_cam, claimed, claimw, nact,
-      cnt, misc, rbound, h0, nhc, wbl, lds_total;    // always LDS
+      cnt, misc, rbound, h0, nhc, wbl, wsrow, lds_total;    // always LDS
   size_t bxy, cxy, hits, dig, nh, act;               // narrow: LDS.  wide: hits / nh (exact counts of the multi-hit pairs) in the workspace, the rest unused
   size_t bt;                                          // table mode: DLT contribution per (camera, blob)
   size_t ws_total;
@@ -104,6 +126,7 @@ struct FrameLayout {
     cnt = o;       o += sizeof(int32_t) * C;
     misc = o;      o += sizeof(int32_t) * 64;
     root_blob = o; o += sizeof(uint16_t) * R;
+    wsrow = o;     o += wide ? sizeof(uint16_t) * R : 0;  // wide: the workspace row that holds root r's multi-hit lists (its row at the time they were written)
     root_cam = o;  o += R;
     claimed = o;   o += wide ? 0 : M;
     nact = o;      o += wide ? 0 : R;
@@ -168,7 +191,9 @@ struct FrameState {
   unsigned long long* claimw;  // wide: [C][ceil(M / 64)] blobs claimed so far (match_wide)
   uint8_t* h0;                 // wide: [R][C] blob index of the closest gated hit (the root's own blob at its camera)   (LDS)
   unsigned long long* nhc;     // wide: [R][2] camera masks of root r: bit c of [0] = a gated hit in camera c (the root's own camera included), of [1] = several (LDS)
+  uint16_t* wsrow;             // wide: [R] workspace row of root r's exact counts / hit lists (a provisional root keeps them where they were written when it moves down: spec_finish)
   float2* wbl;                 // wide: [T / 64][kMaxBlobs] a wave's copy of the camera it is matching against               (LDS)
+  int spec_base = -1;          // wide: first row of the provisional roots while they are matched speculatively (spec_begin / spec_finish), else -1
 
   __device__ FrameState(const FrameArgs& p_, unsigned char* smem)
       : p(p_), cv(p_.cv), C(p_.cv.C), M(p_.M), R(p_.K_max), tid(threadIdx.x) {
@@ -203,13 +228,14 @@ struct FrameState {
     h0 = smem + L.h0;
     nhc = (unsigned long long*)(smem + L.nhc);
     wbl = (float2*)(smem + L.wbl);
+    wsrow = (uint16_t*)(smem + L.wsrow);
   }
 
   // gated hits of root r in camera c (wide: the LDS byte, or the exact count from the workspace when it saturated)
   __device__ __forceinline__ uint32_t nhits(int r, int c) const {
     if constexpr (WIDE) {
       if (!((nhc[2 * (size_t)r] >> c) & 1ull)) return 0u;
-      return ((nhc[2 * (size_t)r + 1] >> c) & 1ull) ? (uint32_t)nh[(size_t)r * C + c] : 1u;  // (several: resolve_pair left the exact count in the workspace)
+      return ((nhc[2 * (size_t)r + 1] >> c) & 1ull) ? (uint32_t)nh[(size_t)wsrow[r] * C + c] : 1u;  // (several: resolve_pair left the exact count in the workspace)
     } else {
       return nh[(size_t)r * C + c];
     }
@@ -225,7 +251,7 @@ struct FrameState {
   // blob index of root r's d-th closest hit in camera c (d < nhits(r, c))
   __device__ __forceinline__ uint32_t hit_at(int r, int c, uint32_t d) const {
     if constexpr (WIDE) {
-      return d == 0 ? (uint32_t)h0[(size_t)r * C + c] : (uint32_t)hits[((size_t)r * C + c) * Hs + d];
+      return d == 0 ? (uint32_t)h0[(size_t)r * C + c] : (uint32_t)hits[((size_t)wsrow[r] * C + c) * Hs + d];
     } else {
       return hits[((size_t)r * C + c) * Hs + d];
     }
@@ -479,16 +505,24 @@ struct FrameState {
       nhits += __popcll(hmask[sg]);
     }
     if (!nhits) return;
-    if (nhits > H) atomicOr(&misc[MI_STATUS], MOCAP_ST_HIT_OVERFLOW_);
+    const bool spec = spec_base >= 0;  // a provisional root: it claims nothing yet, and its flags count only if it turns out real
+    if (nhits > H) {
+      if (spec)
+        atomicOr(&misc[MI_SPEC_OVER + ((rq - spec_base) >> 5)], 1 << ((rq - spec_base) & 31));
+      else
+        atomicOr(&misc[MI_STATUS], MOCAP_ST_HIT_OVERFLOW_);
+    }
     if (nhits == 1) {
       // the one blob inside the gate is the closest hit and claims itself (helpers.py:391)
       int k1 = 0;
 #pragma unroll
       for (int sg = 0; sg < 4; sg++)
         if (hmask[sg]) k1 = 64 * sg + (__ffsll((long long)hmask[sg]) - 1);
+      if (!spec) {
 #pragma unroll
-      for (int sg = 0; sg < 4; sg++)
-        if (hit[sg]) atomicOr(&claimw[(size_t)i * MW + sg], 1ull << lane);
+        for (int sg = 0; sg < 4; sg++)
+          if (hit[sg]) atomicOr(&claimw[(size_t)i * MW + sg], 1ull << lane);
+      }
       if (lane == q) {
         my_nh = 1;
         my_k0 = k1;
@@ -528,11 +562,16 @@ struct FrameState {
         p0x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bl[sg].x), k0 & 63));
         p0y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bl[sg].y), k0 & 63));
       }
+    int nclaim = 0;
 #pragma unroll
     for (int sg = 0; sg < 4; sg++) {
       const unsigned long long cm = __ballot(hit[sg] && bl[sg].x == p0x && bl[sg].y == p0y);
-      if (cm && lane == 0) atomicOr(&claimw[(size_t)i * MW + sg], cm);
+      if (cm && lane == 0 && !spec) atomicOr(&claimw[(size_t)i * MW + sg], cm);
+      nclaim += __popcll(cm);
     }
+    // speculative pass: the claims are replayed later from the closest hits alone (spec_begin / spec_finish); hits that share the
+    // closest hit's coordinates are claimed with it (helpers.py:391) -- such a frame goes to the sequential chain instead
+    if (spec && nclaim != 1 && lane == 0) misc[MI_SPEC_N] = 1;
   }
 
   // Epipolar line of a root in camera i: cv.computeCorrespondEpilines on a float32 point -- double math, scale by
@@ -607,6 +646,68 @@ struct FrameState {
           }
         }
         wave_lds_sync();
+#if MOCAP_WIDE_ACC == 3
+        // All four batches of the group in ONE walk over the camera's blobs: a lane holds the float32 lines of its four roots, so
+        // a broadcast read of four blobs serves 4 x 64 x 4 tests instead of 64 x 4 (the walk was bound by the LDS return path:
+        // 16 cycles per ds_read_b128 and CU whatever the wave does with it).  Bookkeeping without compares, masks or branches:
+        // a blob's KEY = the bit pattern of |t| with its low byte replaced by the blob's index (a positive float's bits order
+        // like the float; dropping the low byte only ever lets MORE blobs through), per root the two smallest keys so far
+        // (v_min_u32 / v_med3_u32); after the walk: how many keys are within the threshold (0, 1, several) and the one
+        // blob's index.  Per test: half a v_pk_fma_f32 pair + v_and_or_b32 + v_med3_u32 + v_min_u32.  The double-precision
+        // lines are computed again per batch below (same expressions, same bits) instead of being kept across the walk.
+        int np4[4], kk4[4];
+        {
+          f32x2 a2[4], b2[4], c2[4];
+          uint32_t thrk[4], kb[4], ks[4];
+#pragma unroll
+          for (int b = 0; b < 4; b++) {
+            const bool have = g0 + 64 * b + lane < rhi;
+            double la = 0, lb = 0, lc = 0, lden = 1, lrden = 1;
+            if (have) {
+              if constexpr (CAM0)
+                epiline_wide(as_ctab(cv.F + 9 * (size_t)i), rp[b], la, lb, lc, lden, lrden);
+              else
+                epiline_wide(cv.F + 9 * ((size_t)rcv[b] * C + i), rp[b], la, lb, lc, lden, lrden);
+            }
+            const float a32 = (float)la, b32 = (float)lb, c32 = (float)lc;
+            float thr = finf;
+            if (F32R) thr = __double2float_ru(p.gate_px * lden * (1.0 + 1e-12) + (2.5 * 0x1p-24) * (2.0 * om + fabs(lc)) * (1.0 + 1e-6));
+            a2[b] = f32x2{a32, a32};
+            b2[b] = f32x2{b32, b32};
+            c2[b] = f32x2{c32, c32};
+            thrk[b] = have ? (__float_as_uint(thr) | 0xffu) : 0u;  // (thr >= 0; idle lanes: `have` gates every use below)
+            kb[b] = ~0u;
+            ks[b] = ~0u;
+          }
+          const uint32_t keym = opaque_vgpr(0x7fffff00u);
+          for (int k0 = 0; k0 < ((MOCAP_WIDE_DEBUG_SKIP & 8) ? 4 : M4); k0 += 4) {  // scalar loop; four blobs per step, two broadcast reads
+            const float4 X = *reinterpret_cast<const float4*>(wx + k0);
+            const float4 Y = *reinterpret_cast<const float4*>(wy + k0);
+            // (the four indices in scalar registers of their own: left to itself the compiler writes k0 + 1 as `k0 | 1` and spends a
+            // v_and + v_or3 per key instead of one v_and_or)
+            uint32_t k1, k2, k3;
+            asm("s_add_i32 %0, %1, 1" : "=s"(k1) : "s"(k0) : "scc");
+            asm("s_add_i32 %0, %1, 2" : "=s"(k2) : "s"(k0) : "scc");
+            asm("s_add_i32 %0, %1, 3" : "=s"(k3) : "s"(k0) : "scc");
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+              const f32x2 t01 = __builtin_elementwise_fma(a2[b], f32x2{X.x, X.y}, __builtin_elementwise_fma(b2[b], f32x2{Y.x, Y.y}, c2[b]));
+              const f32x2 t23 = __builtin_elementwise_fma(a2[b], f32x2{X.z, X.w}, __builtin_elementwise_fma(b2[b], f32x2{Y.z, Y.w}, c2[b]));
+              const uint32_t u0 = (__float_as_uint(t01.x) & keym) | (uint32_t)k0, u1 = (__float_as_uint(t01.y) & keym) | k1;
+              const uint32_t u2 = (__float_as_uint(t23.x) & keym) | k2, u3 = (__float_as_uint(t23.y) & keym) | k3;
+              ks[b] = umed3(kb[b], ks[b], u0); kb[b] = kb[b] < u0 ? kb[b] : u0;
+              ks[b] = umed3(kb[b], ks[b], u1); kb[b] = kb[b] < u1 ? kb[b] : u1;
+              ks[b] = umed3(kb[b], ks[b], u2); kb[b] = kb[b] < u2 ? kb[b] : u2;
+              ks[b] = umed3(kb[b], ks[b], u3); kb[b] = kb[b] < u3 ? kb[b] : u3;
+            }
+          }
+#pragma unroll
+          for (int b = 0; b < 4; b++) {
+            np4[b] = (int)(kb[b] <= thrk[b]) + (int)(ks[b] <= thrk[b]);
+            kk4[b] = (int)(kb[b] & 0xffu);  // (meaningful when np == 1)
+          }
+        }
+#endif
         for (int b = 0; b < 4 && g0 + 64 * b < rhi; b++) {  // wave-uniform; ONE copy of the body (not unrolled)
           const int r = g0 + 64 * b + lane;
           const bool have = r < rhi;
@@ -627,11 +728,15 @@ struct FrameState {
           if (F32R) thr = __double2float_ru(p.gate_px * lden * (1.0 + 1e-12) + (2.5 * 0x1p-24) * (2.0 * om + fabs(lc)) * (1.0 + 1e-6));
           if (!have) thr = -1.0f;
           int np = 0, kk = 0;
-#if MOCAP_WIDE_ACC
+#if MOCAP_WIDE_ACC == 3
+          np = b == 0 ? np4[0] : (b == 1 ? np4[1] : (b == 2 ? np4[2] : np4[3]));
+          kk = b == 0 ? kk4[0] : (b == 1 ? kk4[1] : (b == 2 ? kk4[2] : kk4[3]));
+#elif MOCAP_WIDE_ACC
           // bookkeeping as four accumulators, one per position of a step: += 0x10000 + k0 when the blob passes, i.e. the
           // count in the high half and the index (sum) in the low half -- a select and an add per blob
           uint32_t acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
 #endif
+#if MOCAP_WIDE_ACC != 3
           for (int k0 = 0; k0 < M4; k0 += 4) {  // scalar loop; four blobs per step, two broadcast reads
             const float4 X = *reinterpret_cast<const float4*>(wx + k0);
             const float4 Y = *reinterpret_cast<const float4*>(wy + k0);
@@ -672,7 +777,8 @@ struct FrameState {
             }
 #endif
           }
-#if MOCAP_WIDE_ACC
+#endif
+#if MOCAP_WIDE_ACC && MOCAP_WIDE_ACC != 3
           np = (int)((acc0 >> 16) + (acc1 >> 16) + (acc2 >> 16) + (acc3 >> 16));
           kk = acc0 ? (int)(acc0 & 0xffffu) : (acc1 ? (int)(acc1 & 0xffffu) + 1 : (acc2 ? (int)(acc2 & 0xffffu) + 2 : (int)(acc3 & 0xffffu) + 3));  // (meaningful when np == 1)
 #endif
@@ -681,7 +787,11 @@ struct FrameState {
             int fneg = 0;
             for (int k = 0; k < Mi; k++) {
               const float2 v = make_float2(wx[k], wy[k]);
+#if MOCAP_WIDE_ACC == 3
+              const bool pass = (__float_as_uint(fmaf(a32, v.x, fmaf(b32, v.y, c32))) & 0x7fffff00u) <= (__float_as_uint(thr) | 0xffu);  // the keys' test
+#else
               const bool pass = fabsf(fmaf(a32, v.x, fmaf(b32, v.y, c32))) <= thr;
+#endif
               if (!pass && div_by(fabs(la * (double)v.x + lb * (double)v.y + lc), lden, lrden) < p.gate_px) fneg++;
             }
             atomicAdd(&p.status[p.n_frames], 1);
@@ -698,6 +808,7 @@ struct FrameState {
             }
           }
           unsigned long long multi = __ballot(have && np >= 2);
+          if (MOCAP_WIDE_DEBUG_SKIP & 16) multi = 0;
           if (multi) {  // rare: roots with several candidates, one at a time, the camera's blobs four per lane
             float2 bl[4];
             bool pc[4];
@@ -760,7 +871,10 @@ struct FrameState {
       }
       for (int rb = rlo; rb < rhi; rb += 64) {
         const int r = rb + lane;
-        const bool have = r < rhi;
+        // (a root meets the cameras AFTER its own: always the case for the roots of a chain step -- they were created at
+        // camera clo - 1 -- and the test that matters for provisional roots, which come from many cameras)
+        const bool have = r < rhi && (int)root_cam[r < rhi ? r : rlo] < i;
+        const unsigned long long havem = __ballot(have);
         double la = 0, lb = 0, lc = 0, lden = 1, lrden = 1;
         if (have) {
           // cv.computeCorrespondEpilines on a float32 point: double math, scale by 1/sqrt(a^2+b^2), float32 result
@@ -800,6 +914,7 @@ struct FrameState {
         int cand_k = -1;
         const int nb = rhi - rb < 64 ? rhi - rb : 64;
         for (int q = 0; q < nb; q++) {  // wave-uniform: root rb + q against the camera's blobs
+          if (!((havem >> q) & 1ull)) continue;
           const float fa = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a32), q));
           const float fb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b32), q));
           const float fc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c32), q));
@@ -872,7 +987,7 @@ struct FrameState {
         }
         if (cand_k >= 0) {  // single candidates: helpers.py:373 in double, strict < (helpers.py:375,383); a lone hit claims itself
           if (div_by(fabs(la * (double)cand_x + lb * (double)cand_y + lc), lden, lrden) < p.gate_px) {
-            atomicOr(&claimw[(size_t)i * MW + (cand_k >> 6)], 1ull << (cand_k & 63));
+            if (spec_base < 0) atomicOr(&claimw[(size_t)i * MW + (cand_k >> 6)], 1ull << (cand_k & 63));
             my_nh = 1;
             my_k0 = cand_k;
           }
@@ -883,6 +998,146 @@ struct FrameState {
         }
       }
     }
+  }
+
+  // ---------------------------------------------------------------- the chain over cameras jlo .. C-1 in one pass (round 6)
+  // The sequential chain (match_wide below) pays one round of memory latency per root-creating camera: a blob no root has
+  // claimed becomes a root, is matched against the cameras after it, claims its closest hits there, and only then is the
+  // next camera's unclaimed set known -- 9 to 16 such rounds per stress frame, nearly all for ONE spurious root each.
+  // But a root's lines, gates, orders and hit lists do not depend on the claims at all; only its EXISTENCE does.  So: every
+  // blob of cameras jlo .. C-1 that is unclaimed NOW (by the roots of cameras 0 .. jlo-1) is a provisional root -- the only
+  // blobs that can still become roots, a dozen per stress frame -- and all of them are matched at once, one lane per
+  // provisional root, against the cameras after their own, claiming nothing.  Then one wave replays the reference's order
+  // (helpers.py:402-406): camera by camera, a provisional root whose blob is still unclaimed is real and its closest hits
+  // claim their blobs in the later cameras (helpers.py:391); the real ones move down to consecutive rows in (camera, blob)
+  // order -- the numbering of the sequential chain.  Falls back to that chain (returns false, nothing changed) when there
+  // are more than MOCAP_WIDE_SPEC_T provisional roots or no rows for them, or when a hit list holds a second blob with the closest hit's coordinates
+  // (claimed with it by value: not replayable from the closest hit alone).  All lanes; synchronised on entry and exit.
+  // spec_begin: the provisional roots and their rows; returns their number, 0 (no blob left unclaimed: the chain is complete) or -1.
+  __device__ int spec_begin(int jlo, int n_roots) {
+    const int MW = (M + 63) / 64, lane = tid & 63;
+    if (tid < 64) {
+      int u = 0;
+      if (lane >= jlo && lane < C) {
+        const int Mj = cnt[lane];
+        for (int w = 0; w * 64 < Mj; w++) {
+          const unsigned long long valid = Mj - 64 * w >= 64 ? ~0ull : ((1ull << (Mj - 64 * w)) - 1ull);
+          u += __popcll(~claimw[(size_t)lane * MW + w] & valid);
+        }
+      }
+      const uint32_t incl = wave_inclusive_scan((uint32_t)u, lane);
+      const int total = __builtin_amdgcn_readlane((int)incl, 63);
+      const bool fits = total <= MOCAP_WIDE_SPEC_T && n_roots + total <= R;
+      if (fits && u) {  // lane = camera: its unclaimed blobs in blob order, behind those of the cameras before it
+        int idx = n_roots + (int)incl - u;
+        const int Mj = cnt[lane];
+        for (int w = 0; w * 64 < Mj; w++) {
+          const unsigned long long valid = Mj - 64 * w >= 64 ? ~0ull : ((1ull << (Mj - 64 * w)) - 1ull);
+          unsigned long long m = ~claimw[(size_t)lane * MW + w] & valid;
+          while (m) {
+            const int k = 64 * w + __ffsll((long long)m) - 1;
+            m &= m - 1;
+            root_cam[idx] = (uint8_t)lane;
+            root_blob[idx] = (uint16_t)k;
+            wsrow[idx] = (uint16_t)idx;
+            idx++;
+          }
+        }
+      }
+      if (lane == 0) {
+        misc[MI_SPEC_N] = fits ? total : -1;
+        misc[MI_SPEC_OVER] = 0;
+        misc[MI_SPEC_OVER + 1] = 0;
+      }
+    }
+    __syncthreads();
+    const int nP = misc[MI_SPEC_N];
+    __syncthreads();  // (the slot is reused as the fall-back flag below)
+    if (nP <= 0) return nP;
+    if (tid == 0) misc[MI_SPEC_N] = 0;
+    for (int q = tid; q < nP; q += T) {  // a root's own camera counts as one hit: its blob
+      const int r = n_roots + q, rc = root_cam[r];
+      h0[(size_t)r * C + rc] = (uint8_t)root_blob[r];
+      set_hit_code(r, rc, 1);
+    }
+    __syncthreads();
+    return nP;
+  }
+  // spec_finish: after the provisional roots [n_roots, n_roots + nP) have met their cameras (match_pairs_wide with spec_base set)
+  // and a barrier.  True: the chain is complete, n_roots updated.  False: rows clean, the sequential chain takes over.
+  __device__ bool spec_finish(int nP, int& n_roots) {
+    const int MW = (M + 63) / 64, lane = tid & 63;
+    if (misc[MI_SPEC_N]) {  // workgroup-uniform: the sequential chain starts over from camera jlo with clean rows
+      for (int q = tid; q < 2 * nP; q += T) nhc[2 * (size_t)n_roots + q] = 0ull;
+      __syncthreads();
+      return false;
+    }
+    if (tid < 64) {
+      const int row = n_roots + lane;
+      const bool mine = lane < nP;
+      const int jp = mine ? (int)root_cam[row] : -1, kp = mine ? (int)root_blob[row] : 0;
+      const unsigned long long present = mine ? nhc[2 * (size_t)row] : 0ull;
+      auto bcast64 = [&](unsigned long long v, int l) {
+        return ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(v >> 32), l) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)v, l);
+      };
+      unsigned long long realm = 0ull;
+      int p0 = 0;
+      while (p0 < nP) {  // wave-uniform: the provisional roots are in camera order, one group per camera
+        const int j = __builtin_amdgcn_readlane(jp, p0);
+        const bool at = jp == j;
+        bool real = false;
+        if (at) real = !((claimw[(size_t)j * MW + (kp >> 6)] >> (kp & 63)) & 1ull);
+        const unsigned long long grp = __ballot(at);
+        unsigned long long m = __ballot(real);
+        realm |= m;
+        while (m) {  // a real root's closest hits claim their blobs in the cameras after its own: lane = camera
+          const int q = __ffsll((long long)m) - 1;
+          m &= m - 1;
+          const unsigned long long pres = bcast64(present, q);
+          if (lane > j && lane < C && ((pres >> lane) & 1ull)) {
+            const int k = h0[(size_t)(n_roots + q) * C + lane];
+            atomicOr(&claimw[(size_t)lane * MW + (k >> 6)], 1ull << (k & 63));
+          }
+        }
+        wave_lds_sync();
+        p0 += __popcll(grp);
+      }
+      // the real ones move down to consecutive rows, in order (a row number only ever decreases: no row is overwritten
+      // before it has moved)
+      int d = n_roots;
+      unsigned long long m = realm;
+      while (m) {
+        const int q = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        const int s = n_roots + q;
+        if (s != d) {
+          const unsigned long long pres = nhc[2 * (size_t)s], sev = nhc[2 * (size_t)s + 1];
+          if (lane < C) h0[(size_t)d * C + lane] = h0[(size_t)s * C + lane];  // (the multi-hit lists stay in workspace row s: wsrow)
+          if (lane == 0) {
+            nhc[2 * (size_t)d] = pres;
+            nhc[2 * (size_t)d + 1] = sev;
+            root_cam[d] = root_cam[s];
+            root_blob[d] = root_blob[s];
+            wsrow[d] = (uint16_t)s;
+          }
+          wave_lds_sync();
+        }
+        d++;
+      }
+      const int nreal = __popcll(realm);
+      for (int r = n_roots + nreal + lane; r < n_roots + nP; r += 64) {  // rows left behind: no hits (nothing else of a row is read without its masks)
+        nhc[2 * (size_t)r] = 0ull;
+        nhc[2 * (size_t)r + 1] = 0ull;
+      }
+      if (lane == 0) {
+        const unsigned long long over = ((unsigned long long)(uint32_t)misc[MI_SPEC_OVER + 1] << 32) | (uint32_t)misc[MI_SPEC_OVER];
+        if (over & realm) misc[MI_STATUS] |= MOCAP_ST_HIT_OVERFLOW_;
+        misc[MI_NROOTS] = n_roots + nreal;
+      }
+    }
+    __syncthreads();
+    n_roots = misc[MI_NROOTS];
+    return true;
   }
 
   __device__ void match_wide(int64_t frame) {
@@ -918,6 +1173,7 @@ struct FrameState {
       for (int r = tid; r < n0; r += T) {
         root_cam[r] = 0;
         root_blob[r] = (uint16_t)r;
+        wsrow[r] = (uint16_t)r;
       }
       // a root's own camera counts as one "hit" (its blob), the cameras before it as none: a candidate group is decoded
       // from these two bytes per camera alone
@@ -938,50 +1194,73 @@ struct FrameState {
 #endif
     __syncthreads();
     int n_roots = n0;
+    bool spec_ok = MOCAP_WIDE_SPEC && !(MOCAP_WIDE_DEBUG_SKIP & 2) && p.wide != 2;
     for (int j = 1; j < C; j++) {
-      // unclaimed blobs of camera j become new roots, in blob order (helpers.py:402-406); wave 0 compacts
-      if (tid < 64) {
-        const int Mj = cnt[j];
-        int base_root = n_roots;
-        for (int w = 0; w * 64 < Mj; w++) {
-          const int k = 64 * w + tid;
-          const unsigned long long cl = claimw[(size_t)j * MW + w];
-          const bool flag = k < Mj && !((cl >> tid) & 1ull);
-          const unsigned long long mask = __ballot(flag);
-          const int pos = __popcll(mask & ((1ull << tid) - 1ull));
-          if (flag) {
-            const int rr = base_root + pos;
-            if (rr < R) {
-              root_cam[rr] = (uint8_t)j;
-              root_blob[rr] = (uint16_t)k;
-            }
-          }
-          base_root += __popcll(mask);
-        }
-        if (tid == 0) {
-          if (base_root > R) {
-            misc[MI_STATUS] |= MOCAP_ST_ROOT_OVERFLOW_;
-            base_root = R;
-          }
-          misc[MI_NROOTS] = base_root;
-        }
+      // cameras j .. C-1 in one speculative pass as soon as few blobs are left unclaimed (spec_begin), else camera j alone
+      int nP = -1;
+      if (spec_ok) {
+        nP = spec_begin(j, n_roots);
+        if (nP == 0) break;
       }
-      __syncthreads();
-      const int now = misc[MI_NROOTS];
-      if (now > n_roots) {  // workgroup-uniform
-        // cameras up to the root's own (the pairs with the cameras after it are written by match_pairs_wide below, by
-        // other waves at the same time: the two must not touch the same bytes)
-        const int ncam = (MOCAP_WIDE_DEBUG_SKIP & 2) ? C : j + 1;
-        for (int idx = tid; idx < (now - n_roots) * ncam; idx += T) {
-          const int r = n_roots + idx / ncam, c = idx % ncam;
-          if (c == j) set_hit_code(r, j, 1);
-          h0[(size_t)r * C + c] = (uint8_t)root_blob[r];
-        }
-        if (j + 1 < C && !(MOCAP_WIDE_DEBUG_SKIP & 2)) {
-          // few new roots (the usual chain step): the blobs stay in registers and the roots are broadcast; many: one lane per root
-          if (now - n_roots < MOCAP_WIDE_CHAIN_T) match_pairs_wide(n_roots, now, j + 1); else match_roots_wide<false>(n_roots, now, j + 1);
+      int now = n_roots;
+      if (nP < 0) {
+        // unclaimed blobs of camera j become new roots, in blob order (helpers.py:402-406); wave 0 compacts
+        if (tid < 64) {
+          const int Mj = cnt[j];
+          int base_root = n_roots;
+          for (int w = 0; w * 64 < Mj; w++) {
+            const int k = 64 * w + tid;
+            const unsigned long long cl = claimw[(size_t)j * MW + w];
+            const bool flag = k < Mj && !((cl >> tid) & 1ull);
+            const unsigned long long mask = __ballot(flag);
+            const int pos = __popcll(mask & ((1ull << tid) - 1ull));
+            if (flag) {
+              const int rr = base_root + pos;
+              if (rr < R) {
+                root_cam[rr] = (uint8_t)j;
+                root_blob[rr] = (uint16_t)k;
+                wsrow[rr] = (uint16_t)rr;
+              }
+            }
+            base_root += __popcll(mask);
+          }
+          if (tid == 0) {
+            if (base_root > R) {
+              misc[MI_STATUS] |= MOCAP_ST_ROOT_OVERFLOW_;
+              base_root = R;
+            }
+            misc[MI_NROOTS] = base_root;
+          }
         }
         __syncthreads();
+        now = misc[MI_NROOTS];
+        if (now > n_roots) {  // workgroup-uniform
+          // cameras up to the root's own (the pairs with the cameras after it are written by match_pairs_wide below, by
+          // other waves at the same time: the two must not touch the same bytes)
+          const int ncam = (MOCAP_WIDE_DEBUG_SKIP & 2) ? C : j + 1;
+          for (int idx = tid; idx < (now - n_roots) * ncam; idx += T) {
+            const int r = n_roots + idx / ncam, c = idx % ncam;
+            if (c == j) set_hit_code(r, j, 1);
+            h0[(size_t)r * C + c] = (uint8_t)root_blob[r];
+          }
+        }
+      } else {
+        now = n_roots + nP;
+      }
+      if (now > n_roots) {  // workgroup-uniform
+        if (j + 1 < C && !(MOCAP_WIDE_DEBUG_SKIP & 2)) {
+          // few new roots (the usual chain step), or provisional ones: the blobs stay in registers and the roots are broadcast; many: one lane per root
+          spec_base = nP > 0 ? n_roots : -1;
+          if (nP > 0 || now - n_roots < MOCAP_WIDE_CHAIN_T) match_pairs_wide(n_roots, now, j + 1); else match_roots_wide<false>(n_roots, now, j + 1);
+          spec_base = -1;
+        }
+        __syncthreads();
+      }
+      if (nP > 0) {
+        if (spec_finish(nP, n_roots)) break;
+        spec_ok = false;  // (rare: see spec_finish) camera j again, and the rest of the frame, sequentially
+        j--;
+        continue;
       }
       n_roots = now;
     }
@@ -1236,7 +1515,8 @@ struct FrameState {
         }
         __device__ __forceinline__ bool operator()(int c, double& x, double& y) { return decode(raw(c), x, y); }
       };
-      WideObs wobs{h0 + (size_t)r * C, nhc[2 * (size_t)r], nhc[2 * (size_t)r + 1], nh + (size_t)r * C, hits + (size_t)r * C * Hs, bxy, M, Hs, g - r_beg, 0u};
+      const size_t wr0 = WIDE ? (size_t)wsrow[r] : (size_t)r;
+      WideObs wobs{h0 + (size_t)r * C, nhc[2 * (size_t)r], nhc[2 * (size_t)r + 1], nh + wr0 * C, hits + wr0 * C * Hs, bxy, M, Hs, g - r_beg, 0u};
       // table mode: the column holds blob indices; 0xFF marks "camera not in the group"
       auto contrib = [&](int c, double (&B)[10]) -> bool {
         const uint32_t k = cix[(size_t)c * T];
@@ -1328,8 +1608,8 @@ struct FrameState {
             wobs.h0r = h0 + (size_t)r * C;
             wobs.present = nhc[2 * (size_t)r];
             wobs.several = nhc[2 * (size_t)r + 1];
-            wobs.nh16r = nh + (size_t)r * C;
-            wobs.hitsr = hits + (size_t)r * C * Hs;
+            wobs.nh16r = nh + (size_t)wsrow[r] * C;
+            wobs.hitsr = hits + (size_t)wsrow[r] * C * Hs;
             wobs.gl = 0;
           } else {
             load_group<true>(r, 0);

@@ -54,7 +54,7 @@ struct FrameArgs {
   unsigned char* ws;
   size_t ws_stride;
   int H;
-  int wide;
+  int wide;   // 1: wide variant; 2: ... with the chain over the cameras strictly sequential (A/B, tests: MOCAP_WIDE_SPEC=0)
   int prune;  // cut the reprojection of a group short once it cannot beat the best of its root (exact, see evaluate())
   int eval_bb;  // (host only) the batch goes to frame_bb.hip
   int bb_pl;    // ... candidates per block (at least)

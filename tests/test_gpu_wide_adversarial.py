@@ -138,6 +138,76 @@ def test_duplicate_pixels_and_heavy_dropout(core):
     assert ref["n_out"].max() > 256            # kept roots created by cameras 1..: more points than camera 0 has blobs
 
 
+def _run_wide(core_cls, rig, blobs, counts, gate, K_max, hit_cap, spec):
+    """One forced-wide pass in a fresh context, with the speculative chain on or off (MOCAP_WIDE_SPEC is read per launch)."""
+    old = os.environ.get("MOCAP_WIDE_SPEC")
+    os.environ["MOCAP_WIDE_SPEC"] = "1" if spec else "0"
+    try:
+        core = core_cls(0)
+        core.set_cameras(rig["K"], rig["R"], rig["t"])
+        core.set_frame_limits(hit_cap=hit_cap, force_wide=True)
+        res = core.match_triangulate(blobs, counts, gate_px=gate, K_max=K_max, G_cap=1 << 20)
+        assert core.last_frame_kernel() in ("frame_kernel<512, wide>", "frame_kernel<1024, wide>")
+        return res
+    finally:
+        if old is None:
+            os.environ.pop("MOCAP_WIDE_SPEC", None)
+        else:
+            os.environ["MOCAP_WIDE_SPEC"] = old
+
+
+def test_speculative_chain_on_many_small_frames(core):
+    """Round 6: once few blobs are left unclaimed, the wide variant matches all of them at once as PROVISIONAL roots and
+    replays the reference's camera-by-camera claims afterwards (frame_kernel.hip spec_begin / spec_finish).  What can go
+    wrong there is order and existence -- a provisional root claimed by an earlier provisional root, rows moving down, a
+    hit list that holds a duplicate of the closest hit (the frame must fall back to the sequential chain), a hit list over
+    the cap on a provisional root that turns out not to exist (must not flag the frame).  Thousands of small forced-wide
+    frames with integer pixels (duplicates), dropout (roots from many cameras), wide gates (multi-hit pairs), one run with a
+    hit cap of 2: every output bit equal to the strictly sequential chain (MOCAP_WIDE_SPEC=0), and the uncapped runs equal
+    to the C oracle."""
+    from mocap_core import capi, synth
+    from oracle import c_oracle
+    for C, M, gate, dropout, seed, hit_cap in ((8, 16, 3.0, 0.3, 11, 32), (12, 12, 5.0, 0.15, 12, 32), (16, 24, 2.0, 0.1, 13, 32),
+                                               (8, 16, 1.5, 0.3, 14, 2)):
+        K = [[320.0, 0.0, 160.0], [0.0, 320.0, 160.0], [0.0, 0.0, 1.0]]
+        rig = synth.ring_rig(C, K=K, image_size=(320, 320))
+        blobs, counts, _ = synth.make_blob_stream(rig, 600, M, seed=seed, noise_px=0.3, dropout=dropout, truncate=True)
+        res = _run_wide(capi.MocapCore, rig, blobs, counts, gate, C * M, hit_cap, spec=True)
+        seq = _run_wide(capi.MocapCore, rig, blobs, counts, gate, C * M, hit_cap, spec=False)
+        for k in ("status", "n_out", "n_cand"):
+            assert np.array_equal(res[k], seq[k]), (C, M, k, np.flatnonzero(res[k] != seq[k])[:8])
+        valid = np.arange(res["corr"].shape[1])[None, :] < res["n_out"][:, None]
+        assert np.array_equal(res["corr"][valid], seq["corr"][valid])
+        assert np.array_equal(res["xyz"][valid].view(np.uint64), seq["xyz"][valid].view(np.uint64))
+        assert np.array_equal(res["err"][valid].view(np.uint64), seq["err"][valid].view(np.uint64))
+        if hit_cap == 2:
+            assert (res["status"] != 0).sum() > 10 and (res["status"] == 0).sum() > 10   # (the capped run flags frames, not all)
+            continue
+        ref = c_oracle.COracle(rig["K"], rig["R"], rig["t"]).match_triangulate(blobs, counts, gate_px=gate, K_max=C * M, G_cap=1 << 20)
+        assert np.array_equal(res["status"], ref["status"]) and np.array_equal(res["n_out"], ref["n_out"])
+        kk = min(res["corr"].shape[1], ref["corr"].shape[1])
+        valid = (np.arange(kk)[None, :] < ref["n_out"][:, None]) & (ref["status"] == 0)[:, None]
+        assert valid.sum() > 1000
+        assert np.array_equal(res["corr"][:, :kk][valid], ref["corr"][:, :kk][valid])
+        np.testing.assert_allclose(res["xyz"][:, :kk][valid], ref["xyz"][:, :kk][valid], rtol=1e-9, atol=1e-12)
+
+
+def test_speculative_chain_equals_the_sequential_one_at_the_stress_shape(core):
+    """... and 256 stress frames (64 x 256), where the speculative pass is what runs for nearly every frame."""
+    from mocap_core import capi, synth
+    rig = synth.stress_rig(64)
+    blobs, counts, _ = synth.make_stress_stream_chunked(rig, 256, 256, seed=77)
+    res = _run_wide(capi.MocapCore, rig, blobs, counts, synth.STRESS_GATE_PX, 384, 32, spec=True)
+    seq = _run_wide(capi.MocapCore, rig, blobs, counts, synth.STRESS_GATE_PX, 384, 32, spec=False)
+    for k in ("status", "n_out", "n_cand"):
+        assert np.array_equal(res[k], seq[k]), k
+    valid = np.arange(res["corr"].shape[1])[None, :] < res["n_out"][:, None]
+    assert valid.sum() > 256 * 200
+    assert np.array_equal(res["corr"][valid], seq["corr"][valid])
+    assert np.array_equal(res["xyz"][valid].view(np.uint64), seq["xyz"][valid].view(np.uint64))
+    assert np.array_equal(res["err"][valid].view(np.uint64), seq["err"][valid].view(np.uint64))
+
+
 def test_rig_in_millimetres_and_tiny_gate(core):
     """World units do not enter the pre-test's bound (the line is normalised), coordinates do: a rig in millimetres with
     16 k-pixel coordinates, and a gate far below the float32 resolution of the coordinates' products."""
