@@ -50,22 +50,6 @@
 
 namespace mocap {
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-// median of three unsigned words (with a <= b: the second smallest of {a, b, c})
-__device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) {
-  uint32_t r;
-  asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-  return r;
-}
-// the key mask of the wide pre-test in a VECTOR register the compiler cannot see through: (t & m) | k with a wave-uniform k is then
-// selected as one v_and_or_b32 (one constant-bus operand per instruction; a literal mask would make it v_and + v_or).  Written in
-// C so that the compiler sees the v_pk_fma_f32 -> VALU dependency and keeps the wait state gfx950 wants behind a packed result.
-__device__ __forceinline__ uint32_t opaque_vgpr(uint32_t v) {
-  uint32_t r;
-  asm("v_mov_b32 %0, %1" : "=v"(r) : "s"(v));
-  return r;
-}
-
 // register budget: 4 waves per SIMD (<= 128 VGPRs); the LDS footprint at 8 x 16 allows 4 workgroups
 // of 256 lanes per CU, so both limits meet at 16 waves per CU
 // timing experiments only (results invalid): wide frames without the camera-0 pairs (1) / the chain's pairs (2) / the geometry of the candidate evaluation (4: groups are still loaded, walked and merged)
@@ -73,7 +57,7 @@ __device__ __forceinline__ uint32_t opaque_vgpr(uint32_t v) {
 #define MOCAP_WIDE_DEBUG_SKIP 0
 #endif
 #ifndef MOCAP_WIDE_ACC
-#define MOCAP_WIDE_ACC 1  // (1: 32.4 -> 30.5 ms per 12 500 stress frames; 3: keys + two smallest per position, no compare / branch)
+#define MOCAP_WIDE_ACC 1  // (1: 32.4 -> 30.5 ms per 12 500 stress frames)
 #endif
 #ifndef MOCAP_WIDE_DEPTH_CUT
 #define MOCAP_WIDE_DEPTH_CUT 0
@@ -83,6 +67,12 @@ __device__ __forceinline__ uint32_t opaque_vgpr(uint32_t v) {
 #endif
 #ifndef MOCAP_WIDE_SPEC
 #define MOCAP_WIDE_SPEC 1  // wide frames: the rest of the chain over the cameras matched speculatively in one pass once few blobs are left unclaimed (0: camera by camera)
+#endif
+#ifndef MOCAP_SPLIT_CV
+#define MOCAP_SPLIT_CV 1
+#endif
+#ifndef MOCAP_WIDE_CAM1
+#define MOCAP_WIDE_CAM1 1  // wide frames: camera 1 first, its roots then ride with the camera-0 roots through cameras 2 .. C-1 (0: a chain step for them)
 #endif
 #ifndef MOCAP_WIDE_SPEC_T
 #define MOCAP_WIDE_SPEC_T 32  // ... at most this many (every provisional root costs one broadcast round per camera: a marker no earlier camera saw -- some 60 unclaimed blobs -- is cheaper as one sequential step)
@@ -167,12 +157,29 @@ struct FrameLayout {
 size_t frame_lds_bytes(int C, int M, int R, int T, int H, bool wide, bool table) { return FrameLayout(C, M, R, T, H, wide, table && !wide).lds_total; }
 size_t frame_ws_bytes(int C, int M, int R, int T, int H, bool wide, bool table) { return FrameLayout(C, M, R, T, H, wide, table && !wide).ws_total; }
 
+// The kernel arguments arrive through one s_load_dwordx16; a value that lives in a slice of those sixteen registers is spilled and
+// reloaded as the whole block (16 v_readlane per reload: the camera tables' pointers were reloaded that way inside the candidate
+// evaluation).  Passing each pointer through an empty asm makes it a 64-bit value of its own: two lanes per reload.
+template <class Tp>
+__device__ __forceinline__ Tp* own_sgprs(Tp* ptr) {
+  asm volatile("" : "+s"(ptr));
+  return ptr;
+}
+__device__ __forceinline__ CamView split_cam_view(const CamView& v) {
+  CamView c = v;
+  c.Pq = own_sgprs(v.Pq);
+  c.RT = own_sgprs(v.RT);
+  c.K4 = own_sgprs(v.K4);
+  c.F = own_sgprs(v.F);
+  return c;
+}
+
 // HEAVY (wide variant, re-submit pass only): roots over the candidate cap are exported to the heavy-root search instead of
 // flagging their frames -- a separate instantiation, so that the code does not weigh on the registers of the first pass
 template <int T, bool UNIFORM_K, bool F32R, bool WIDE, bool HEAVY = false>
 struct FrameState {
   const FrameArgs& p;
-  const CamView& cv;
+  const CamView cv;  // a copy whose table pointers are scalar values of their own (split_cam_view), not slices of a 16-dword kernel-argument load
   const int C, M, R, tid;
   int Hs;  // hit-list stride per (root, camera)
   double *line, *dist, *seg_e, *seg_x;
@@ -196,7 +203,7 @@ struct FrameState {
   int spec_base = -1;          // wide: first row of the provisional roots while they are matched speculatively (spec_begin / spec_finish), else -1
 
   __device__ FrameState(const FrameArgs& p_, unsigned char* smem)
-      : p(p_), cv(p_.cv), C(p_.cv.C), M(p_.M), R(p_.K_max), tid(threadIdx.x) {
+      : p(p_), cv(MOCAP_SPLIT_CV ? split_cam_view(p_.cv) : p_.cv), C(p_.cv.C), M(p_.M), R(p_.K_max), tid(threadIdx.x) {
     const FrameLayout L(C, M, R, T, p_.H, WIDE, TABLE);
     Hs = L.Hs;
     line = (double*)(smem + L.line);
@@ -607,12 +614,15 @@ struct FrameState {
   // the blobs that pass for some root of the batch, a scalar branch).  The exact decision of helpers.py:373,375
   // follows for the 64 roots at once; a root with several candidates goes through resolve_pair.  Round 3 kept the blobs in
   // registers and broadcast the roots instead: each pair then paid ~30 scalar / cross-lane instructions to hand the one
-  // passing blob to the lane that holds the root's line (55 issue slots per pair, measured).  CAM0: every root of the
-  // call is a camera-0 root (the fundamental matrices come over the scalar cache).
-  template <bool CAM0>
-  __device__ void match_roots_wide(int rlo, int rhi, int clo) {
+  // passing blob to the lane that holds the root's line (55 issue slots per pair, measured).  CAM01: every root of the
+  // call comes from camera 0 or camera 1 (the two fundamental matrices of a camera come over the scalar cache, a select per
+  // lane).  Cameras [clo, chi): a wave takes every (T / 64)-th; `split`: every wave of the first four takes EVERY camera and
+  // one batch of each group instead (the call for camera 1 alone, on which everything after it waits).
+  template <bool CAM01>
+  __device__ void match_roots_wide(int rlo, int rhi, int clo, int chi, bool split) {
     constexpr int W = T / 64;
     const int lane = tid & 63, wave = tid >> 6;
+    if (split && wave >= 4) return;  // (no workgroup barrier inside)
     const int MW = (M + 63) / 64;
     const double om = (double)__int_as_float(misc[MI_OMAX]);
     // the wave's copy of the camera's blobs, x and y apart: four consecutive x (or y) are one broadcast read
@@ -630,7 +640,7 @@ struct FrameState {
         rcv[b] = okr ? root_cam[r] : 0;
         rp[b] = bxy[(size_t)rcv[b] * M + (okr ? root_blob[r] : 0)];
       }
-      for (int i = clo + wave; i < C; i += W) {  // wave-uniform
+      for (int i = clo + (split ? 0 : wave); i < chi; i += (split ? 1 : W)) {  // wave-uniform
         const int Mi = __builtin_amdgcn_readfirstlane(cnt[i]);  // (uniform anyway: tells the compiler so -- scalar loop control below)
         const int M4 = (Mi + 3) & ~3;
         const float2* row = bxy + (size_t)i * M;
@@ -646,69 +656,7 @@ struct FrameState {
           }
         }
         wave_lds_sync();
-#if MOCAP_WIDE_ACC == 3
-        // All four batches of the group in ONE walk over the camera's blobs: a lane holds the float32 lines of its four roots, so
-        // a broadcast read of four blobs serves 4 x 64 x 4 tests instead of 64 x 4 (the walk was bound by the LDS return path:
-        // 16 cycles per ds_read_b128 and CU whatever the wave does with it).  Bookkeeping without compares, masks or branches:
-        // a blob's KEY = the bit pattern of |t| with its low byte replaced by the blob's index (a positive float's bits order
-        // like the float; dropping the low byte only ever lets MORE blobs through), per root the two smallest keys so far
-        // (v_min_u32 / v_med3_u32); after the walk: how many keys are within the threshold (0, 1, several) and the one
-        // blob's index.  Per test: half a v_pk_fma_f32 pair + v_and_or_b32 + v_med3_u32 + v_min_u32.  The double-precision
-        // lines are computed again per batch below (same expressions, same bits) instead of being kept across the walk.
-        int np4[4], kk4[4];
-        {
-          f32x2 a2[4], b2[4], c2[4];
-          uint32_t thrk[4], kb[4], ks[4];
-#pragma unroll
-          for (int b = 0; b < 4; b++) {
-            const bool have = g0 + 64 * b + lane < rhi;
-            double la = 0, lb = 0, lc = 0, lden = 1, lrden = 1;
-            if (have) {
-              if constexpr (CAM0)
-                epiline_wide(as_ctab(cv.F + 9 * (size_t)i), rp[b], la, lb, lc, lden, lrden);
-              else
-                epiline_wide(cv.F + 9 * ((size_t)rcv[b] * C + i), rp[b], la, lb, lc, lden, lrden);
-            }
-            const float a32 = (float)la, b32 = (float)lb, c32 = (float)lc;
-            float thr = finf;
-            if (F32R) thr = __double2float_ru(p.gate_px * lden * (1.0 + 1e-12) + (2.5 * 0x1p-24) * (2.0 * om + fabs(lc)) * (1.0 + 1e-6));
-            a2[b] = f32x2{a32, a32};
-            b2[b] = f32x2{b32, b32};
-            c2[b] = f32x2{c32, c32};
-            thrk[b] = have ? (__float_as_uint(thr) | 0xffu) : 0u;  // (thr >= 0; idle lanes: `have` gates every use below)
-            kb[b] = ~0u;
-            ks[b] = ~0u;
-          }
-          const uint32_t keym = opaque_vgpr(0x7fffff00u);
-          for (int k0 = 0; k0 < ((MOCAP_WIDE_DEBUG_SKIP & 8) ? 4 : M4); k0 += 4) {  // scalar loop; four blobs per step, two broadcast reads
-            const float4 X = *reinterpret_cast<const float4*>(wx + k0);
-            const float4 Y = *reinterpret_cast<const float4*>(wy + k0);
-            // (the four indices in scalar registers of their own: left to itself the compiler writes k0 + 1 as `k0 | 1` and spends a
-            // v_and + v_or3 per key instead of one v_and_or)
-            uint32_t k1, k2, k3;
-            asm("s_add_i32 %0, %1, 1" : "=s"(k1) : "s"(k0) : "scc");
-            asm("s_add_i32 %0, %1, 2" : "=s"(k2) : "s"(k0) : "scc");
-            asm("s_add_i32 %0, %1, 3" : "=s"(k3) : "s"(k0) : "scc");
-#pragma unroll
-            for (int b = 0; b < 4; b++) {
-              const f32x2 t01 = __builtin_elementwise_fma(a2[b], f32x2{X.x, X.y}, __builtin_elementwise_fma(b2[b], f32x2{Y.x, Y.y}, c2[b]));
-              const f32x2 t23 = __builtin_elementwise_fma(a2[b], f32x2{X.z, X.w}, __builtin_elementwise_fma(b2[b], f32x2{Y.z, Y.w}, c2[b]));
-              const uint32_t u0 = (__float_as_uint(t01.x) & keym) | (uint32_t)k0, u1 = (__float_as_uint(t01.y) & keym) | k1;
-              const uint32_t u2 = (__float_as_uint(t23.x) & keym) | k2, u3 = (__float_as_uint(t23.y) & keym) | k3;
-              ks[b] = umed3(kb[b], ks[b], u0); kb[b] = kb[b] < u0 ? kb[b] : u0;
-              ks[b] = umed3(kb[b], ks[b], u1); kb[b] = kb[b] < u1 ? kb[b] : u1;
-              ks[b] = umed3(kb[b], ks[b], u2); kb[b] = kb[b] < u2 ? kb[b] : u2;
-              ks[b] = umed3(kb[b], ks[b], u3); kb[b] = kb[b] < u3 ? kb[b] : u3;
-            }
-          }
-#pragma unroll
-          for (int b = 0; b < 4; b++) {
-            np4[b] = (int)(kb[b] <= thrk[b]) + (int)(ks[b] <= thrk[b]);
-            kk4[b] = (int)(kb[b] & 0xffu);  // (meaningful when np == 1)
-          }
-        }
-#endif
-        for (int b = 0; b < 4 && g0 + 64 * b < rhi; b++) {  // wave-uniform; ONE copy of the body (not unrolled)
+        for (int b = split ? wave : 0; b < 4 && g0 + 64 * b < rhi; b += split ? 4 : 1) {  // wave-uniform; ONE copy of the body (not unrolled)
           const int r = g0 + 64 * b + lane;
           const bool have = r < rhi;
           // this batch's root point: selected from registers (b is wave-uniform), never an indexed array
@@ -716,10 +664,19 @@ struct FrameState {
           const int rcb = b == 0 ? rcv[0] : (b == 1 ? rcv[1] : (b == 2 ? rcv[2] : rcv[3]));
           double la = 0, lb = 0, lc = 0, lden = 1, lrden = 1;
           if (have) {
-            if constexpr (CAM0)
-              epiline_wide(as_ctab(cv.F + 9 * (size_t)i), rpb, la, lb, lc, lden, lrden);
-            else
+            if constexpr (CAM01) {
+              struct F01 {  // F[0][i] or F[1][i], by the root's camera: two scalar loads and a select per entry
+                ctab_t f0, f1;
+                bool one;
+                __device__ __forceinline__ double operator[](int k) const {
+                  const double a = f0[k], b = f1[k];
+                  return one ? b : a;
+                }
+              };
+              epiline_wide(F01{as_ctab(cv.F + 9 * (size_t)i), as_ctab(cv.F + 9 * ((size_t)C + i)), rcb != 0}, rpb, la, lb, lc, lden, lrden);
+            } else {
               epiline_wide(cv.F + 9 * ((size_t)rcb * C + i), rpb, la, lb, lc, lden, lrden);
+            }
           }
           // pre-test threshold, rounded up (a rigorous bound on the float32 evaluation, see match_pairs_wide); +inf --
           // everything goes to the exact test -- without the float32 line; idle lanes never pass
@@ -728,15 +685,11 @@ struct FrameState {
           if (F32R) thr = __double2float_ru(p.gate_px * lden * (1.0 + 1e-12) + (2.5 * 0x1p-24) * (2.0 * om + fabs(lc)) * (1.0 + 1e-6));
           if (!have) thr = -1.0f;
           int np = 0, kk = 0;
-#if MOCAP_WIDE_ACC == 3
-          np = b == 0 ? np4[0] : (b == 1 ? np4[1] : (b == 2 ? np4[2] : np4[3]));
-          kk = b == 0 ? kk4[0] : (b == 1 ? kk4[1] : (b == 2 ? kk4[2] : kk4[3]));
-#elif MOCAP_WIDE_ACC
+#if MOCAP_WIDE_ACC
           // bookkeeping as four accumulators, one per position of a step: += 0x10000 + k0 when the blob passes, i.e. the
           // count in the high half and the index (sum) in the low half -- a select and an add per blob
           uint32_t acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
 #endif
-#if MOCAP_WIDE_ACC != 3
           for (int k0 = 0; k0 < M4; k0 += 4) {  // scalar loop; four blobs per step, two broadcast reads
             const float4 X = *reinterpret_cast<const float4*>(wx + k0);
             const float4 Y = *reinterpret_cast<const float4*>(wy + k0);
@@ -777,8 +730,7 @@ struct FrameState {
             }
 #endif
           }
-#endif
-#if MOCAP_WIDE_ACC && MOCAP_WIDE_ACC != 3
+#if MOCAP_WIDE_ACC
           np = (int)((acc0 >> 16) + (acc1 >> 16) + (acc2 >> 16) + (acc3 >> 16));
           kk = acc0 ? (int)(acc0 & 0xffffu) : (acc1 ? (int)(acc1 & 0xffffu) + 1 : (acc2 ? (int)(acc2 & 0xffffu) + 2 : (int)(acc3 & 0xffffu) + 3));  // (meaningful when np == 1)
 #endif
@@ -787,11 +739,7 @@ struct FrameState {
             int fneg = 0;
             for (int k = 0; k < Mi; k++) {
               const float2 v = make_float2(wx[k], wy[k]);
-#if MOCAP_WIDE_ACC == 3
-              const bool pass = (__float_as_uint(fmaf(a32, v.x, fmaf(b32, v.y, c32))) & 0x7fffff00u) <= (__float_as_uint(thr) | 0xffu);  // the keys' test
-#else
               const bool pass = fabsf(fmaf(a32, v.x, fmaf(b32, v.y, c32))) <= thr;
-#endif
               if (!pass && div_by(fabs(la * (double)v.x + lb * (double)v.y + lc), lden, lrden) < p.gate_px) fneg++;
             }
             atomicAdd(&p.status[p.n_frames], 1);
@@ -808,7 +756,6 @@ struct FrameState {
             }
           }
           unsigned long long multi = __ballot(have && np >= 2);
-          if (MOCAP_WIDE_DEBUG_SKIP & 16) multi = 0;
           if (multi) {  // rare: roots with several candidates, one at a time, the camera's blobs four per lane
             float2 bl[4];
             bool pc[4];
@@ -1140,6 +1087,53 @@ struct FrameState {
     return true;
   }
 
+  // The unclaimed blobs of camera j become roots n_roots .., in blob order (helpers.py:402-406; wave 0 compacts), with their
+  // rows up to their own camera.  Returns the new number of roots.  All lanes; synchronised on entry, not on exit (the rows'
+  // bytes for the cameras after j belong to the matching pass that follows).
+  __device__ int create_roots(int j, int n_roots) {
+    const int MW = (M + 63) / 64;
+    if (tid < 64) {
+      const int Mj = cnt[j];
+      int base_root = n_roots;
+      for (int w = 0; w * 64 < Mj; w++) {
+        const int k = 64 * w + tid;
+        const unsigned long long cl = claimw[(size_t)j * MW + w];
+        const bool flag = k < Mj && !((cl >> tid) & 1ull);
+        const unsigned long long mask = __ballot(flag);
+        const int pos = __popcll(mask & ((1ull << tid) - 1ull));
+        if (flag) {
+          const int rr = base_root + pos;
+          if (rr < R) {
+            root_cam[rr] = (uint8_t)j;
+            root_blob[rr] = (uint16_t)k;
+            wsrow[rr] = (uint16_t)rr;
+          }
+        }
+        base_root += __popcll(mask);
+      }
+      if (tid == 0) {
+        if (base_root > R) {
+          misc[MI_STATUS] |= MOCAP_ST_ROOT_OVERFLOW_;
+          base_root = R;
+        }
+        misc[MI_NROOTS] = base_root;
+      }
+    }
+    __syncthreads();
+    const int now = misc[MI_NROOTS];
+    if (now > n_roots) {  // workgroup-uniform
+      // cameras up to the root's own (the pairs with the cameras after it are written by the matching pass, by other waves at
+      // the same time: the two must not touch the same bytes)
+      const int ncam = (MOCAP_WIDE_DEBUG_SKIP & 2) ? C : j + 1;
+      for (int idx = tid; idx < (now - n_roots) * ncam; idx += T) {
+        const int r = n_roots + idx / ncam, c = idx % ncam;
+        if (c == j) set_hit_code(r, j, 1);
+        h0[(size_t)r * C + c] = (uint8_t)root_blob[r];
+      }
+    }
+    return now;
+  }
+
   __device__ void match_wide(int64_t frame) {
     const int MW = (M + 63) / 64;
     {
@@ -1189,74 +1183,55 @@ struct FrameState {
       }
     }
     __syncthreads();
+    // The camera-0 roots meet camera 1 first (one batch per wave: everything else waits for it), camera 1's unclaimed blobs
+    // become roots, and BOTH sets meet cameras 2 .. C-1 in one pass, a lane per root: the dozen roots of camera 1 ride in the
+    // free lanes of the last batch instead of paying a chain step of their own (2.6 of 29 ms per 12 500 stress frames).
+    int n_roots = n0, n_tot = n0, n_main = n0;
+    bool pre1 = false;
 #if !(MOCAP_WIDE_DEBUG_SKIP & 1)
-    match_roots_wide<true>(0, n0, 1);
-#endif
+#pragma nounroll
+    for (int ph = 0; ph < 2; ph++) {
+      const int clo = 1 + ph, chi = ph ? C : (C < 2 ? C : 2), hi = ph ? n_main : n0;
+      if (clo < chi && hi > 0) match_roots_wide<true>(0, hi, clo, chi, ph == 0);
+      __syncthreads();
+      if (ph == 0 && C > 2 && MOCAP_WIDE_CAM1 && !(MOCAP_WIDE_DEBUG_SKIP & 2)) {
+        n_tot = create_roots(1, n0);
+        pre1 = true;
+        // ... unless they would open a new group of 256 lanes for a handful of roots: those meet their cameras as a chain step
+        n_main = n_tot;
+        if (n_tot > 256 && (n_tot & 255) < MOCAP_WIDE_CHAIN_T) n_main = n_tot - (n_tot & 255);
+      }
+    }
+#else
     __syncthreads();
-    int n_roots = n0;
+#endif
     bool spec_ok = MOCAP_WIDE_SPEC && !(MOCAP_WIDE_DEBUG_SKIP & 2) && p.wide != 2;
     for (int j = 1; j < C; j++) {
       // cameras j .. C-1 in one speculative pass as soon as few blobs are left unclaimed (spec_begin), else camera j alone
       int nP = -1;
-      if (spec_ok) {
-        nP = spec_begin(j, n_roots);
-        if (nP == 0) break;
-      }
+      if ((MOCAP_WIDE_DEBUG_SKIP & 32) && j == 2) break;
       int now = n_roots;
-      if (nP < 0) {
-        // unclaimed blobs of camera j become new roots, in blob order (helpers.py:402-406); wave 0 compacts
-        if (tid < 64) {
-          const int Mj = cnt[j];
-          int base_root = n_roots;
-          for (int w = 0; w * 64 < Mj; w++) {
-            const int k = 64 * w + tid;
-            const unsigned long long cl = claimw[(size_t)j * MW + w];
-            const bool flag = k < Mj && !((cl >> tid) & 1ull);
-            const unsigned long long mask = __ballot(flag);
-            const int pos = __popcll(mask & ((1ull << tid) - 1ull));
-            if (flag) {
-              const int rr = base_root + pos;
-              if (rr < R) {
-                root_cam[rr] = (uint8_t)j;
-                root_blob[rr] = (uint16_t)k;
-                wsrow[rr] = (uint16_t)rr;
-              }
-            }
-            base_root += __popcll(mask);
-          }
-          if (tid == 0) {
-            if (base_root > R) {
-              misc[MI_STATUS] |= MOCAP_ST_ROOT_OVERFLOW_;
-              base_root = R;
-            }
-            misc[MI_NROOTS] = base_root;
-          }
-        }
-        __syncthreads();
-        now = misc[MI_NROOTS];
-        if (now > n_roots) {  // workgroup-uniform
-          // cameras up to the root's own (the pairs with the cameras after it are written by match_pairs_wide below, by
-          // other waves at the same time: the two must not touch the same bytes)
-          const int ncam = (MOCAP_WIDE_DEBUG_SKIP & 2) ? C : j + 1;
-          for (int idx = tid; idx < (now - n_roots) * ncam; idx += T) {
-            const int r = n_roots + idx / ncam, c = idx % ncam;
-            if (c == j) set_hit_code(r, j, 1);
-            h0[(size_t)r * C + c] = (uint8_t)root_blob[r];
-          }
-        }
+      if (j == 1 && pre1) {
+        n_roots = n_main;  // camera 1's roots exist; those from n_main on have not met the cameras after it yet
+        now = n_tot;
       } else {
-        now = n_roots + nP;
+        if (spec_ok) {
+          nP = spec_begin(j, n_roots);
+          if (nP == 0) break;
+        }
+        now = nP < 0 ? create_roots(j, n_roots) : n_roots + nP;
       }
       if (now > n_roots) {  // workgroup-uniform
         if (j + 1 < C && !(MOCAP_WIDE_DEBUG_SKIP & 2)) {
           // few new roots (the usual chain step), or provisional ones: the blobs stay in registers and the roots are broadcast; many: one lane per root
           spec_base = nP > 0 ? n_roots : -1;
-          if (nP > 0 || now - n_roots < MOCAP_WIDE_CHAIN_T) match_pairs_wide(n_roots, now, j + 1); else match_roots_wide<false>(n_roots, now, j + 1);
+          if (nP > 0 || now - n_roots < MOCAP_WIDE_CHAIN_T) match_pairs_wide(n_roots, now, j + 1); else match_roots_wide<false>(n_roots, now, j + 1, C, false);
           spec_base = -1;
         }
         __syncthreads();
       }
       if (nP > 0) {
+        if (MOCAP_WIDE_DEBUG_SKIP & 64) break;
         if (spec_finish(nP, n_roots)) break;
         spec_ok = false;  // (rare: see spec_finish) camera j again, and the rest of the frame, sequentially
         j--;
