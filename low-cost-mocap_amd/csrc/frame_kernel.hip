@@ -68,9 +68,6 @@ namespace mocap {
 #ifndef MOCAP_WIDE_SPEC
 #define MOCAP_WIDE_SPEC 1  // wide frames: the rest of the chain over the cameras matched speculatively in one pass once few blobs are left unclaimed (0: camera by camera)
 #endif
-#ifndef MOCAP_SPLIT_CV
-#define MOCAP_SPLIT_CV 1
-#endif
 #ifndef MOCAP_WIDE_CAM1
 #define MOCAP_WIDE_CAM1 1  // wide frames: camera 1 first, its roots then ride with the camera-0 roots through cameras 2 .. C-1 (0: a chain step for them)
 #endif
@@ -157,29 +154,12 @@ struct FrameLayout {
 size_t frame_lds_bytes(int C, int M, int R, int T, int H, bool wide, bool table) { return FrameLayout(C, M, R, T, H, wide, table && !wide).lds_total; }
 size_t frame_ws_bytes(int C, int M, int R, int T, int H, bool wide, bool table) { return FrameLayout(C, M, R, T, H, wide, table && !wide).ws_total; }
 
-// The kernel arguments arrive through one s_load_dwordx16; a value that lives in a slice of those sixteen registers is spilled and
-// reloaded as the whole block (16 v_readlane per reload: the camera tables' pointers were reloaded that way inside the candidate
-// evaluation).  Passing each pointer through an empty asm makes it a 64-bit value of its own: two lanes per reload.
-template <class Tp>
-__device__ __forceinline__ Tp* own_sgprs(Tp* ptr) {
-  asm volatile("" : "+s"(ptr));
-  return ptr;
-}
-__device__ __forceinline__ CamView split_cam_view(const CamView& v) {
-  CamView c = v;
-  c.Pq = own_sgprs(v.Pq);
-  c.RT = own_sgprs(v.RT);
-  c.K4 = own_sgprs(v.K4);
-  c.F = own_sgprs(v.F);
-  return c;
-}
-
 // HEAVY (wide variant, re-submit pass only): roots over the candidate cap are exported to the heavy-root search instead of
 // flagging their frames -- a separate instantiation, so that the code does not weigh on the registers of the first pass
 template <int T, bool UNIFORM_K, bool F32R, bool WIDE, bool HEAVY = false>
 struct FrameState {
   const FrameArgs& p;
-  const CamView cv;  // a copy whose table pointers are scalar values of their own (split_cam_view), not slices of a 16-dword kernel-argument load
+  const CamView& cv;
   const int C, M, R, tid;
   int Hs;  // hit-list stride per (root, camera)
   double *line, *dist, *seg_e, *seg_x;
@@ -203,7 +183,7 @@ struct FrameState {
   int spec_base = -1;          // wide: first row of the provisional roots while they are matched speculatively (spec_begin / spec_finish), else -1
 
   __device__ FrameState(const FrameArgs& p_, unsigned char* smem)
-      : p(p_), cv(MOCAP_SPLIT_CV ? split_cam_view(p_.cv) : p_.cv), C(p_.cv.C), M(p_.M), R(p_.K_max), tid(threadIdx.x) {
+      : p(p_), cv(p_.cv), C(p_.cv.C), M(p_.M), R(p_.K_max), tid(threadIdx.x) {
     const FrameLayout L(C, M, R, T, p_.H, WIDE, TABLE);
     Hs = L.Hs;
     line = (double*)(smem + L.line);
