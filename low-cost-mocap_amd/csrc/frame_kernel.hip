@@ -780,68 +780,65 @@ struct FrameState {
   // (distance, index) order.
   __device__ void match_pairs_wide(int rlo, int rhi, int clo) {
     constexpr int W = T / 64;
+    // a wave visits cameras clo + wave, + W, ...: at most NV of them (C <= 64); a lane holds ONE (root, visit) pair of the
+    // sub-batch: root q = lane / NV of up to NQ roots, visit v = lane % NV.  (Round 6: before, every visit computed the lines
+    // of its camera for a batch of 64 roots -- two square roots and a division in double for the ONE or dozen roots of a chain
+    // step, eight times per wave; now all the sub-batch's lines, exact decisions and stores are one pass per wave.)
+    constexpr int VB = W >= 16 ? 2 : 3, NV = 1 << VB, NQ = 64 >> VB;
+    static_assert(W * NV >= 64, "a wave's visits cover every camera");
     const int lane = tid & 63, wave = tid >> 6;
     const int MW = (M + 63) / 64;
     const double om = (double)__int_as_float(misc[MI_OMAX]);
-    for (int i = clo + wave; i < C; i += W) {  // wave-uniform
-      const int Mi = cnt[i];
-      const float2* row = bxy + (size_t)i * M;
-      float2 bl[4];
-      bool ok[4];
-#pragma unroll
-      for (int sg = 0; sg < 4; sg++) {
-        const int k = 64 * sg + lane;
-        ok[sg] = k < Mi;
-        // slots beyond the camera's count hold +inf: the pre-test's |fl(a x + b y + c)| <= thr is false for them
-        // (inf or NaN), no separate validity test in the inner loop
-        bl[sg] = ok[sg] ? row[k] : make_float2(__int_as_float(0x7f800000), __int_as_float(0x7f800000));
+    const float finf = __int_as_float(0x7f800000);
+    const int ql = lane >> VB, vl = lane & (NV - 1);
+    const int il = clo + wave + W * vl;  // this lane's camera
+    for (int sb = rlo; sb < rhi; sb += NQ) {  // workgroup-uniform
+      const int r = sb + ql;
+      // (a root meets the cameras AFTER its own: always the case for the roots of a chain step -- they were created at
+      // camera clo - 1 -- and the test that matters for provisional roots, which come from many cameras)
+      const bool have = r < rhi && il < C && (int)root_cam[r < rhi ? r : rlo] < il;
+      const unsigned long long havem = __ballot(have);
+      if (!havem) continue;  // wave-uniform
+      double la = 0, lb = 0, lc = 0, lden = 1, lrden = 1;
+      if (have) {
+        // cv.computeCorrespondEpilines on a float32 point: double math, scale by 1/sqrt(a^2+b^2), float32 result
+        // (helpers.py:363-364)
+        const int rc = root_cam[r], rbl = root_blob[r];
+        epiline_wide(cv.F + 9 * ((size_t)rc * C + il), bxy[(size_t)rc * M + rbl], la, lb, lc, lden, lrden);
       }
-      for (int rb = rlo; rb < rhi; rb += 64) {
-        const int r = rb + lane;
-        // (a root meets the cameras AFTER its own: always the case for the roots of a chain step -- they were created at
-        // camera clo - 1 -- and the test that matters for provisional roots, which come from many cameras)
-        const bool have = r < rhi && (int)root_cam[r < rhi ? r : rlo] < i;
-        const unsigned long long havem = __ballot(have);
-        double la = 0, lb = 0, lc = 0, lden = 1, lrden = 1;
-        if (have) {
-          // cv.computeCorrespondEpilines on a float32 point: double math, scale by 1/sqrt(a^2+b^2), float32 result
-          // (helpers.py:363-364)
-          const int rc = root_cam[r], rbl = root_blob[r];
-          const double* Fm = cv.F + 9 * ((size_t)rc * C + i);
-          const float2 rp = bxy[(size_t)rc * M + rbl];
-          const double x = (double)rp.x, y = (double)rp.y;
-          double a = Fm[0] * x + Fm[1] * y + Fm[2];
-          double bb = Fm[3] * x + Fm[4] * y + Fm[5];
-          double c = Fm[6] * x + Fm[7] * y + Fm[8];
-          double nu = a * a + bb * bb;
-          nu = nu != 0.0 ? 1.0 / sqrt(nu) : 1.0;
-          a *= nu;
-          bb *= nu;
-          c *= nu;
-          if (F32R) {
-            a = (double)(float)a;
-            bb = (double)(float)bb;
-            c = (double)(float)c;
-          }
-          la = a;
-          lb = bb;
-          lc = c;
-          lden = sqrt(a * a + bb * bb);  // helpers.py:373 divides by it again
-          lrden = recip_refined(lden);
+      // pre-test threshold, rounded up; +inf (everything goes to the exact test) without the float32 line
+      const float a32 = (float)la, b32 = (float)lb, c32 = (float)lc;
+      float thr = finf;
+      if (F32R) thr = __double2float_ru(p.gate_px * lden * (1.0 + 1e-12) + (2.5 * 0x1p-24) * (2.0 * om + fabs(lc)) * (1.0 + 1e-6));
+      int my_nh = 0, my_k0 = 0;
+      // the usual outcome of a (root, camera) pair: ONE blob passes the pre-test (the marker's own blob).  It is handed
+      // to the lane that holds the pair's line (its coordinates travel, not the line), and the exact decision is
+      // taken for all the pairs at once after the visits.
+      float cand_x = 0.f, cand_y = 0.f;
+      int cand_k = -1;
+      for (int v = 0; v < NV; v++) {  // wave-uniform: the wave's v-th camera
+        const int i = clo + wave + W * v;
+        if (i >= C) break;
+        unsigned long long vm = 0ull;  // lanes of visit v: bits v, v + NV, ...
+#pragma unroll
+        for (int t = 0; t < NQ; t++) vm |= 1ull << (t * NV);
+        unsigned long long m = havem & (vm << v);
+        if (!m) continue;
+        const int Mi = cnt[i];
+        const float2* row = bxy + (size_t)i * M;
+        float2 bl[4];
+        bool ok[4];
+#pragma unroll
+        for (int sg = 0; sg < 4; sg++) {
+          const int k = 64 * sg + lane;
+          ok[sg] = k < Mi;
+          // slots beyond the camera's count hold +inf: the pre-test's |fl(a x + b y + c)| <= thr is false for them
+          // (inf or NaN), no separate validity test in the inner loop
+          bl[sg] = ok[sg] ? row[k] : make_float2(finf, finf);
         }
-        // pre-test threshold, rounded up; +inf (everything goes to the exact test) without the float32 line
-        const float a32 = (float)la, b32 = (float)lb, c32 = (float)lc;
-        float thr = __int_as_float(0x7f800000);
-        if (F32R) thr = __double2float_ru(p.gate_px * lden * (1.0 + 1e-12) + (2.5 * 0x1p-24) * (2.0 * om + fabs(lc)) * (1.0 + 1e-6));
-        int my_nh = 0, my_k0 = 0;
-        // the usual outcome of a (root, camera) pair: ONE blob passes the pre-test (the marker's own blob).  It is handed
-        // to the lane that holds the root's line (its coordinates travel, not the line), and the exact decision is
-        // taken for the batch's 64 roots at once after the loop.
-        float cand_x = 0.f, cand_y = 0.f;
-        int cand_k = -1;
-        const int nb = rhi - rb < 64 ? rhi - rb : 64;
-        for (int q = 0; q < nb; q++) {  // wave-uniform: root rb + q against the camera's blobs
-          if (!((havem >> q) & 1ull)) continue;
+        while (m) {  // wave-uniform: the pair held by lane q against the camera's blobs
+          const int q = __ffsll((long long)m) - 1;
+          m &= m - 1;
           const float fa = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a32), q));
           const float fb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b32), q));
           const float fc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c32), q));
@@ -856,8 +853,8 @@ struct FrameState {
           }
 #ifdef MOCAP_DEBUG_PRETEST  // self-check build: the exact decision (helpers.py:373,375) for EVERY blob the float32 pre-test
           {                    // rejected; a blob inside the gate among them is a false negative (must never happen)
-            auto bc = [&](double v) {
-              const long long bits = __double_as_longlong(v);
+            auto bc = [&](double v_) {
+              const long long bits = __double_as_longlong(v_);
               return __longlong_as_double(((long long)__builtin_amdgcn_readlane((int)(bits >> 32), q) << 32) |
                                           (unsigned int)__builtin_amdgcn_readlane((int)bits, q));
             };
@@ -909,20 +906,20 @@ struct FrameState {
             bool pc[4];
 #pragma unroll
             for (int sg = 0; sg < 4; sg++) pc[sg] = pm[sg] && ok[sg];
-            resolve_pair(q, rb + q, i, bl, pc, la, lb, lc, lden, lrden, my_nh, my_k0);
+            resolve_pair(q, sb + (q >> VB), i, bl, pc, la, lb, lc, lden, lrden, my_nh, my_k0);
           }
         }
-        if (cand_k >= 0) {  // single candidates: helpers.py:373 in double, strict < (helpers.py:375,383); a lone hit claims itself
-          if (div_by(fabs(la * (double)cand_x + lb * (double)cand_y + lc), lden, lrden) < p.gate_px) {
-            if (spec_base < 0) atomicOr(&claimw[(size_t)i * MW + (cand_k >> 6)], 1ull << (cand_k & 63));
-            my_nh = 1;
-            my_k0 = cand_k;
-          }
+      }
+      if (cand_k >= 0) {  // single candidates: helpers.py:373 in double, strict < (helpers.py:375,383); a lone hit claims itself
+        if (div_by(fabs(la * (double)cand_x + lb * (double)cand_y + lc), lden, lrden) < p.gate_px) {
+          if (spec_base < 0) atomicOr(&claimw[(size_t)il * MW + (cand_k >> 6)], 1ull << (cand_k & 63));
+          my_nh = 1;
+          my_k0 = cand_k;
         }
-        if (have) {
-          h0[(size_t)r * C + i] = (uint8_t)my_k0;
-          set_hit_code(r, i, my_nh);
-        }
+      }
+      if (have) {
+        h0[(size_t)r * C + il] = (uint8_t)my_k0;
+        set_hit_code(r, il, my_nh);
       }
     }
   }
