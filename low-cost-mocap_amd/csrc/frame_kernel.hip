@@ -156,6 +156,8 @@ size_t frame_ws_bytes(int C, int M, int R, int T, int H, bool wide, bool table) 
 
 // HEAVY (wide variant, re-submit pass only): roots over the candidate cap are exported to the heavy-root search instead of
 // flagging their frames -- a separate instantiation, so that the code does not weigh on the registers of the first pass
+// Every phase below is __forceinline__: the frame kernels are ONE body per instantiation.  (Round 6: a self-check build had
+// write_point outlined as a real function -- calls, a stack in scratch, and a barrier the ISA test could no longer prove safe.)
 template <int T, bool UNIFORM_K, bool F32R, bool WIDE, bool HEAVY = false>
 struct FrameState {
   const FrameArgs& p;
@@ -247,7 +249,7 @@ struct FrameState {
   // ---------------------------------------------------------------- phases A-C
   // Leaves roots / hit lists / candidate offsets in LDS; returns with all lanes synchronised.  (Narrow frames; wide
   // frames take match_wide.)
-  __device__ void match(int64_t frame, int skip = 0 /* timing experiments: 1 = no table build, 2 = no camera loop */) {
+  __device__ __forceinline__ void match(int64_t frame, int skip = 0 /* timing experiments: 1 = no table build, 2 = no camera loop */) {
     {
       const float2* src = (const float2*)(p.blobs + (size_t)frame * C * M * 2);
       for (int i = tid; i < C * M; i += T) bxy[i] = src[i];
@@ -599,7 +601,7 @@ struct FrameState {
   // lane).  Cameras [clo, chi): a wave takes every (T / 64)-th; `split`: every wave of the first four takes EVERY camera and
   // one batch of each group instead (the call for camera 1 alone, on which everything after it waits).
   template <bool CAM01>
-  __device__ void match_roots_wide(int rlo, int rhi, int clo, int chi, bool split) {
+  __device__ __forceinline__ void match_roots_wide(int rlo, int rhi, int clo, int chi, bool split) {
     constexpr int W = T / 64;
     const int lane = tid & 63, wave = tid >> 6;
     if (split && wave >= 4) return;  // (no workgroup barrier inside)
@@ -778,7 +780,7 @@ struct FrameState {
   // multiply-adds round; omax = largest coordinate of the frame), and whatever passes is decided by the exact double
   // expression of helpers.py:373.  The rare hits go through a 64-entry list of the wave in LDS and come out in
   // (distance, index) order.
-  __device__ void match_pairs_wide(int rlo, int rhi, int clo) {
+  __device__ __forceinline__ void match_pairs_wide(int rlo, int rhi, int clo) {
     constexpr int W = T / 64;
     // a wave visits cameras clo + wave, + W, ...: at most NV of them (C <= 64); a lane holds ONE (root, visit) pair of the
     // sub-batch: root q = lane / NV of up to NQ roots, visit v = lane % NV.  (Round 6: before, every visit computed the lines
@@ -938,7 +940,7 @@ struct FrameState {
   // are more than MOCAP_WIDE_SPEC_T provisional roots or no rows for them, or when a hit list holds a second blob with the closest hit's coordinates
   // (claimed with it by value: not replayable from the closest hit alone).  All lanes; synchronised on entry and exit.
   // spec_begin: the provisional roots and their rows; returns their number, 0 (no blob left unclaimed: the chain is complete) or -1.
-  __device__ int spec_begin(int jlo, int n_roots) {
+  __device__ __forceinline__ int spec_begin(int jlo, int n_roots) {
     const int MW = (M + 63) / 64, lane = tid & 63;
     if (tid < 64) {
       int u = 0;
@@ -989,7 +991,7 @@ struct FrameState {
   }
   // spec_finish: after the provisional roots [n_roots, n_roots + nP) have met their cameras (match_pairs_wide with spec_base set)
   // and a barrier.  True: the chain is complete, n_roots updated.  False: rows clean, the sequential chain takes over.
-  __device__ bool spec_finish(int nP, int& n_roots) {
+  __device__ __forceinline__ bool spec_finish(int nP, int& n_roots) {
     const int MW = (M + 63) / 64, lane = tid & 63;
     if (misc[MI_SPEC_N]) {  // workgroup-uniform: the sequential chain starts over from camera jlo with clean rows
       for (int q = tid; q < 2 * nP; q += T) nhc[2 * (size_t)n_roots + q] = 0ull;
@@ -1067,7 +1069,7 @@ struct FrameState {
   // The unclaimed blobs of camera j become roots n_roots .., in blob order (helpers.py:402-406; wave 0 compacts), with their
   // rows up to their own camera.  Returns the new number of roots.  All lanes; synchronised on entry, not on exit (the rows'
   // bytes for the cameras after j belong to the matching pass that follows).
-  __device__ int create_roots(int j, int n_roots) {
+  __device__ __forceinline__ int create_roots(int j, int n_roots) {
     const int MW = (M + 63) / 64;
     if (tid < 64) {
       const int Mj = cnt[j];
@@ -1111,7 +1113,7 @@ struct FrameState {
     return now;
   }
 
-  __device__ void match_wide(int64_t frame) {
+  __device__ __forceinline__ void match_wide(int64_t frame) {
     const int MW = (M + 63) / 64;
     {
       bxy = const_cast<float2*>((const float2*)(p.blobs + (size_t)frame * C * M * 2));  // read in place, never written
@@ -1224,7 +1226,7 @@ struct FrameState {
 
   // Heavy roots (FrameArgs::heavy_bb): the root's hit counts and hit lists leave for the heavy-root search (csrc/heavy_bb.hip).
   // All lanes; the workgroup is synchronised on entry and on exit.
-  __device__ void export_heavy(int64_t frame) {
+  __device__ __forceinline__ void export_heavy(int64_t frame) {
     const int nhv = misc[MI_HEAVY_N] < kMaxHeavyPerFrame ? misc[MI_HEAVY_N] : kMaxHeavyPerFrame;
     for (int h = 0; h < nhv; h++) {
       const int r = misc[MI_HEAVY_R0 + h];
@@ -1262,7 +1264,7 @@ struct FrameState {
   }
 
   // C: candidate counts per root (all lanes; the roots and hit lists are in place and the workgroup is synchronised)
-  __device__ void count_candidates() {
+  __device__ __forceinline__ void count_candidates() {
     const int nroots = misc[MI_NROOTS];
     for (int r = tid; r < nroots; r += T) {
       const int rc = root_cam[r];
@@ -1386,7 +1388,7 @@ struct FrameState {
   }
 
   // Evaluate candidates [g_lo, g_hi); per (lane, root) segment winners land in seg_* .
-  __device__ void evaluate(uint32_t g_lo, uint32_t g_hi) {
+  __device__ __forceinline__ void evaluate(uint32_t g_lo, uint32_t g_hi) {
     const int nroots = misc[MI_NROOTS];
     const uint32_t q = (g_hi - g_lo + T - 1) / T;
     uint32_t g = g_lo + (uint32_t)tid * q;
@@ -1582,7 +1584,7 @@ struct FrameState {
 
   // first minimum over the (lane, root) segments of root r inside [g_lo, g_hi); false if the
   // root has no candidate in the range
-  __device__ bool root_winner(int r, uint32_t g_lo, uint32_t g_hi, double& eb, uint32_t& gb, double (&Xb)[3]) {
+  __device__ __forceinline__ bool root_winner(int r, uint32_t g_lo, uint32_t g_hi, double& eb, uint32_t& gb, double (&Xb)[3]) {
     const uint32_t a = goff[r] > g_lo ? goff[r] : g_lo;
     const uint32_t b = goff[r + 1] < g_hi ? goff[r + 1] : g_hi;
     if (a >= b) return false;
@@ -1607,7 +1609,7 @@ struct FrameState {
   }
 
   // ---------------------------------------------------------------- phase E
-  __device__ void write_point(int64_t frame, int r, double e, uint32_t gl, const double (&X)[3]) {
+  __device__ __forceinline__ void write_point(int64_t frame, int r, double e, uint32_t gl, const double (&X)[3]) {
     const size_t o = (size_t)frame * R + outslot[r];
     store_point(p, o, X);  // incl. the fused world-coordinate epilogue (helpers.py:96-103)
     p.err[o] = e;
@@ -1631,7 +1633,7 @@ struct FrameState {
     }
   }
 
-  __device__ void write_frame_header(int64_t frame) {
+  __device__ __forceinline__ void write_frame_header(int64_t frame) {
     if (tid == 0) {
       const int status = misc[MI_STATUS];
       p.n_out[frame] = status ? 0 : misc[MI_NOUT];
