@@ -151,8 +151,10 @@ struct FrameLayout {
   }
 };
 
+#ifndef MOCAP_FRAME_TU_WIDE
 size_t frame_lds_bytes(int C, int M, int R, int T, int H, bool wide, bool table) { return FrameLayout(C, M, R, T, H, wide, table && !wide).lds_total; }
 size_t frame_ws_bytes(int C, int M, int R, int T, int H, bool wide, bool table) { return FrameLayout(C, M, R, T, H, wide, table && !wide).ws_total; }
+#endif
 
 // HEAVY (wide variant, re-submit pass only): roots over the candidate cap are exported to the heavy-root search instead of
 // flagging their frames -- a separate instantiation, so that the code does not weigh on the registers of the first pass
@@ -1979,13 +1981,21 @@ static hipError_t launch_T(const FrameArgs& a, int mode, int grid, size_t lds, h
   }
 }
 
+// The wide variant's instantiations are a translation unit of their own (csrc/frame_kernel_wide.hip = this file with
+// MOCAP_FRAME_TU_WIDE defined): its 1 400-line kernel body is compiled with scheduler / allocator options that cost the one-wave
+// kernels of small frames 4 % (Makefile: FRAME_WIDE_FLAGS; 28.0 -> 27.0 ms per 12 500 stress frames).
+#ifdef MOCAP_FRAME_TU_WIDE
+hipError_t launch_frame_kernel_wide(const FrameArgs& a, int mode, int threads, int grid, size_t lds, hipStream_t stream) {
+  if (threads == kWideThreads) return launch_T<kWideThreads, true>(a, mode, grid, lds, stream);
+  if (threads == 512 && mode == MODE_ALL) return launch_TM<512, true, MODE_ALL>(a, grid, lds, stream);  // two frames per CU (capi.hip plan_frame)
+  return hipErrorInvalidValue;
+}
+#else
+hipError_t launch_frame_kernel_wide(const FrameArgs& a, int mode, int threads, int grid, size_t lds, hipStream_t stream);
+
 hipError_t launch_frame_kernel(const FrameArgs& a, int mode, int threads, int grid, hipStream_t stream) {
   const size_t lds = frame_lds_bytes(a.cv.C, a.M, a.K_max, threads, a.H, a.wide != 0, a.cv.uniformK != 0);
-  if (a.wide) {
-    if (threads == kWideThreads) return launch_T<kWideThreads, true>(a, mode, grid, lds, stream);
-    if (threads == 512 && mode == MODE_ALL) return launch_TM<512, true, MODE_ALL>(a, grid, lds, stream);  // two frames per CU (capi.hip plan_frame)
-    return hipErrorInvalidValue;
-  }
+  if (a.wide) return launch_frame_kernel_wide(a, mode, threads, grid, lds, stream);
   switch (threads) {
     case 64: return launch_T<64, false>(a, mode, grid, lds, stream);
     case 128: return launch_T<128, false>(a, mode, grid, lds, stream);
@@ -1993,5 +2003,6 @@ hipError_t launch_frame_kernel(const FrameArgs& a, int mode, int threads, int gr
     default: return hipErrorInvalidValue;
   }
 }
+#endif
 
 }  // namespace mocap

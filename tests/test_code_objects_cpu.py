@@ -71,10 +71,10 @@ def test_wide_kernel_budget(kernels):
     HBM workspace (57 spilled VGPRs, 164 B of scratch then); a change that pushes the spills back up shows here first."""
     k = _find(kernels, "frame_kernelILi1024ELb1ELb1ELb1ELi3ELb0E")   # (...Lb1E: the re-submit pass's instantiation, below)
     assert k["vgpr_count"] <= 128, k
-    assert k["vgpr_spill_count"] <= 60 and k["private_segment_fixed_size"] <= 232, k   # (round 6: 58 with the hit masks)
+    assert k["vgpr_spill_count"] <= 66 and k["private_segment_fixed_size"] <= 232, k   # (round 6: 58 with the hit masks; 62 under FRAME_WIDE_FLAGS, which trade four more spills for a schedule that is 1 ms per 12 500 stress frames faster)
     # round 6: the instantiation the stress shape takes now -- 512 lanes per frame, two frames per CU (same budget: 16 waves per CU)
     k5 = _find(kernels, "frame_kernelILi512ELb1ELb1ELb1ELi3ELb0E")
-    assert k5["vgpr_count"] <= 128 and k5["vgpr_spill_count"] <= 60, k5
+    assert k5["vgpr_count"] <= 128 and k5["vgpr_spill_count"] <= 66, k5
     # round 5: the export of heavy roots (csrc/heavy_bb.hip) lives in an instantiation of its own -- it must not cost the
     # first pass a register
     heavy = _find(kernels, "frame_kernelILi1024ELb1ELb1ELb1ELi3ELb1E")

@@ -248,7 +248,9 @@ def test_frame_calls_stay_fast_while_a_calibration_runs(core):
         th.join()
     finally:
         sys.setswitchinterval(old)
-    assert result["solves"] >= 2 and len(lat) > 100, (result, len(lat))       # the calibrations really overlapped
+    # the calibrations really overlapped (one solve is 0.1-0.2 s on a quiet host; on a bench box whose host cores are shared --
+    # round 6 -- a single solve has been seen to take the whole second: the frame calls still ran THROUGH it, which is the point)
+    assert result["solves"] >= 1 and len(lat) > 100, (result, len(lat))
     lat = np.sort(np.array(lat)) * 1e3
     p50, p90, p99 = lat[len(lat) // 2], lat[int(len(lat) * 0.90)], lat[int(len(lat) * 0.99)]
     print(f"frame calls during calibrations: n {len(lat)} p50 {p50:.3f} ms p90 {p90:.3f} p99 {p99:.3f} ms max {lat[-1]:.3f} ms; "
