@@ -651,7 +651,10 @@ static int match_dev_locked(mocap_ctx* ctx, int64_t n_frames, int M_max, const f
   const bool batch = n_frames >= 2 * full_grid;
   FrameQueues& q = a.q;
   q.heavy_threshold = ctx->heavy_threshold >= 0 ? (uint32_t)ctx->heavy_threshold : (batch ? 32768u : 16u * T);  // batch: swept under the single-launch schedule (16 k: 13.45, 24-32 k: 13.32, 48 k: 13.50, 64 k: 13.72 ms per 100 k frames); live calls: swept, p50 0.129 -> 0.117 ms vs 2T, same p99
-  q.slice_size = ctx->slice_size > 0 ? (uint32_t)ctx->slice_size : (batch ? 8192u : 4u * T);
+  // (wide frames: every slice re-does the frame's matching, ~2/3 of an average frame's time, so the slices are three times as long --
+  // swept at the stress shape on two streams, scripts/gpu_r06_t.sh: 8 192 -> 24 576 candidates: 26.97 -> 25.65 and 24.82 -> 24.56 ms per
+  // 12 500 frames; 16 384 / 20 480 / 28 672 / 32 768 in between or worse, 65 536: 30.5)
+  q.slice_size = ctx->slice_size > 0 ? (uint32_t)ctx->slice_size : (batch ? (wide ? 24576u : 8192u) : 4u * T);
   if (a.heavy_bb) q.heavy_threshold = 0;  // (a sliced frame would be matched, and its heavy roots exported, once per slice)
   // small frames: amortise the queue atomic over a chunk (keeps >= 64 chunks per workgroup for balance);
   // frames with real work keep the finest granularity, their candidate counts are heavy-tailed
@@ -858,8 +861,10 @@ static int resubmit_dev_locked(mocap_ctx* ctx, int64_t n_frames, int M_max, cons
   }
   HIP_TRY(ctx, launch_resubmit_gather(ra, ctx->stream));
   ctx->resub_calls++;
+  const char* batch_kernel = ctx->last_frame_kernel;  // mocap_last_frame_kernel() keeps naming the pass that did the batch, not the repair of its flagged frames
   const int rc = match_dev_locked(ctx, cap, M_max, ra.b2, ra.c2, gate_px, K_big, G2, x2, e2, r2, n2, s2, g2,
                                   /*hit_cap_override=*/M_max, /*n_frames_dev=*/ra.count, heavy_ok ? &hk : nullptr);
+  if (std::strcmp(batch_kernel, "none") != 0) ctx->last_frame_kernel = batch_kernel;
   if (rc) return rc;
   if (heavy_ok) {
     HeavyArgs ha;

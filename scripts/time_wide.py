@@ -7,11 +7,12 @@ F = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 C, M, K = 64, 256, int(os.environ.get("TW_K", "384"))
 rig = synth.stress_rig(C)
-cache = f"/tmp/stress_{F}.npz"
+SEED = int(os.environ.get("TW_SEED", "1"))
+cache = f"/tmp/stress_{F}_{SEED}.npz"
 if os.path.exists(cache):
     z = np.load(cache); blobs, counts = z["b"], z["c"]
 else:
-    blobs, counts, _ = synth.make_stress_stream_chunked(rig, F, M, seed=1)   # (bench.py's stream since round 6)
+    blobs, counts, _ = synth.make_stress_stream_chunked(rig, F, M, seed=SEED)   # (bench.py's stream since round 6)
     np.savez(cache, b=blobs, c=counts)
 dev = torch.device("cuda:0")
 core = capi.MocapCore(0)
