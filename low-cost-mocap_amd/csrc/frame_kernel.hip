@@ -68,6 +68,9 @@ namespace mocap {
 #ifndef MOCAP_WIDE_SPEC
 #define MOCAP_WIDE_SPEC 1  // wide frames: the rest of the chain over the cameras matched speculatively in one pass once few blobs are left unclaimed (0: camera by camera)
 #endif
+#ifndef MOCAP_WIDE_PAIR2
+#define MOCAP_WIDE_PAIR2 1  // wide frames: a (root, camera) pair with two candidates at different positions of a step is decided by its own lane
+#endif
 #ifndef MOCAP_WIDE_CAM1
 #define MOCAP_WIDE_CAM1 1  // wide frames: camera 1 first, its roots then ride with the camera-0 roots through cameras 2 .. C-1 (0: a chain step for them)
 #endif
@@ -739,7 +742,45 @@ struct FrameState {
               my_k0 = kk;
             }
           }
-          unsigned long long multi = __ballot(have && np >= 2);
+          // Two candidates at different positions of a step (three quarters of the pairs with several candidates: ~300 such pairs
+          // per stress frame, one in most (batch, camera) rounds): each accumulator holds ONE index, so the pair is decided right
+          // here, for all such lanes at once -- both distances in double (helpers.py:373), strict gate (helpers.py:375,383), the hits
+          // in (distance, index) order, the closest claims by value (helpers.py:391) -- exactly resolve_pair's outcome without its
+          // wave-serial round (broadcast of the line, distances of all 256 blobs, ranking by broadcast: ~250 instructions per pair).
+          bool two = false;
+#if MOCAP_WIDE_ACC && MOCAP_WIDE_PAIR2
+          two = have && np == 2 && p.H >= 2 && ((acc0 | acc1 | acc2 | acc3) >> 17) == 0u;  // (no accumulator counts two)
+          if (__ballot(two)) {  // wave-uniform
+            if (two) {
+              const int c0 = (int)(acc0 >> 16), c1 = (int)(acc1 >> 16), c2 = (int)(acc2 >> 16), c3 = (int)(acc3 >> 16);
+              const int k0c = (int)(acc0 & 0xffffu), k1c = (int)(acc1 & 0xffffu) + 1, k2c = (int)(acc2 & 0xffffu) + 2, k3c = (int)(acc3 & 0xffffu) + 3;
+              const int lo = c0 ? k0c : (c1 ? k1c : k2c), hi = c3 ? k3c : (c2 ? k2c : k1c);  // the lowest / highest position that counted
+              const int kA = lo < hi ? lo : hi, kB = lo < hi ? hi : lo;                      // by blob index
+              const float2 vA = make_float2(wx[kA], wy[kA]), vB = make_float2(wx[kB], wy[kB]);
+              const double dA = div_by(fabs(la * (double)vA.x + lb * (double)vA.y + lc), lden, lrden);
+              const double dB = div_by(fabs(la * (double)vB.x + lb * (double)vB.y + lc), lden, lrden);
+              const bool hitA = kA < Mi && dA < p.gate_px, hitB = kB < Mi && dB < p.gate_px;
+              if (hitA && hitB) {
+                const bool bfirst = dB < dA;  // equal distances: the lower blob index first (stable order, see resolve_pair)
+                const int k1 = bfirst ? kB : kA, k2 = bfirst ? kA : kB;
+                uint8_t* hl = hits + ((size_t)r * C + i) * Hs;
+                hl[0] = (uint8_t)k1;
+                hl[1] = (uint8_t)k2;
+                nh[(size_t)r * C + i] = (uint16_t)2;  // the exact count (the LDS code only says "several")
+                atomicOr(&claimw[(size_t)i * MW + (k1 >> 6)], 1ull << (k1 & 63));
+                if (vA.x == vB.x && vA.y == vB.y) atomicOr(&claimw[(size_t)i * MW + (k2 >> 6)], 1ull << (k2 & 63));  // the same coordinates: claimed with it
+                my_nh = 2;
+                my_k0 = k1;
+              } else if (hitA || hitB) {  // one blob inside the gate after all: it is the closest hit and claims itself
+                const int k1 = hitA ? kA : kB;
+                atomicOr(&claimw[(size_t)i * MW + (k1 >> 6)], 1ull << (k1 & 63));
+                my_nh = 1;
+                my_k0 = k1;
+              }
+            }
+          }
+#endif
+          unsigned long long multi = __ballot(have && np >= 2 && !two);
           if (multi) {  // rare: roots with several candidates, one at a time, the camera's blobs four per lane
             float2 bl[4];
             bool pc[4];
