@@ -159,6 +159,40 @@ size_t frame_lds_bytes(int C, int M, int R, int T, int H, bool wide, bool table)
 size_t frame_ws_bytes(int C, int M, int R, int T, int H, bool wide, bool table) { return FrameLayout(C, M, R, T, H, wide, table && !wide).ws_total; }
 #endif
 
+// The kernel arguments arrive through one s_load_dwordx16; a value that lives in a slice of those sixteen registers is spilled and
+// reloaded as the whole block (16 v_readlane per reload: the camera tables' pointers were reloaded that way inside the candidate
+// evaluation of the wide variant, at 17 places of its loops).  own_sgprs makes each pointer a 64-bit scalar value of its own.
+// (wide variant only: 25.4 -> 24.1 ms per 12 500 stress frames; the one-wave kernels of small frames measure the same either way)
+#ifndef MOCAP_SPLIT_CV
+#ifdef MOCAP_FRAME_TU_WIDE
+#define MOCAP_SPLIT_CV 1
+#else
+#define MOCAP_SPLIT_CV 0
+#endif
+#endif
+__device__ __forceinline__ uint32_t opaque_v(uint32_t x) {
+  uint32_t r;
+  asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "s"(x));
+  return r;
+}
+template <class Tp>
+__device__ __forceinline__ Tp* own_sgprs(Tp* ptr) {
+  // through a vector register and back: a scalar value DEFINED by v_readfirstlane (an empty asm is a copy the register coalescer
+  // folds back into the slice of the block)
+  const unsigned long long u = (unsigned long long)(uintptr_t)ptr;
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)opaque_v((uint32_t)u));
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)opaque_v((uint32_t)(u >> 32)));
+  return (Tp*)(uintptr_t)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ CamView split_cam_view(const CamView& v) {
+  CamView c = v;
+  c.Pq = own_sgprs(v.Pq);
+  c.RT = own_sgprs(v.RT);
+  c.K4 = own_sgprs(v.K4);
+  c.F = own_sgprs(v.F);
+  return c;
+}
+
 // HEAVY (wide variant, re-submit pass only): roots over the candidate cap are exported to the heavy-root search instead of
 // flagging their frames -- a separate instantiation, so that the code does not weigh on the registers of the first pass
 // Every phase below is __forceinline__: the frame kernels are ONE body per instantiation.  (Round 6: a self-check build had
@@ -166,7 +200,11 @@ size_t frame_ws_bytes(int C, int M, int R, int T, int H, bool wide, bool table) 
 template <int T, bool UNIFORM_K, bool F32R, bool WIDE, bool HEAVY = false>
 struct FrameState {
   const FrameArgs& p;
+#if MOCAP_SPLIT_CV
+  const CamView cv;  // a copy whose table pointers are scalar values of their own (split_cam_view), not slices of the 16-dword kernel-argument load
+#else
   const CamView& cv;
+#endif
   const int C, M, R, tid;
   int Hs;  // hit-list stride per (root, camera)
   double *line, *dist, *seg_e, *seg_x;
@@ -190,7 +228,11 @@ struct FrameState {
   int spec_base = -1;          // wide: first row of the provisional roots while they are matched speculatively (spec_begin / spec_finish), else -1
 
   __device__ FrameState(const FrameArgs& p_, unsigned char* smem)
+#if MOCAP_SPLIT_CV
+      : p(p_), cv(split_cam_view(p_.cv)), C(p_.cv.C), M(p_.M), R(p_.K_max), tid(threadIdx.x) {
+#else
       : p(p_), cv(p_.cv), C(p_.cv.C), M(p_.M), R(p_.K_max), tid(threadIdx.x) {
+#endif
     const FrameLayout L(C, M, R, T, p_.H, WIDE, TABLE);
     Hs = L.Hs;
     line = (double*)(smem + L.line);
