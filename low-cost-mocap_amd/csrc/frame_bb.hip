@@ -192,6 +192,23 @@ struct BBCamTables<0> {
   __device__ __forceinline__ const double* f() const { return base + 28 * C; }
 };
 
+// Issue priority of the frame's phases (s_setprio: arbitration between the waves of one SIMD -- here the four frames
+// of a CU, each with one wave per SIMD, each in a phase of its own).  The candidate evaluation is the bulk of the work and
+// runs at 0; everything that holds the other waves of its workgroup at a barrier runs above it: the single-wave stretches
+// (chain bookkeeping, scans) at 3, the rest of the matching and the output at 2, the seed pass at 1.  A frame's serial
+// depth then costs what it costs alone, not what it costs sharing its SIMD's issue slots with three evaluations:
+// 4.70 -> 4.50 ms per 100 k frames of 8 x 16 (profiles/r06_wide_experiments.txt, (14); MOCAP_BB_PRIO=0: without).
+#ifndef MOCAP_BB_PRIO
+#define MOCAP_BB_PRIO 1
+#endif
+enum { kPrioEval = 0, kPrioSeed = 1, kPrioPhase = 2, kPrioSerial = 3 };
+template <int P>
+__device__ __forceinline__ void bb_prio() {
+#if MOCAP_BB_PRIO
+  __builtin_amdgcn_s_setprio(P);
+#endif
+}
+
 // ML, RL: the layout's blobs per camera and root slots when they are known at compile time (with CT: every LDS array
 // sits at a constant address, which takes the base registers, their spills to vector lanes and the address arithmetic
 // out of every phase -- 5.72 -> 5.39 ms per 100 k frames of 8 x 16), 0 = runtime.  ML is the frame's M_max itself (the
@@ -587,6 +604,7 @@ struct BBState {
       }
     }
     __syncthreads();
+    if (wave == 0) bb_prio<kPrioSerial>();
     if (wave == 0 && pre) {
       // B1, pre-matched: lane p <-> provisional root p = the p-th unclaimed blob of cameras 1 .. C-1 in (camera, blob) order.
       // A provisional root is real when no root created at an earlier camera claims its blob (helpers.py:391,402-406).
@@ -721,6 +739,7 @@ struct BBState {
         misc[MI_NEXT] = it < frame_count(p) ? it : -1;
       }
     }
+    bb_prio<kPrioPhase>();
     __syncthreads();
     if (pre) {
       // the real provisional roots' rows leave the staging area for their final place: one lane per (new root, camera)
@@ -785,6 +804,7 @@ struct BBState {
     }
     if (tid == 0) misc[MI_BBCTR] = misc[MI_BBCTR2] = 0;
     __syncthreads();
+    if (wave == 0) bb_prio<kPrioSerial>();
     if (wave == 0) {  // candidate offsets, block offsets and output slots: scans over the roots, 64 at a time (sums stay below 2^32: 255 x 2^24)
       uint32_t carry = 0, bcarry = 0;
       int slots = 0;
@@ -811,6 +831,7 @@ struct BBState {
         misc[MI_G] = misc[MI_STATUS] ? 0 : (int32_t)carry;
       }
     }
+    bb_prio<kPrioPhase>();
     __syncthreads();
   }
 
@@ -942,6 +963,7 @@ struct BBState {
       return s1 * fma(2e-12, tr, p.p3max2c * limit_adj) < 1.0;
     };
     if (bound_tests) {
+      bb_prio<kPrioSeed>();
       // ---- 1. seeds: s1 of every block (cached for the tests); per root the block with the largest s1 (smallest
       // bound) almost always holds the winner
       // (a frame of at most T blocks -- the usual one -- takes one trip through this loop: the lane that turns out to hold its
@@ -996,6 +1018,7 @@ struct BBState {
           push_block(r, gh, pk);
         }
       }
+      bb_prio<kPrioEval>();
       __syncthreads();
     }
     // ---- 2. the queued records' candidates (spread over all lanes, whatever root they belong to), then the next
@@ -1232,8 +1255,10 @@ __global__ __launch_bounds__(kBBThreads, MOCAP_BB_WAVES_PER_EU) void frame_bb_ke
   __syncthreads();
   while (item >= 0) {
     const int64_t frame = item;
+    bb_prio<kPrioPhase>();
     st.stage(frame);
     st.match();
+    bb_prio<kPrioEval>();
     const int next = st.misc[MI_NEXT];
     if (next >= 0) st.prefetch_lds(next);  // in flight during the search
     if (tid == 0) {
@@ -1247,6 +1272,7 @@ __global__ __launch_bounds__(kBBThreads, MOCAP_BB_WAVES_PER_EU) void frame_bb_ke
       // the bound tests pay their fixed cost (seed pass + a test per block) only on frames with enough candidates;
       // smaller frames queue every block -- same evaluation rounds, same result
       st.search(G >= (uint32_t)p.bb_min_g);
+      bb_prio<kPrioPhase>();
       const int nroots = st.misc[MI_NROOTS];
       for (int r = tid; r < nroots; r += kBBThreads) {
         if (st.outslot[r] < 0) continue;
@@ -1256,6 +1282,7 @@ __global__ __launch_bounds__(kBBThreads, MOCAP_BB_WAVES_PER_EU) void frame_bb_ke
       }
     }
     wait_own_stores();  // ... and loads: the next frame's blobs are in LDS
+    bb_prio<kPrioEval>();
     __syncthreads();  // the frame's LDS state is dead: the next one may be staged
     item = next;
   }

@@ -197,6 +197,28 @@ __device__ __forceinline__ CamView split_cam_view(const CamView& v) {
 // flagging their frames -- a separate instantiation, so that the code does not weigh on the registers of the first pass
 // Every phase below is __forceinline__: the frame kernels are ONE body per instantiation.  (Round 6: a self-check build had
 // write_point outlined as a real function -- calls, a stack in scratch, and a barrier the ISA test could no longer prove safe.)
+#ifndef MOCAP_FRAME_PRIO_MATCH
+#define MOCAP_FRAME_PRIO_MATCH 0
+#endif
+#ifndef MOCAP_FRAME_PRIO_CHAIN
+#define MOCAP_FRAME_PRIO_CHAIN 0
+#endif
+#ifndef MOCAP_FRAME_PRIO_SERIAL
+#define MOCAP_FRAME_PRIO_SERIAL MOCAP_FRAME_PRIO_CHAIN
+#endif
+#ifndef MOCAP_FRAME_PRIO_EVAL
+#define MOCAP_FRAME_PRIO_EVAL 0
+#endif
+#ifndef MOCAP_FRAME_PRIO_OUT
+#define MOCAP_FRAME_PRIO_OUT 0
+#endif
+#define MOCAP_FRAME_PRIO_ANY (MOCAP_FRAME_PRIO_MATCH | MOCAP_FRAME_PRIO_CHAIN | MOCAP_FRAME_PRIO_EVAL | MOCAP_FRAME_PRIO_OUT)
+template <int P>
+__device__ __forceinline__ void frame_prio() {
+#if MOCAP_FRAME_PRIO_ANY
+  __builtin_amdgcn_s_setprio(P);
+#endif
+}
 template <int T, bool UNIFORM_K, bool F32R, bool WIDE, bool HEAVY = false>
 struct FrameState {
   const FrameArgs& p;
@@ -1027,6 +1049,7 @@ struct FrameState {
   // spec_begin: the provisional roots and their rows; returns their number, 0 (no blob left unclaimed: the chain is complete) or -1.
   __device__ __forceinline__ int spec_begin(int jlo, int n_roots) {
     const int MW = (M + 63) / 64, lane = tid & 63;
+    if (tid < 64) frame_prio<MOCAP_FRAME_PRIO_SERIAL>();
     if (tid < 64) {
       int u = 0;
       if (lane >= jlo && lane < C) {
@@ -1061,6 +1084,7 @@ struct FrameState {
         misc[MI_SPEC_OVER + 1] = 0;
       }
     }
+    frame_prio<MOCAP_FRAME_PRIO_CHAIN>();
     __syncthreads();
     const int nP = misc[MI_SPEC_N];
     __syncthreads();  // (the slot is reused as the fall-back flag below)
@@ -1083,6 +1107,7 @@ struct FrameState {
       __syncthreads();
       return false;
     }
+    if (tid < 64) frame_prio<MOCAP_FRAME_PRIO_SERIAL>();
     if (tid < 64) {
       const int row = n_roots + lane;
       const bool mine = lane < nP;
@@ -1146,6 +1171,7 @@ struct FrameState {
         misc[MI_NROOTS] = n_roots + nreal;
       }
     }
+    frame_prio<MOCAP_FRAME_PRIO_CHAIN>();
     __syncthreads();
     n_roots = misc[MI_NROOTS];
     return true;
@@ -1156,6 +1182,7 @@ struct FrameState {
   // bytes for the cameras after j belong to the matching pass that follows).
   __device__ __forceinline__ int create_roots(int j, int n_roots) {
     const int MW = (M + 63) / 64;
+    if (tid < 64) frame_prio<MOCAP_FRAME_PRIO_SERIAL>();
     if (tid < 64) {
       const int Mj = cnt[j];
       int base_root = n_roots;
@@ -1183,6 +1210,7 @@ struct FrameState {
         misc[MI_NROOTS] = base_root;
       }
     }
+    frame_prio<MOCAP_FRAME_PRIO_CHAIN>();
     __syncthreads();
     const int now = misc[MI_NROOTS];
     if (now > n_roots) {  // workgroup-uniform
@@ -1269,6 +1297,7 @@ struct FrameState {
 #else
     __syncthreads();
 #endif
+    frame_prio<MOCAP_FRAME_PRIO_CHAIN>();
     bool spec_ok = MOCAP_WIDE_SPEC && !(MOCAP_WIDE_DEBUG_SKIP & 2) && p.wide != 2;
     for (int j = 1; j < C; j++) {
       // cameras j .. C-1 in one speculative pass as soon as few blobs are left unclaimed (spec_begin), else camera j alone
@@ -1388,6 +1417,7 @@ struct FrameState {
       gcnt[r] = views > 1 ? (heavy ? 1u : (over ? 0u : (uint32_t)total)) : 0u;  // helpers.py:413-414 drops 1-view roots
     }
     __syncthreads();
+    if (tid < 64) frame_prio<MOCAP_FRAME_PRIO_SERIAL>();
     if (tid < 64) {  // candidate offsets and output slots: wave scans over the roots, 64 at a time
       const int lane = tid;
       unsigned long long carry = 0;
@@ -1411,6 +1441,7 @@ struct FrameState {
         misc[MI_G] = misc[MI_STATUS] ? 0 : (int32_t)(uint32_t)carry;
       }
     }
+    frame_prio<MOCAP_FRAME_PRIO_CHAIN>();
     __syncthreads();
   }
 
@@ -1805,6 +1836,7 @@ __global__ __launch_bounds__(T, MOCAP_FRAME_WAVES_PER_EU) void frame_kernel(Fram
         S = q_load(&q.heavy[4 * h + 2]);
         sl = item - base;
       }
+      frame_prio<MOCAP_FRAME_PRIO_MATCH>();
       if constexpr (WIDE) st.match_wide(frame); else st.match(frame);
       const uint32_t G = (uint32_t)st.misc[MI_G];
       if (kind == 1) {
@@ -1841,7 +1873,9 @@ __global__ __launch_bounds__(T, MOCAP_FRAME_WAVES_PER_EU) void frame_kernel(Fram
         g_lo = (uint32_t)((uint64_t)G * (uint64_t)sl / S);
         g_hi = (uint32_t)((uint64_t)G * (uint64_t)(sl + 1) / S);
       }
+      frame_prio<MOCAP_FRAME_PRIO_EVAL>();
       if (g_hi > g_lo) st.evaluate(g_lo, g_hi);
+      frame_prio<MOCAP_FRAME_PRIO_OUT>();
       const int nroots = st.misc[MI_NROOTS];
       bool merge = false;
       for (int r = tid; r < nroots; r += T) {
