@@ -629,7 +629,7 @@ static int match_dev_locked(mocap_ctx* ctx, int64_t n_frames, int M_max, const f
   }
   // persistent grid: enough workgroups to fill every CU at the LDS-limited occupancy
   int per_cu = (int)((160 * 1024) / lds);
-  const int wave_cap = use_bb ? frame_bb_wg_per_cu_cap() : (16 / (T / 64) > 0 ? 16 / (T / 64) : 1);  // 128 VGPRs -> 16 waves per CU
+  const int wave_cap = use_bb ? frame_bb_wg_per_cu_cap(ctx->C, M_max, K_max) : (16 / (T / 64) > 0 ? 16 / (T / 64) : 1);  // 128 VGPRs -> 16 waves per CU (the headline kernel: its instantiation's own budget)
   if (per_cu > wave_cap) per_cu = wave_cap;
   if (per_cu < 1) per_cu = 1;
   const int64_t full_grid = (int64_t)ctx->num_cus * per_cu;

@@ -52,15 +52,26 @@ constexpr int kBBRecs = kBBThreads + 64;  // surviving blocks queued between two
 // LDS carving, identical on host (size) and device (pointers): the frame's persistent state (blobs, per-blob DLT table,
 // roots, hit lists), the search's arrays (block records, result slots -- dead while matching, which keeps its speculative
 // lines there), the spare blob buffer of the frame pipeline and the cache of block bounds.
+// Workgroups (= waves per SIMD) per CU an instantiation is built for: its register budget (512 / n per lane) and the occupancy
+// step its LDS layout sizes the block cache for.  Four everywhere (128 VGPRs; 33-40 KB of LDS) except the 8-camera, 16-blob,
+// 48-slot layout -- the bench's -- whose 29.2 KB leave room for FIVE frames per CU: 96 VGPRs (52 spilled instead of 22, +6 % per
+// frame) and a block cache of 161 entries instead of 385, and still 4.50 -> 4.31 ms per 100 k frames (profiles/r06_wide_experiments.txt, (15)).
+#ifndef MOCAP_BB_WAVES_PER_EU
+#define MOCAP_BB_WAVES_PER_EU 4
+#endif
+#ifndef MOCAP_BB_WAVES_PER_EU_48
+#define MOCAP_BB_WAVES_PER_EU_48 5
+#endif
+constexpr int bb_wg_per_cu(int RL) { return RL == 48 ? MOCAP_BB_WAVES_PER_EU_48 : MOCAP_BB_WAVES_PER_EU; }
 #ifndef MOCAP_BB_LDS_SLACK
 #define MOCAP_BB_LDS_SLACK 1024  // (measured: 512 keeps the occupancy step as well, 0 does not)
 #endif
 struct BBLayout {
-  size_t bxy, bxy_nx, cnt_nx, bt, rbound, seedkey, slot_key, slot_x, claimw, recs, rpk, scr, scr_bytes, goff, gcnt, outslot, boff, bnb, seedgh, slot_g, cnt,
+  size_t bxy, bxy_nx, cnt_nx, bt, rbound, seedkey, slot_key, claimw, recs, rpk, scr, scr_bytes, goff, gcnt, outslot, boff, bnb, seedgh, slot_g, cnt,
       misc, bpl, nh, hits, act, root_blob, root_cam, nact, bnl, bv, bcache, bpk, total;
   int ncache;
   __host__ __device__ static size_t al(size_t x, size_t a) { return (x + a - 1) / a * a; }
-  __host__ __device__ BBLayout(int C, int M, int R, int CW) {
+  __host__ __device__ BBLayout(int C, int M, int R, int CW, int wg_per_cu) {
     size_t o = 0;
     auto take = [&](size_t bytes, size_t a) {
       o = al(o, a);
@@ -79,17 +90,16 @@ struct BBLayout {
     // lines here (match(): lines of every blob that MIGHT become a root, computed off the critical path)
     scr = seedkey = take(8 * (size_t)R, 8);
     slot_key = take(8 * (size_t)kBBWaves * R, 8);
-    slot_x = take(24 * (size_t)kBBWaves * R, 8);
     recs = take(8 * (size_t)kBBRecs, 8);
     rpk = take(8 * (size_t)kBBRecs * CW, 8);
+    seedgh = take(4 * (size_t)R, 4);
+    slot_g = take(4 * (size_t)kBBWaves * R, 4);
     scr_bytes = o - scr;
     goff = take(4 * (size_t)(R + 1), 4);
     gcnt = take(4 * (size_t)R, 4);
     outslot = take(4 * (size_t)R, 4);
     boff = take(4 * (size_t)(R + 1), 4);
     bnb = take(4 * (size_t)R, 4);
-    seedgh = take(4 * (size_t)R, 4);
-    slot_g = take(4 * (size_t)kBBWaves * R, 4);
     cnt = take(4 * (size_t)C, 4);
     misc = take(4 * 16, 4);
     bpl = take(2 * (size_t)R, 2);
@@ -107,7 +117,7 @@ struct BBLayout {
     bcache = take(0, 8);
     ncache = 0;
     const size_t per_entry = 8 + 8 * (size_t)CW;
-    for (int per_cu = 5; per_cu >= 1; per_cu--) {
+    for (int per_cu = wg_per_cu; per_cu >= 1; per_cu--) {
       const size_t lim = ((size_t)160 * 1024 / per_cu - MOCAP_BB_LDS_SLACK) / 256 * 256;  // (slack: allocation granule, other LDS users)
       if (lim >= o + per_entry * 64) {
         const size_t n = (lim - o) / per_entry;
@@ -135,9 +145,9 @@ static int frame_bb_root_slots(int C, int M, int R) {
   const int f = bb_fixed_slots(C, M, R);
   return f ? f : R;
 }
-size_t frame_bb_lds_bytes(int C, int M, int R) { return BBLayout(C, M, frame_bb_root_slots(C, M, R), C <= 8 ? 1 : 2).total; }
+size_t frame_bb_lds_bytes(int C, int M, int R) { return BBLayout(C, M, frame_bb_root_slots(C, M, R), C <= 8 ? 1 : 2, bb_wg_per_cu(bb_fixed_slots(C, M, R))).total; }
 static size_t frame_bb_lds_bytes_min(int C, int M, int R) {
-  const BBLayout L(C, M, frame_bb_root_slots(C, M, R), C <= 8 ? 1 : 2);
+  const BBLayout L(C, M, frame_bb_root_slots(C, M, R), C <= 8 ? 1 : 2, bb_wg_per_cu(bb_fixed_slots(C, M, R)));
   return L.total - (8 + 8 * (size_t)(C <= 8 ? 1 : 2)) * (size_t)L.ncache;
 }
 bool frame_bb_fits(int C, int M, int R) {
@@ -225,7 +235,6 @@ struct BBState {
   float2 *bxy, *bxy_nx;
   int32_t* cnt_nx;
   unsigned long long *rbound, *seedkey, *slot_key, *claimw, *rpk;
-  double* slot_x;
   struct BRec { uint32_t gh, rs; };  // surviving block gh of root (rs & 0xFF); its candidates start at rs >> 8 of the expanded list
   BRec* recs;
   uint32_t *goff, *gcnt, *boff, *bnb, *seedgh, *slot_g;
@@ -250,7 +259,7 @@ struct BBState {
       cv.base = (const double*)(uintptr_t)(((unsigned long long)thi << 32) | tlo);
       if constexpr (CT == 0) cv.C = C;
     }
-    const BBLayout L(C, M, RS, CW);
+    const BBLayout L(C, M, RS, CW, bb_wg_per_cu(RL));
     bt = (double*)(smem + L.bt);
     bxy = (float2*)(smem + L.bxy);
     bxy_nx = (float2*)(smem + L.bxy_nx);
@@ -258,7 +267,6 @@ struct BBState {
     rbound = (unsigned long long*)(smem + L.rbound);
     seedkey = (unsigned long long*)(smem + L.seedkey);
     slot_key = (unsigned long long*)(smem + L.slot_key);
-    slot_x = (double*)(smem + L.slot_x);
     claimw = (unsigned long long*)(smem + L.claimw);
     recs = (BRec*)(smem + L.recs);
     rpk = (unsigned long long*)(smem + L.rpk);
@@ -1091,12 +1099,6 @@ struct BBState {
             wave_lds_sync();
             if (holder) atomicMin(&slot_g[ss], gword);
             wave_lds_sync();
-            if (holder && slot_g[ss] == gword) {
-              slot_x[3 * ss + 0] = X[0];
-              slot_x[3 * ss + 1] = X[1];
-              slot_x[3 * ss + 2] = X[2];
-            }
-            wave_lds_sync();
           }
         }
         __syncthreads();  // every lane is done with the records: new ones may be queued (through the other counter)
@@ -1175,11 +1177,10 @@ struct BBState {
   }
 
   // winner of root r: the (wave, root) slots merged
-  __device__ bool root_winner(int r, double& eb, uint32_t& gb, double (&Xb)[3]) const {
+  __device__ bool root_winner(int r, double& eb, uint32_t& gb) const {
     if (!gcnt[r]) return false;
     unsigned long long kb = ~0ull;
     uint32_t gw = 0xFFFFFFFFu;
-    int sb = r;
     for (int w = 0; w < W; w++) {
       const int s = w * RS + r;
       const unsigned long long k = slot_key[s];
@@ -1187,25 +1188,27 @@ struct BBState {
       if (k < kb || (k == kb && g < gw)) {
         kb = k;
         gw = g;
-        sb = s;
       }
     }
     if (kb == ~0ull) return false;
     gb = gw >> 1;
     eb = kb != kInfBits ? __longlong_as_double((long long)kb)
                         : ((gw & 1u) ? __longlong_as_double(0x7ff8000000000000ll) : __builtin_huge_val());
-    Xb[0] = slot_x[3 * sb + 0];
-    Xb[1] = slot_x[3 * sb + 1];
-    Xb[2] = slot_x[3 * sb + 2];
     return true;
   }
 
   // ---------------------------------------------------------------- phase E
-  __device__ void write_point(int64_t frame, int r, double e, uint32_t gl, const double (&X)[3]) const {
+  // The winner's point is not kept while the search runs (12 doubles per root and wave: 4.5 of the frame's 33.8 KB of LDS,
+  // the difference between four and five frames per CU): the group is decoded here anyway, its DLT matrix is the canonical
+  // sum again (cameras ascending, fetch_candidate's bits) and the point is solve_and_score's own arithmetic on it -- nothing
+  // of which depends on the bound the evaluation was cut against.
+  __device__ void write_point(int64_t frame, int r, double e, uint32_t gl) const {
     const int C = cn();
     const size_t o = (size_t)frame * R + outslot[r];
-    store_point(p, o, X);  // incl. the fused world-coordinate epilogue (helpers.py:96-103)
     p.err[o] = e;
+    double B[10];
+#pragma unroll
+    for (int ee = 0; ee < 10; ee++) B[ee] = 0.0;
     uint32_t rem = gl;  // decode the winning group
     const int rc = root_cam[r];
     int16_t* co = p.corr + o * C;
@@ -1226,16 +1229,20 @@ struct BBState {
         }
       }
       co[c] = s;
+      if (s >= 0) {
+        const double* t = bt + ((size_t)c * M + (uint32_t)s) * 10;
+#pragma unroll
+        for (int ee = 0; ee < 10; ee++) B[ee] = B[ee] + t[ee];
+      }
     }
+    double X[3];
+    solve_point(B, X);
+    store_point(p, o, X);  // incl. the fused world-coordinate epilogue (helpers.py:96-103)
   }
 };
 
-#ifndef MOCAP_BB_WAVES_PER_EU
-#define MOCAP_BB_WAVES_PER_EU 4
-#endif
-
 template <bool F32R, int CW, int CT, int ML, int RL>
-__global__ __launch_bounds__(kBBThreads, MOCAP_BB_WAVES_PER_EU) void frame_bb_kernel(FrameArgs p) {
+__global__ __launch_bounds__(kBBThreads, bb_wg_per_cu(RL)) void frame_bb_kernel(FrameArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   BBState<F32R, CW, CT, ML, RL> st(p, smem);
   const int tid = threadIdx.x;
@@ -1276,9 +1283,9 @@ __global__ __launch_bounds__(kBBThreads, MOCAP_BB_WAVES_PER_EU) void frame_bb_ke
       const int nroots = st.misc[MI_NROOTS];
       for (int r = tid; r < nroots; r += kBBThreads) {
         if (st.outslot[r] < 0) continue;
-        double e, X[3];
+        double e;
         uint32_t gl;
-        if (st.root_winner(r, e, gl, X)) st.write_point(frame, r, e, gl, X);
+        if (st.root_winner(r, e, gl)) st.write_point(frame, r, e, gl);
       }
     }
     wait_own_stores();  // ... and loads: the next frame's blobs are in LDS
@@ -1291,7 +1298,7 @@ __global__ __launch_bounds__(kBBThreads, MOCAP_BB_WAVES_PER_EU) void frame_bb_ke
     for (int c = 0; c < QC_COUNT; c++) q_store(&q.counters[c], 0);
 }
 
-int frame_bb_wg_per_cu_cap() { return MOCAP_BB_WAVES_PER_EU; }
+int frame_bb_wg_per_cu_cap(int C, int M, int R) { return bb_wg_per_cu(bb_fixed_slots(C, M, R)); }
 size_t frame_bb_ws_bytes(int) { return 0; }  // (no per-workgroup HBM workspace: everything between input and output lives in LDS)
 
 hipError_t launch_frame_bb(const FrameArgs& a, int grid, hipStream_t stream) {

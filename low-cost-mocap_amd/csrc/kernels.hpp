@@ -134,7 +134,7 @@ hipError_t launch_frame_kernel(const FrameArgs& a, int mode, int threads, int gr
 bool frame_bb_fits(int C, int M, int R);
 size_t frame_bb_lds_bytes(int C, int M, int R);
 hipError_t launch_frame_bb(const FrameArgs& a, int grid, hipStream_t stream);
-int frame_bb_wg_per_cu_cap();  // workgroups per CU the kernel's register budget allows (its waves per SIMD)
+int frame_bb_wg_per_cu_cap(int C, int M, int R);  // workgroups per CU the kernel's register budget allows (its waves per SIMD)
 size_t frame_bb_ws_bytes(int C);  // bytes of global workspace per workgroup (the probe scheme's parked candidates), 0 = none
 
 // object (drone) locator over the frame path's output (reference helpers.py:424-480), csrc/post_kernels.hip

@@ -496,6 +496,17 @@ __device__ __forceinline__ void solve_and_score(const View& cv, double (&B)[10],
   score_point<UNIFORM_K, PAIRWISE, F32R, BATCH>(cv, v, obs2, X, err, limit);
 }
 
+// The point alone (helpers.py:318-321) of a group whose DLT matrix is B: solve_and_score's arithmetic up to the point,
+// nothing cut (a caller that knows the group's error already and did not keep its point).
+__device__ __forceinline__ void solve_point(double (&B)[10], double (&X)[3]) {
+  double vec[4], lam_lb;
+  smallest_eigvec4(B, vec, __builtin_huge_val(), lam_lb);
+  const double rw = recip_refined(vec[3]);
+  X[0] = div_by(vec[0], vec[3], rw);
+  X[1] = div_by(vec[1], vec[3], rw);
+  X[2] = div_by(vec[2], vec[3], rw);
+}
+
 // calculate_reprojection_error (helpers.py:214-241) of a GIVEN point X seen by v cameras.
 template <bool UNIFORM_K, bool PAIRWISE, bool F32R, int BATCH, class View, class Obs2>
 __device__ __forceinline__ void score_point(const View& cv, int v, Obs2&& obs2, const double (&X)[3], double& err,

@@ -49,12 +49,14 @@ def test_every_kernel_family_of_the_path_is_in_the_library(kernels):
 
 def test_headline_kernel_budget(kernels):
     # frame_bb_kernel<F32R = true, CW = 1, CT = 8, ML = 16, RL = 48>: the instantiation bench.py's 8 x 16 workload takes
-    for rl in ("Li48E", "Li64E"):
+    # round 6: the 48-slot layout is built for FIVE frames per CU (96 VGPRs, 29.2 KB of LDS + block cache: the winners' points are
+    # recomputed at the output instead of living in LDS) -- 42 spilled / 172 B there; the 64-slot layout stays at four (17 / 72 B)
+    for rl, vgprs, spills, scratch in (("Li48E", 96, 46, 188), ("Li64E", 128, 26, 108)):
         k = _find(kernels, "frame_bb_kernelILb1ELi1ELi8ELi16E" + rl)
-        assert k["vgpr_count"] <= 128, k                      # 4 waves per SIMD
+        assert k["vgpr_count"] <= vgprs, k                    # 5 / 4 waves per SIMD
         # round 3: 23 / 96-100 B; round 5 (record of zeros + tiny division: 5.43 -> 5.28 ms): 26 / 108 B -- stored once before
         # the frame loop (+ two stores in the output stage), reloaded at a handful of places per frame
-        assert k["vgpr_spill_count"] <= 26 and k["private_segment_fixed_size"] <= 108, k
+        assert k["vgpr_spill_count"] <= spills and k["private_segment_fixed_size"] <= scratch, k
         assert k["group_segment_fixed_size"] == 0, k          # LDS is dynamic: sized by frame_bb_lds_bytes for the launch
     general = _find(kernels, "frame_bb_kernelILb1ELi1ELi8ELi0ELi0E")
     assert general["vgpr_count"] <= 128 and general["vgpr_spill_count"] <= 48, general
