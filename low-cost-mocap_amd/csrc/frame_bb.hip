@@ -208,6 +208,9 @@ struct BBCamTables<0> {
 // (chain bookkeeping, scans) at 3, the rest of the matching and the output at 2, the seed pass at 1.  A frame's serial
 // depth then costs what it costs alone, not what it costs sharing its SIMD's issue slots with three evaluations:
 // 4.70 -> 4.50 ms per 100 k frames of 8 x 16 (profiles/r06_wide_experiments.txt, (14); MOCAP_BB_PRIO=0: without).
+#ifndef MOCAP_BB_FRESH_TID
+#define MOCAP_BB_FRESH_TID 1
+#endif
 #ifndef MOCAP_BB_PRIO
 #define MOCAP_BB_PRIO 1
 #endif
@@ -229,7 +232,20 @@ struct BBState {
   static constexpr int T = kBBThreads, W = kBBWaves;
   const FrameArgs& p;
   BBCamTables<CT> cv;
-  const int C_, M, R, RS, tid, lane, wave;  // R = K_max (root limit, output stride), RS = root slots of the layout
+  const int C_, M, R, RS;  // R = K_max (root limit, output stride), RS = root slots of the layout
+  int tid, lane, wave;
+  // The lane's number taken afresh (an empty asm the optimiser cannot see through): what a phase derives from it -- LDS addresses,
+  // (root, camera) pair indices, masks -- is computed in that phase instead of once before the frame loop, where it would sit in a
+  // register for the whole frame, i.e. in scratch (MOCAP_BB_FRESH_TID=0: without)
+  __device__ __forceinline__ void fresh_tid() {
+#if MOCAP_BB_FRESH_TID
+    int t = tid;
+    asm volatile("" : "+v"(t));
+    tid = t;
+    lane = t & 63;
+    wave = t >> 6;
+#endif
+  }
   __device__ __forceinline__ int cn() const { return CT > 0 ? CT : C_; }
   double* bt;
   float2 *bxy, *bxy_nx;
@@ -418,6 +434,7 @@ struct BBState {
   }
   // the prefetched frame becomes the current one (buffer swap)
   __device__ __forceinline__ void stage(int64_t frame) {
+    fresh_tid();
     const int C = cn();
     float2* t = bxy;
     bxy = bxy_nx;
@@ -437,6 +454,7 @@ struct BBState {
   // Also pulls the NEXT frame from the queue into misc[MI_NEXT] (one lane of wave 1, while wave 0 walks the cameras: the
   // atomic's round trip to L2 is off everybody's critical path), so that every lane can prefetch that frame afterwards.
   __device__ void match() {
+    fresh_tid();
     const int C = cn();
     __syncthreads();
     int gs_shift = 0;
@@ -612,6 +630,7 @@ struct BBState {
       }
     }
     __syncthreads();
+    fresh_tid();
     if (wave == 0) bb_prio<kPrioSerial>();
     if (wave == 0 && pre) {
       // B1, pre-matched: lane p <-> provisional root p = the p-th unclaimed blob of cameras 1 .. C-1 in (camera, blob) order.
@@ -767,6 +786,7 @@ struct BBState {
     }
 
     // C: candidate counts per root
+    fresh_tid();
     const int nroots = misc[MI_NROOTS];
     for (int r = tid; r < nroots; r += T) {
       const int rc = root_cam[r];
@@ -929,6 +949,7 @@ struct BBState {
   }
 
   __device__ void search(bool bound_tests) {
+    fresh_tid();
     const int C = cn();
     (void)C;
     const int nroots = misc[MI_NROOTS];
@@ -1032,6 +1053,7 @@ struct BBState {
     // ---- 2. the queued records' candidates (spread over all lanes, whatever root they belong to), then the next
     // blocks' tests, until nothing is left
     uint32_t b0 = 0;
+    fresh_tid();
     while (true) {
       const uint32_t cv_ = (uint32_t)*ctr;
       const uint32_t ns = cv_ & 0x3FFu, ne = cv_ >> 10;
@@ -1281,7 +1303,8 @@ __global__ __launch_bounds__(kBBThreads, bb_wg_per_cu(RL)) void frame_bb_kernel(
       st.search(G >= (uint32_t)p.bb_min_g);
       bb_prio<kPrioPhase>();
       const int nroots = st.misc[MI_NROOTS];
-      for (int r = tid; r < nroots; r += kBBThreads) {
+      st.fresh_tid();
+      for (int r = st.tid; r < nroots; r += kBBThreads) {
         if (st.outslot[r] < 0) continue;
         double e;
         uint32_t gl;

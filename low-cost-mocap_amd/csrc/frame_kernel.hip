@@ -197,6 +197,9 @@ __device__ __forceinline__ CamView split_cam_view(const CamView& v) {
 // flagging their frames -- a separate instantiation, so that the code does not weigh on the registers of the first pass
 // Every phase below is __forceinline__: the frame kernels are ONE body per instantiation.  (Round 6: a self-check build had
 // write_point outlined as a real function -- calls, a stack in scratch, and a barrier the ISA test could no longer prove safe.)
+#ifndef MOCAP_FRAME_FRESH_TID
+#define MOCAP_FRAME_FRESH_TID 1
+#endif
 #ifndef MOCAP_FRAME_PRIO_MATCH
 #define MOCAP_FRAME_PRIO_MATCH 0
 #endif
@@ -227,7 +230,17 @@ struct FrameState {
 #else
   const CamView& cv;
 #endif
-  const int C, M, R, tid;
+  const int C, M, R;
+  int tid;
+  // The lane's number taken afresh (an empty asm the optimiser cannot see through; csrc/frame_bb.hip has the measurements): what a
+  // phase derives from it is computed in that phase instead of once before the frame loop -- where it would sit in scratch
+  __device__ __forceinline__ void fresh_tid() {
+#if MOCAP_FRAME_FRESH_TID
+    int t = tid;
+    asm volatile("" : "+v"(t));
+    tid = t;
+#endif
+  }
   int Hs;  // hit-list stride per (root, camera)
   double *line, *dist, *seg_e, *seg_x;
   unsigned long long* rbound;  // [R] bit pattern of the smallest error any lane has found for the root (+inf at start)
@@ -319,6 +332,7 @@ struct FrameState {
   // Leaves roots / hit lists / candidate offsets in LDS; returns with all lanes synchronised.  (Narrow frames; wide
   // frames take match_wide.)
   __device__ __forceinline__ void match(int64_t frame, int skip = 0 /* timing experiments: 1 = no table build, 2 = no camera loop */) {
+    fresh_tid();
     {
       const float2* src = (const float2*)(p.blobs + (size_t)frame * C * M * 2);
       for (int i = tid; i < C * M; i += T) bxy[i] = src[i];
@@ -671,6 +685,7 @@ struct FrameState {
   // one batch of each group instead (the call for camera 1 alone, on which everything after it waits).
   template <bool CAM01>
   __device__ __forceinline__ void match_roots_wide(int rlo, int rhi, int clo, int chi, bool split) {
+    fresh_tid();
     constexpr int W = T / 64;
     const int lane = tid & 63, wave = tid >> 6;
     if (split && wave >= 4) return;  // (no workgroup barrier inside)
@@ -888,6 +903,7 @@ struct FrameState {
   // expression of helpers.py:373.  The rare hits go through a 64-entry list of the wave in LDS and come out in
   // (distance, index) order.
   __device__ __forceinline__ void match_pairs_wide(int rlo, int rhi, int clo) {
+    fresh_tid();
     constexpr int W = T / 64;
     // a wave visits cameras clo + wave, + W, ...: at most NV of them (C <= 64); a lane holds ONE (root, visit) pair of the
     // sub-batch: root q = lane / NV of up to NQ roots, visit v = lane % NV.  (Round 6: before, every visit computed the lines
@@ -1048,6 +1064,7 @@ struct FrameState {
   // (claimed with it by value: not replayable from the closest hit alone).  All lanes; synchronised on entry and exit.
   // spec_begin: the provisional roots and their rows; returns their number, 0 (no blob left unclaimed: the chain is complete) or -1.
   __device__ __forceinline__ int spec_begin(int jlo, int n_roots) {
+    fresh_tid();
     const int MW = (M + 63) / 64, lane = tid & 63;
     if (tid < 64) frame_prio<MOCAP_FRAME_PRIO_SERIAL>();
     if (tid < 64) {
@@ -1101,6 +1118,7 @@ struct FrameState {
   // spec_finish: after the provisional roots [n_roots, n_roots + nP) have met their cameras (match_pairs_wide with spec_base set)
   // and a barrier.  True: the chain is complete, n_roots updated.  False: rows clean, the sequential chain takes over.
   __device__ __forceinline__ bool spec_finish(int nP, int& n_roots) {
+    fresh_tid();
     const int MW = (M + 63) / 64, lane = tid & 63;
     if (misc[MI_SPEC_N]) {  // workgroup-uniform: the sequential chain starts over from camera jlo with clean rows
       for (int q = tid; q < 2 * nP; q += T) nhc[2 * (size_t)n_roots + q] = 0ull;
@@ -1181,6 +1199,7 @@ struct FrameState {
   // rows up to their own camera.  Returns the new number of roots.  All lanes; synchronised on entry, not on exit (the rows'
   // bytes for the cameras after j belong to the matching pass that follows).
   __device__ __forceinline__ int create_roots(int j, int n_roots) {
+    fresh_tid();
     const int MW = (M + 63) / 64;
     if (tid < 64) frame_prio<MOCAP_FRAME_PRIO_SERIAL>();
     if (tid < 64) {
@@ -1227,6 +1246,7 @@ struct FrameState {
   }
 
   __device__ __forceinline__ void match_wide(int64_t frame) {
+    fresh_tid();
     const int MW = (M + 63) / 64;
     {
       bxy = const_cast<float2*>((const float2*)(p.blobs + (size_t)frame * C * M * 2));  // read in place, never written
@@ -1379,6 +1399,7 @@ struct FrameState {
 
   // C: candidate counts per root (all lanes; the roots and hit lists are in place and the workgroup is synchronised)
   __device__ __forceinline__ void count_candidates() {
+    fresh_tid();
     const int nroots = misc[MI_NROOTS];
     for (int r = tid; r < nroots; r += T) {
       const int rc = root_cam[r];
@@ -1505,6 +1526,7 @@ struct FrameState {
 
   // Evaluate candidates [g_lo, g_hi); per (lane, root) segment winners land in seg_* .
   __device__ __forceinline__ void evaluate(uint32_t g_lo, uint32_t g_hi) {
+    fresh_tid();
     const int nroots = misc[MI_NROOTS];
     const uint32_t q = (g_hi - g_lo + T - 1) / T;
     uint32_t g = g_lo + (uint32_t)tid * q;

@@ -11,4 +11,8 @@
 #ifndef MOCAP_FRAME_PRIO_OUT
 #define MOCAP_FRAME_PRIO_OUT 1
 #endif
+// (the wide variant is compiled without machine LICM instead of taking the lane's number afresh per phase: Makefile, FRAME_WIDE_FLAGS)
+#ifndef MOCAP_FRAME_FRESH_TID
+#define MOCAP_FRAME_FRESH_TID 0
+#endif
 #include "frame_kernel.hip"

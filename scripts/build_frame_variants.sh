@@ -9,7 +9,7 @@ for spec in "$@"; do
   tag=${spec%%=*}; flags=${spec#*=}
   # (both translation units of the frame kernel: the small-frame kernels, and the wide variant with the product's FRAME_WIDE_FLAGS
   # unless the variant says NOWIDEFLAGS=1)
-  WF="-mllvm -amdgpu-schedule-relaxed-occupancy=true -mllvm -greedy-regclass-priority-trumps-globalness=1 -mllvm -enable-post-misched=false"
+  WF="-mllvm -amdgpu-schedule-relaxed-occupancy=true -mllvm -greedy-regclass-priority-trumps-globalness=1 -mllvm -enable-post-misched=false -mllvm -disable-machine-licm"
   [ "${NOWIDEFLAGS:-0}" = 1 ] && WF=""
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function $flags -c csrc/frame_kernel.hip -o build/frame_kernel_v_$tag.o &
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function $WF $flags -c csrc/frame_kernel_wide.hip -o build/frame_kernel_wide_v_$tag.o &

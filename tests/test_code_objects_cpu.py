@@ -51,7 +51,9 @@ def test_headline_kernel_budget(kernels):
     # frame_bb_kernel<F32R = true, CW = 1, CT = 8, ML = 16, RL = 48>: the instantiation bench.py's 8 x 16 workload takes
     # round 6: the 48-slot layout is built for FIVE frames per CU (96 VGPRs, 29.2 KB of LDS + block cache: the winners' points are
     # recomputed at the output instead of living in LDS) -- 42 spilled / 172 B there; the 64-slot layout stays at four (17 / 72 B)
-    for rl, vgprs, spills, scratch in (("Li48E", 96, 46, 188), ("Li64E", 128, 26, 108)):
+    # ... and without machine LICM + with the lane's number taken afresh per phase (Makefile FRAME_BB_FLAGS, BBState::fresh_tid) the
+    # loop-invariant values no longer live in scratch: 4 spilled / 20 B and 0 / 0
+    for rl, vgprs, spills, scratch in (("Li48E", 96, 8, 40), ("Li64E", 128, 4, 24)):
         k = _find(kernels, "frame_bb_kernelILb1ELi1ELi8ELi16E" + rl)
         assert k["vgpr_count"] <= vgprs, k                    # 5 / 4 waves per SIMD
         # round 3: 23 / 96-100 B; round 5 (record of zeros + tiny division: 5.43 -> 5.28 ms): 26 / 108 B -- stored once before
@@ -59,7 +61,7 @@ def test_headline_kernel_budget(kernels):
         assert k["vgpr_spill_count"] <= spills and k["private_segment_fixed_size"] <= scratch, k
         assert k["group_segment_fixed_size"] == 0, k          # LDS is dynamic: sized by frame_bb_lds_bytes for the launch
     general = _find(kernels, "frame_bb_kernelILb1ELi1ELi8ELi0ELi0E")
-    assert general["vgpr_count"] <= 128 and general["vgpr_spill_count"] <= 48, general
+    assert general["vgpr_count"] <= 128 and general["vgpr_spill_count"] <= 8, general
 
 
 def test_ba_and_blob_kernels_do_not_spill(kernels):
@@ -73,10 +75,10 @@ def test_wide_kernel_budget(kernels):
     HBM workspace (57 spilled VGPRs, 164 B of scratch then); a change that pushes the spills back up shows here first."""
     k = _find(kernels, "frame_kernelILi1024ELb1ELb1ELb1ELi3ELb0E")   # (...Lb1E: the re-submit pass's instantiation, below)
     assert k["vgpr_count"] <= 128, k
-    assert k["vgpr_spill_count"] <= 66 and k["private_segment_fixed_size"] <= 232, k   # (round 6: 58 with the hit masks; 62 under FRAME_WIDE_FLAGS, which trade four more spills for a schedule that is 1 ms per 12 500 stress frames faster)
+    assert k["vgpr_spill_count"] <= 30 and k["private_segment_fixed_size"] <= 160, k   # (round 6: 58 with the hit masks; 62 under FRAME_WIDE_FLAGS, which trade four more spills for a schedule that is 1 ms per 12 500 stress frames faster)
     # round 6: the instantiation the stress shape takes now -- 512 lanes per frame, two frames per CU (same budget: 16 waves per CU)
     k5 = _find(kernels, "frame_kernelILi512ELb1ELb1ELb1ELi3ELb0E")
-    assert k5["vgpr_count"] <= 128 and k5["vgpr_spill_count"] <= 66, k5
+    assert k5["vgpr_count"] <= 128 and k5["vgpr_spill_count"] <= 30, k5      # (round 6, end: 20 without machine LICM -- Makefile FRAME_WIDE_FLAGS; 61 before)
     # round 5: the export of heavy roots (csrc/heavy_bb.hip) lives in an instantiation of its own -- it must not cost the
     # first pass a register
     heavy = _find(kernels, "frame_kernelILi1024ELb1ELb1ELb1ELi3ELb1E")
