@@ -841,7 +841,8 @@ def main():
     ap.add_argument("--frames", type=int, default=0, help="frames per GPU per step (0 = the workload's default)")
     ap.add_argument("--chunks", type=int, default=0,
                     help="N > 1: sub-batches a rank's shard is cut into per step, so that the gather of chunk k travels while chunk "
-                         "k + 1 is computed inside ONE step (0 = automatic: 4, or 2 at 64 x 256; 1 = the whole shard at once)")
+                         "k + 1 is computed inside ONE step (0 = automatic: 1 = the whole shard at once when the run has >= 4 steps, whose "
+                         "exchanges travel under the NEXT step's kernels; a shorter run: 4, or 2 at 64 x 256)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ba", action="store_true")
     ap.add_argument("--no-blobs", action="store_true")
@@ -926,7 +927,13 @@ def main():
     # rank, 3.7 GB into the root).  Each chunk has its own compactor buffers.
     # (automatic: 4 sub-batches; 2 at the stress shape, where every sub-batch pays a kernel tail of ~1 ms and its own re-submit --
     # gather, second pass, heavy-root search: 1.7 ms -- measured in round 5: 4 x 8.5 ms instead of 30.6 for the first pass alone)
-    n_chunks = 1 if not multi else max(1, min(args.chunks or (2 if C * M >= 4096 else 4), F))
+    # Round 6, measured on one GPU with the exchange code path on (scripts/gpu_r06_chunks.sh, 20 steps of 8 x 16): 1 / 2 / 4
+    # sub-batches = 4.50 / 4.89 / 5.38 ms per step against 4.18 without the exchange; 64 x 256: 35.5 (1) / 40.8 (2) against 34.7.
+    # A sub-batch costs ~0.3 ms (8 x 16) / ~5 ms (64 x 256) on EVERY step; what it buys -- a smaller exposed tail after the LAST
+    # kernel -- is paid once per run, because step i's exchange is posted behind step i + 1's kernels anyway.  So: the whole shard
+    # at once when there are steps to hide behind (>= 4), sub-batches only for a run of a few steps.
+    auto_chunks = 1 if args.steps >= 4 else (2 if C * M >= 4096 else 4)
+    n_chunks = 1 if not multi else max(1, min(args.chunks or auto_chunks, F))
     cb = [mdist.shard_bounds(F, c, n_chunks) for c in range(n_chunks)]
     comps = [mdist.TrackCompactor(core, hi - lo, K_MAX, C, dev) for lo, hi in cb] if multi else []
     comm = torch.cuda.Stream(dev) if multi else None

@@ -115,7 +115,7 @@ def test_rccl_gather_api_world1():
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("F,K,C", [(1, 4, 2), (700, 16, 4), (1024, 8, 3), (5000, 48, 8)])
+@pytest.mark.parametrize("F,K,C", [(1, 4, 2), (700, 16, 4), (1024, 8, 3), (5000, 48, 8), (300, 90, 64), (37, 70, 5)])
 def test_compaction_kernel_matches_reference(core, F, K, C):
     """mocap_compact_tracks_dev (exclusive prefix sum over n_out + scatter into 32 + 2C-byte records) against its
     host restatement mocap_core.dist.compact_tracks_reference: offsets, total, every record byte.  Sizes cross the
@@ -150,6 +150,18 @@ def test_compaction_kernel_matches_reference(core, F, K, C):
     back = mdist.unpack_compact(n_out, d_rec.cpu().numpy()[:rec_ref.shape[0]], C, K)
     valid = np.arange(K)[None, :] < np.where((n_out < 0) | (n_out > K), 0, n_out)[:, None]
     assert np.array_equal(back["xyz"][valid], xyz[valid]) and np.array_equal(back["corr"][valid], corr[valid])
+    # a record buffer SHORTER than the total: the records that fit are written (a frame's run may be cut in the middle), nothing
+    # lands past the capacity, offsets and the total still describe the whole batch
+    cap = int(off_ref[-1]) * 2 // 3
+    if cap > 0:
+        d_rec.fill_(0xAB)
+        d_off.fill_(-1)
+        core.compact_tracks_dev(F, K, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), d_off.data_ptr(),
+                                d_rec.data_ptr(), cap, total.data_ptr())
+        core.synchronize()
+        assert int(total[0]) == int(off_ref[-1]) and np.array_equal(d_off.cpu().numpy(), off_ref)
+        assert np.array_equal(d_rec.cpu().numpy()[:cap], rec_ref[:cap])
+        assert (d_rec.cpu().numpy()[cap:] == 0xAB).all()
 
 
 def test_compact_exchange_through_rccl_world1(core):
