@@ -35,7 +35,7 @@ int mocap_ctx::fail(int code, const char* fmt, ...) {
 }
 
 int mocap_ctx::hip_fail(hipError_t e, const char* what) {
-  frame_q_clean = false;  // a launch that failed or aborted may have left the self-cleaning queue counters dirty
+  frame_q_dirty();  // a launch that failed or aborted may have left the self-cleaning queue counters dirty
   return fail(MOCAP_E_HIP, "%s: %s", what, hipGetErrorString(e));
 }
 
@@ -123,6 +123,7 @@ extern "C" void mocap_destroy(mocap_ctx* ctx) {
   ctx->resub.release();
   ctx->live_stage.release();
   ctx->resub_ctr.release();
+  ctx->resub_q.release();
   ctx->heavy_recs.release();
   ctx->heavy_ws.release();
   ctx->heavy_enum.release();
@@ -177,7 +178,7 @@ extern "C" int mocap_set_stream(mocap_ctx* ctx, void* hip_stream) {
     const hipError_t e = hipStreamWaitEvent(ns, ctx->handover_event, 0);
     if (prev_dev >= 0 && prev_dev != ctx->device) (void)hipSetDevice(prev_dev);
     if (e != hipSuccess) return ctx->hip_fail(e, "hipStreamWaitEvent(handover)");
-    ctx->frame_q_clean = false;
+    ctx->frame_q_dirty();
   }
   ctx->stream = ns;
   return MOCAP_OK;
@@ -672,7 +673,8 @@ static int match_dev_locked(mocap_ctx* ctx, int64_t n_frames, int M_max, const f
   const size_t b_cnt = al(sizeof(int32_t) * QC_COUNT), b_heavy = al(sizeof(int32_t) * 4 * (size_t)q.H_cap),
                b_slice = al(sizeof(int32_t) * (size_t)q.W_cap), b_gen = b_slice, b_pe = al(sizeof(double) * (size_t)q.W_cap * K_max),
                b_pg = al(sizeof(uint32_t) * (size_t)q.W_cap * K_max), b_px = al(sizeof(double) * 3 * (size_t)q.W_cap * K_max);
-  DevBuf& wq = ctx->scratch[3];
+  const int qs = n_frames_dev ? 1 : 0;  // the re-submit's second pass keeps queues of its own
+  DevBuf& wq = qs ? ctx->resub_q : ctx->scratch[3];
   const void* wq_before = wq.ptr;
   if (wq.reserve(b_cnt + b_heavy + b_slice + b_gen + b_pe + b_pg + b_px))
     return ctx->fail(MOCAP_E_HIP, "hipMalloc(frame work queues) failed");
@@ -683,7 +685,7 @@ static int match_dev_locked(mocap_ctx* ctx, int64_t n_frames, int M_max, const f
   const bool one_launch = ctx->frame_launches != 3 && !(tiny_batch && !getenv("MOCAP_FRAME_LAUNCHES"));
   // one-launch schedule: the kernel leaves the counters at zero and slices carry a launch generation, so the queue
   // needs clearing only when the buffer is new, the layout moved, or the other schedule used it last
-  const bool fresh = wq.ptr != wq_before || ctx->frame_q_cap != q.W_cap || !ctx->frame_q_clean;
+  const bool fresh = wq.ptr != wq_before || ctx->frame_q_cap[qs] != q.W_cap || !ctx->frame_q_clean[qs];
   char* w = (char*)wq.ptr;
   q.counters = (int32_t*)w;     w += b_cnt;
   q.slice_heavy = (int32_t*)w;  w += b_slice;
@@ -691,7 +693,7 @@ static int match_dev_locked(mocap_ctx* ctx, int64_t n_frames, int M_max, const f
   q.gen = ++ctx->frame_gen;
   if (ctx->frame_gen == 0x7fffffff) {  // generation wrap: start over from a cleared queue
     ctx->frame_gen = 0;
-    ctx->frame_q_clean = false;
+    ctx->frame_q_dirty();
   }
   q.heavy = (int32_t*)w;        w += b_heavy;
   q.part_e = (double*)w;        w += b_pe;
@@ -702,13 +704,13 @@ static int match_dev_locked(mocap_ctx* ctx, int64_t n_frames, int M_max, const f
     if (q.heavy_threshold) HIP_TRY(ctx, hipMemsetAsync(q.slice_heavy, 0xFF, b_slice, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(q.slice_gen, 0, b_gen, ctx->stream));
   }
-  ctx->frame_q_cap = q.W_cap;
-  ctx->frame_q_clean = false;  // until the launch below is known to be queued
+  ctx->frame_q_cap[qs] = q.W_cap;
+  ctx->frame_q_clean[qs] = false;  // until the launch below is known to be queued
   if (use_bb) {
     // frames only: a frame's cost follows its surviving blocks, not its candidate count -- no heavy list, no slices
     ctx->last_frame_kernel = ctx->C <= 8 ? "frame_bb_kernel<CW=1>" : "frame_bb_kernel<CW=2>";
     HIP_TRY(ctx, launch_frame_bb(a, (int)grid, ctx->stream));
-    ctx->frame_q_clean = true;
+    ctx->frame_q_clean[qs] = true;
     return MOCAP_OK;
   }
   ctx->last_frame_kernel = wide ? (T == 512 ? "frame_kernel<512, wide>" : "frame_kernel<1024, wide>") : (T == 64 ? "frame_kernel<64>" : (T == 128 ? "frame_kernel<128>" : "frame_kernel<256>"));
@@ -718,7 +720,7 @@ static int match_dev_locked(mocap_ctx* ctx, int64_t n_frames, int M_max, const f
     int64_t g1 = n_frames + (q.heavy_threshold ? 64 : 0);
     if (g1 > full_grid) g1 = full_grid;
     HIP_TRY(ctx, launch_frame_kernel(a, MODE_ALL, T, (int)g1, ctx->stream));
-    ctx->frame_q_clean = true;
+    ctx->frame_q_clean[qs] = true;
     return MOCAP_OK;
   }
   HIP_TRY(ctx, launch_frame_kernel(a, MODE_MAIN, T, (int)grid, ctx->stream));

@@ -24,9 +24,11 @@ struct mocap_ctx {
   int hit_cap = 32;         // wide frames: hits kept per (root, camera) (mocap_set_frame_limits)
   int force_wide = 0;       // route every frame batch through the wide (HBM workspace) variant
   int32_t frame_gen = 0;    // generation of the last frame-path launch (tags the slices it publishes)
-  int frame_q_cap = 0;      // W_cap the work-queue buffer was laid out for
+  int frame_q_cap[2] = {0, 0};  // W_cap the work-queue buffer was laid out for ([0] a batch's own pass, [1] the re-submit's second pass:
+                            // two buffers, so that neither pass finds the other's layout and clears the queue again -- six fills per call)
   const char* last_frame_kernel = "none";  // which kernel the last frame batch went to (mocap_last_frame_kernel)
-  bool frame_q_clean = false;  // the queue counters were left at zero by the one-launch schedule
+  bool frame_q_clean[2] = {false, false};  // the queue counters were left at zero by the one-launch schedule
+  void frame_q_dirty() { frame_q_clean[0] = frame_q_clean[1] = false; }
   int frame_launches = 1;   // 1: one persistent launch per batch (MODE_ALL); 3: main / slice / merge launches
   int prune = 1;            // stop a candidate group's reprojection once it cannot beat its root's best (exact)
   int exhaustive = 0;       // MOCAP_OPT_EXHAUSTIVE_WALK: no branch and bound, no cut-offs (verification mode)
@@ -80,6 +82,7 @@ struct mocap_ctx {
   DevBuf live_stage;        // mocap_track_frame: device copy of a wide frame's blobs (narrow frames are read from pinned host memory in place)
   DevBuf resub;             // device-side re-submit: counters | frame list | gathered inputs | second-pass outputs
   DevBuf resub_ctr;         // ... its two alternating counters (never re-allocated while a call is in flight)
+  DevBuf resub_q;           // ... the second pass's work queues (frame_q_cap[1])
   DevBuf heavy_recs;        // ... heavy roots exported by the second pass (csrc/heavy_bb.hip)
   DevBuf heavy_ws;          // ... the search's frontier workspace
   DevBuf heavy_enum;        // ... queue + per-workgroup winners of the roots enumerated over the whole GPU (heavy_enum_kernel)
