@@ -925,8 +925,8 @@ def main():
     # A rank's shard is cut into sub-batches: the gather of chunk k is posted once chunk k + 1's kernels are queued, so the
     # exchange overlaps compute INSIDE a step too (a one-step run used to expose all of it: at 64 x 256 that is 532 MB per
     # rank, 3.7 GB into the root).  Each chunk has its own compactor buffers.
-    # (automatic: 4 sub-batches; 2 at the stress shape, where every sub-batch pays a kernel tail of ~1 ms and its own re-submit --
-    # gather, second pass, heavy-root search: 1.7 ms -- measured in round 5: 4 x 8.5 ms instead of 30.6 for the first pass alone)
+    # (runs of one to three steps: 4 sub-batches, 2 at the stress shape, where every sub-batch pays a kernel tail of ~1 ms and its
+    # own re-submit -- gather, second pass, heavy-root search: 1.7 ms)
     # Round 6, measured on one GPU with the exchange code path on (scripts/gpu_r06_chunks.sh, 20 steps of 8 x 16): 1 / 2 / 4
     # sub-batches = 4.50 / 4.89 / 5.38 ms per step against 4.18 without the exchange; 64 x 256: 35.5 (1) / 40.8 (2) against 34.7.
     # A sub-batch costs ~0.3 ms (8 x 16) / ~5 ms (64 x 256) on EVERY step; what it buys -- a smaller exposed tail after the LAST
