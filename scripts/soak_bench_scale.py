@@ -1,0 +1,46 @@
+"""Bench-scale parity soak (GPU): the 100 000-frame bench stream of 8 x 16 -- and other seeds of it -- through the SHIPPED
+configuration many times, every output bit of every frame against the exhaustive walk of the same batch
+(MOCAP_OPT_EXHAUSTIVE_WALK), compared on the device.  tests/test_gpu_bench_scale.py does 20 repetitions of seed 1 on every
+suite run; this is the long version for profiles/ (usage: soak_bench_scale.py [reps per seed] [seed ...] -> one JSON line)."""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "low-cost-mocap_amd"))
+import torch  # noqa: E402
+from mocap_core import capi, devcheck, synth  # noqa: E402
+
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+seeds = [int(a) for a in sys.argv[2:]] or [1, 2, 3, 4, 5]
+C, M, F, K_MAX, G_CAP, GATE = 8, 16, 100_000, 48, 1 << 20, 5.0
+dev = torch.device("cuda", 0)
+stream = torch.cuda.current_stream(dev)
+rig = synth.ring_rig(C)
+shipped, walk = capi.MocapCore(0), capi.MocapCore(0)
+walk.set_options(exhaustive_walk=True)
+for c in (shipped, walk):
+    c.set_stream(stream.cuda_stream)
+    c.set_cameras(rig["K"], rig["R"], rig["t"])
+res = {"frames_per_pass": F, "repetitions_per_seed": reps, "seeds": {}, "frame_evaluations": 0, "frames_differing_total": 0}
+t0 = time.perf_counter()
+for seed in seeds:
+    blobs, counts, _ = synth.make_blob_stream(rig, F, M, seed=seed)
+    d_blobs, d_counts = torch.from_numpy(blobs).to(dev), torch.from_numpy(counts).to(dev)
+    ref = devcheck.FrameOutputs(F, K_MAX, C, dev)
+    ref.run(walk, M, d_blobs, d_counts, GATE, G_CAP)
+    torch.cuda.synchronize(dev)
+    out = devcheck.FrameOutputs(F, K_MAX, C, dev)
+    bad = 0
+    for rep in range(reps):
+        out.zero_()
+        out.run(shipped, M, d_blobs, d_counts, GATE, G_CAP)
+        cmp = devcheck.compare_bitwise(out, ref)
+        bad += int(cmp["frames_differing"]) + (0 if torch.equal(out.n_cand, ref.n_cand) else 1)
+    res["seeds"][str(seed)] = {"frames_differing": bad, "points": int(ref.n_out.sum().item()), "flagged_frames": int((ref.status != 0).sum().item())}
+    res["frame_evaluations"] += F * reps
+    res["frames_differing_total"] += bad
+res["kernel"] = shipped.last_frame_kernel()
+res["walk_kernel"] = walk.last_frame_kernel()
+res["wall_s"] = time.perf_counter() - t0
+print(json.dumps(res))
