@@ -44,3 +44,47 @@ res["kernel"] = shipped.last_frame_kernel()
 res["walk_kernel"] = walk.last_frame_kernel()
 res["wall_s"] = time.perf_counter() - t0
 print(json.dumps(res))
+
+# ---- the wide variant at the same scale (MOCAP force_wide: the kernel of the 64 x 256 shape run on the 8 x 16 stream, where the
+# exhaustive walk exists to compare with), and the stress shape itself run to run (wide first pass + re-submit + heavy-root search)
+if os.environ.get("SOAK_WIDE"):
+    wreps = int(os.environ["SOAK_WIDE"])
+    wide = capi.MocapCore(0)
+    wide.set_stream(stream.cuda_stream)
+    wide.set_cameras(rig["K"], rig["R"], rig["t"])
+    wide.set_frame_limits(force_wide=True)
+    blobs, counts, _ = synth.make_blob_stream(rig, F, M, seed=1)
+    d_blobs, d_counts = torch.from_numpy(blobs).to(dev), torch.from_numpy(counts).to(dev)
+    ref = devcheck.FrameOutputs(F, K_MAX, C, dev)
+    ref.run(walk, M, d_blobs, d_counts, GATE, G_CAP)
+    out = devcheck.FrameOutputs(F, K_MAX, C, dev)
+    bad, t1 = 0, time.perf_counter()
+    for rep in range(wreps):
+        out.zero_()
+        out.run(wide, M, d_blobs, d_counts, GATE, G_CAP)
+        bad += int(devcheck.compare_bitwise(out, ref)["frames_differing"])
+    print(json.dumps({"mode": "wide variant forced on the 8 x 16 stream vs the exhaustive walk", "kernel": wide.last_frame_kernel(),
+                      "repetitions": wreps, "frame_evaluations": F * wreps, "frames_differing_total": bad, "wall_s": time.perf_counter() - t1}))
+if os.environ.get("SOAK_STRESS"):
+    sreps = int(os.environ["SOAK_STRESS"])
+    Cs, Ms, Fs, Ks = 64, 256, 4096, 384
+    srig = synth.stress_rig(Cs)
+    blobs, counts, _ = synth.make_stress_stream(srig, Fs, Ms, seed=1)
+    d_blobs, d_counts = torch.from_numpy(blobs).to(dev), torch.from_numpy(counts).to(dev)
+    core = capi.MocapCore(0)
+    core.set_stream(stream.cuda_stream)
+    core.set_cameras(srig["K"], srig["R"], srig["t"])
+    first = devcheck.FrameOutputs(Fs, Ks, Cs, dev)
+    first.run(core, Ms, d_blobs, d_counts, synth.STRESS_GATE_PX, 1 << 20)
+    torch.cuda.synchronize(dev)
+    flagged, rerun = (int(v) for v in first.info.cpu().numpy())
+    out = devcheck.FrameOutputs(Fs, Ks, Cs, dev)
+    bad, t1 = 0, time.perf_counter()
+    for rep in range(sreps):
+        out.zero_()
+        out.run(core, Ms, d_blobs, d_counts, synth.STRESS_GATE_PX, 1 << 20)
+        bad += int(devcheck.compare_bitwise(out, first)["frames_differing"])
+    print(json.dumps({"mode": "64 x 256 stress frames run to run (first pass, re-submit, heavy-root search, enumeration)",
+                      "kernel": core.last_frame_kernel(), "frames_per_pass": Fs, "flagged_by_first_pass": flagged, "re_run": rerun,
+                      "frames_left_flagged": int((first.status != 0).sum().item()), "repetitions": sreps,
+                      "frame_evaluations": Fs * sreps, "frames_differing_total": bad, "wall_s": time.perf_counter() - t1}))
