@@ -88,3 +88,25 @@ if os.environ.get("SOAK_STRESS"):
                       "kernel": core.last_frame_kernel(), "frames_per_pass": Fs, "flagged_by_first_pass": flagged, "re_run": rerun,
                       "frames_left_flagged": int((first.status != 0).sum().item()), "repetitions": sreps,
                       "frame_evaluations": Fs * sreps, "frames_differing_total": bad, "wall_s": time.perf_counter() - t1}))
+if os.environ.get("SOAK_4X4"):
+    qreps = int(os.environ["SOAK_4X4"])
+    Cq, Mq, Fq, Kq = 4, 4, 1_000_000, 16
+    qrig = synth.ring_rig(Cq)
+    blobs, counts, _ = synth.make_blob_stream(qrig, Fq, Mq, seed=1)
+    d_blobs, d_counts = torch.from_numpy(blobs).to(dev), torch.from_numpy(counts).to(dev)
+    core, qwalk = capi.MocapCore(0), capi.MocapCore(0)
+    qwalk.set_options(exhaustive_walk=True)
+    for c in (core, qwalk):
+        c.set_stream(stream.cuda_stream)
+        c.set_cameras(qrig["K"], qrig["R"], qrig["t"])
+    ref = devcheck.FrameOutputs(Fq, Kq, Cq, dev)
+    ref.run(qwalk, Mq, d_blobs, d_counts, 5.0, 1 << 20)
+    out = devcheck.FrameOutputs(Fq, Kq, Cq, dev)
+    bad, t1 = 0, time.perf_counter()
+    for rep in range(qreps):
+        out.zero_()
+        out.run(core, Mq, d_blobs, d_counts, 5.0, 1 << 20)
+        bad += int(devcheck.compare_bitwise(out, ref)["frames_differing"])
+    print(json.dumps({"mode": "4 x 4, 10^6 frames per pass (three-launch schedule of one-wave workgroups) vs the walk without cut-offs",
+                      "kernel": core.last_frame_kernel(), "repetitions": qreps, "frame_evaluations": Fq * qreps,
+                      "frames_differing_total": bad, "wall_s": time.perf_counter() - t1}))
